@@ -1,0 +1,254 @@
+"""The oracle (CPU restatement) is pinned against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU-only; runs in the build container and on the GPU box."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import gast, synth
+from oracle.model import OracleDeeplabv2, param_shapes
+from oracle.step import HYPER, SGDState, ssl_step
+from oracle.weights import checksum, det_state_dict, fill_like, subsample
+
+C = 6
+
+
+def test_pseudo_selection_bit_exact():
+    g = load_golden("pseudo_selection")
+    for m, h in zip(g["masks"], g["hards"]):
+        out = gast.pseudo_selection(m, 0.8, 0.6, -1)
+        assert out.dtype == torch.int64
+        assert torch.equal(out, h)
+
+
+@pytest.mark.parametrize("mode", ["all", "s", "p", "l"])
+def test_label_refine_modes(mode):
+    g = load_golden("label_refine")
+    out = gast.label_refine(g["sup"], g["feat"], [g["p1"], g["p2"]], g["soft"], g["protos"], True, mode, 2.0)
+    torch.testing.assert_close(out, g["out_" + mode], rtol=1e-5, atol=2e-7)
+
+
+def test_label_refine_irregular_and_single_pred():
+    g = load_golden("label_refine")
+    out = gast.label_refine(g["sup_irregular"], g["feat"], [g["p1"], g["p2"]], g["soft"], g["protos"], True, "all", 2.0)
+    torch.testing.assert_close(out, g["out_all_irregular"], rtol=1e-5, atol=2e-7)
+    out = gast.label_refine(g["sup"], g["feat"], g["p1"], g["soft"], g["protos"], True, "l", 1.5)
+    torch.testing.assert_close(out, g["out_single_pred"], rtol=1e-5, atol=2e-7)
+
+
+def test_pearson_gemm_form():
+    g = load_golden("pearson")
+    torch.testing.assert_close(gast.pearson_dist(g["x"], g["protos"]), g["dist"], rtol=1e-5, atol=1e-6)
+
+
+def test_downscale_label_exact():
+    g = load_golden("downscale_label")
+    out = gast.downscale_label(g["label"], C)
+    assert torch.equal(out, g["out"])
+    assert out[0, 0, 0, 0] == 2 and out[0, 0, 1, 0] == -1 and out[1, 0, 0, 0] == -1
+
+
+def test_update_prototype_with_empty_class():
+    g = load_golden("update_prototype")
+    new, ds = gast.update_prototype(g["feat"], g["label"], g["protos_in"], C, 0.996)
+    assert torch.equal(ds, g["label_ds"])
+    torch.testing.assert_close(new, g["protos_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_losses_and_grads():
+    g = load_golden("losses")
+    l1 = g["logits1"].clone().requires_grad_(True)
+    l2 = g["logits2"].clone().requires_grad_(True)
+    loss = gast.loss_calc_uvem([l1, l2], g["hard"], g["soft"], 0.2, 0.7, 4.0, -1, C)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g["uvem"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(l1.grad, g["uvem_g1"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(l2.grad, g["uvem_g2"], rtol=1e-4, atol=1e-8)
+    l3 = g["logits1"].clone().requires_grad_(True)
+    l4 = g["logits2"].clone().requires_grad_(True)
+    ce = gast.loss_calc([l3, l4], g["label_s"], -1)
+    ce.backward()
+    torch.testing.assert_close(ce.detach(), g["ce"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(l3.grad, g["ce_g1"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(gast.uvem_weight(g["u"]), g["uvem_w"], rtol=1e-6, atol=1e-7)
+
+
+def test_class_balance_three_steps():
+    g = load_golden("class_balance")
+    cb = gast.ClassBalance(C, -1, 0.99, 2.0)
+    for lab, w in zip(g["labels"], g["weights"]):
+        torch.testing.assert_close(cb.get_class_weight_4pixel(lab), w, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(cb.freq, g["freq"], rtol=1e-6, atol=1e-8)
+
+
+def test_lr_schedule():
+    g = load_golden("lr_schedule")
+    for i, lr in zip(g["iters"].tolist(), g["lrs"].tolist()):
+        assert gast.learning_rate(i, 1e-2, int(6000 / 20), 6000 * 1.5, 0.9) == pytest.approx(lr, rel=1e-12)
+
+
+def test_scatter_semantics():
+    src = torch.tensor([[[1.0, -2.0], [3.0, -1.0], [0.5, -4.0]]])
+    idx = torch.tensor([[[2], [0], [2]]])
+    out = gast.scatter(src, idx, 1, "max")
+    assert out.shape == (1, 3, 2)
+    assert out[0, 1].tolist() == [0.0, 0.0]              # untouched segment -> 0
+    assert out[0, 2].tolist() == [1.0, -2.0] and out[0, 0].tolist() == [3.0, -1.0]
+    assert gast.scatter(src, idx, 1, "sum")[0, 2].tolist() == [1.5, -6.0]
+
+
+# ---------------- layers ---------------------------------------------------------------------------
+def _layer_model(state):
+    m = OracleDeeplabv2({}, requires_grad=False)
+    m.p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in state.items()}
+    return m
+
+
+def _check_layer(name, shapes, fn, rtol=2e-4, atol=2e-5):
+    g = load_golden(name)
+    m = _layer_model(fill_like(shapes, name))
+    x = g["x"].clone().requires_grad_(True)
+    y = fn(m, x)
+    torch.testing.assert_close(y, g["y"], rtol=rtol, atol=atol)
+    y.backward(g["gy"])
+    torch.testing.assert_close(x.grad, g["gx"], rtol=rtol * 5, atol=atol * 5)
+    for k, v in g.items():
+        if k.startswith("g:"):
+            torch.testing.assert_close(subsample(m.p[k[2:]].grad), v, rtol=rtol * 5, atol=atol * 20)
+        if k.startswith("post:"):
+            torch.testing.assert_close(m.p[k[5:]], v, rtol=1e-5, atol=1e-6)
+
+
+def _bn_shapes(prefix, c):
+    return {prefix + ".weight": (c,), prefix + ".bias": (c,), prefix + ".running_mean": (c,),
+            prefix + ".running_var": (c,), prefix + ".num_batches_tracked": ()}
+
+
+def _bott_shapes(inpl, planes, ds):
+    s = {"conv1.weight": (planes, inpl, 1, 1)}
+    s.update(_bn_shapes("bn1", planes))
+    s["conv2.weight"] = (planes, planes, 3, 3)
+    s.update(_bn_shapes("bn2", planes))
+    s["conv3.weight"] = (planes * 4, planes, 1, 1)
+    s.update(_bn_shapes("bn3", planes * 4))
+    if ds:
+        s["downsample.0.weight"] = (planes * 4, inpl, 1, 1)
+        s.update(_bn_shapes("downsample.1", planes * 4))
+    return s
+
+
+def _strip(m, prefix):
+    """oracle blocks address params as '<prefix>.conv1.weight'; fixtures use bare names."""
+    m.p = {prefix + "." + k: v for k, v in m.p.items()}
+
+
+def test_layer_bottleneck_stride2():
+    def fn(m, x):
+        _strip(m, "blk")
+        y = m._bottleneck(x, "blk", 2, 1, True)
+        m.p = {k[4:]: v for k, v in m.p.items()}
+        return y
+    _check_layer("layer_bottleneck_s2", _bott_shapes(64, 32, True), fn)
+
+
+def test_layer_bottleneck_dilation2():
+    def fn(m, x):
+        _strip(m, "blk")
+        y = m._bottleneck(x, "blk", 1, 2, False)
+        m.p = {k[4:]: v for k, v in m.p.items()}
+        return y
+    _check_layer("layer_bottleneck_d2", _bott_shapes(128, 32, False), fn)
+
+
+def test_layer_aspp():
+    shapes = {}
+    for i in range(4):
+        shapes[f"conv2d_list.{i}.weight"] = (C, 32, 3, 3)
+        shapes[f"conv2d_list.{i}.bias"] = (C,)
+
+    def fn(m, x):
+        _strip(m, "hd")
+        y = m.aspp_head(x, "hd")
+        m.p = {k[3:]: v for k, v in m.p.items()}
+        return y
+    _check_layer("layer_aspp", shapes, fn)
+
+
+def test_layer_ppm():
+    shapes = {}
+    for i in range(4):
+        shapes[f"ppm.{i}.1.weight"] = (512, 32, 1, 1)
+        shapes.update(_bn_shapes(f"ppm.{i}.2", 512))
+    shapes["conv_last.0.weight"] = (512, 32 + 2048, 3, 3)
+    shapes.update(_bn_shapes("conv_last.1", 512))
+    shapes["conv_last.4.weight"] = (C, 512, 1, 1)
+    shapes["conv_last.4.bias"] = (C,)
+
+    def fn(m, x):
+        _strip(m, "hd")
+        y = m.ppm_head(x, "hd", dropout=False)
+        m.p = {k[3:]: v for k, v in m.p.items()}
+        return y
+    _check_layer("layer_ppm", shapes, fn, rtol=1e-3, atol=1e-4)
+
+
+def test_layer_instnorm_and_stem():
+    g = load_golden("layer_instnorm")
+    x = g["x"].clone().requires_grad_(True)
+    y = F.instance_norm(x, eps=1e-5)
+    torch.testing.assert_close(y, g["y"], rtol=1e-5, atol=1e-6)
+    y.backward(g["gy"])
+    torch.testing.assert_close(x.grad, g["gx"], rtol=1e-4, atol=1e-6)
+    shapes = {"0.weight": (64, 3, 7, 7)}
+    shapes.update(_bn_shapes("1", 64))
+
+    def fn(m, x):
+        m.p = {("encoder.resnet.conv1.weight" if k == "0.weight" else "encoder.resnet.bn1" + k[1:]): v
+               for k, v in m.p.items()}
+        y = F.conv2d(x, m.p["encoder.resnet.conv1.weight"], stride=2, padding=3)
+        y = F.max_pool2d(F.relu(m._bn(y, "encoder.resnet.bn1")), 3, 2, 1)
+        m.p = {("0.weight" if k.endswith("conv1.weight") else "1" + k[len("encoder.resnet.bn1"):]): v
+               for k, v in m.p.items()}
+        return y
+    _check_layer("layer_stem", shapes, fn)
+
+
+# ---------------- full model + one SSL step (B=2, 256^2: BASELINE config 1) ------------------------------
+@pytest.mark.parametrize("tag", ["aspp", "ppm"])
+def test_full_model_ssl_step(tag):
+    use_ppm = tag == "ppm"
+    g = load_golden(f"model_{tag}_r50_b2_256")
+    sd = det_state_dict("resnet50", C, use_ppm, seed=2333)
+    assert list(sd.keys()) == list(param_shapes("resnet50", C, use_ppm).keys())
+    assert len(sd) == (382 if use_ppm else 334)
+    model = OracleDeeplabv2(sd, "resnet50", C, use_ppm)
+    batch = synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333)
+    model.eval()
+    with torch.no_grad():
+        prob = model(batch["images_t"])
+    torch.testing.assert_close(prob[:, :, ::8, ::8], g["eval_prob_sample"], rtol=1e-4, atol=1e-6)
+    opt = SGDState(model.parameters(), HYPER["momentum"], HYPER["weight_decay"])
+    out = ssl_step(model, opt, batch["prototypes"], batch, float(g["lr"]), HYPER, dropout=False)
+    torch.testing.assert_close(out["pred_s1"], g["pred_s1"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["pred_t2"], g["pred_t2"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["feat_t"].reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["label_t_soft"][:, :, ::4, ::4], g["soft_sample"], rtol=1e-4, atol=1e-6)
+    agree = (out["label_t_hard"] == g["hard"].long()).float().mean().item()
+    assert agree >= 0.9999, agree
+    torch.testing.assert_close(out["loss_source"], g["loss_source"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["loss_target"], g["loss_target"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["prototypes"], g["prototypes"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["grad_norm"], g["grad_norm"], rtol=1e-3, atol=1e-5)
+    named = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad:"):
+            # fixture grads are views taken before clip_grad_norm_ scaled them in place => post-clip
+            torch.testing.assert_close(subsample(named[k[5:]].grad), v, rtol=2e-2, atol=2e-5)
+    s, a = checksum(model.parameters())
+    assert s == pytest.approx(float(g["post_checksum"][0]), rel=1e-5, abs=1e-2)
+    assert a == pytest.approx(float(g["post_checksum"][1]), rel=1e-6)
+    torch.testing.assert_close(model.p["encoder.resnet.bn1.running_mean"], g["post_bn1_running_mean"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(model.p["encoder.resnet.layer4.2.bn3.running_var"], g["post_l4_bn3_running_var"], rtol=1e-4, atol=1e-6)
+    assert int(model.p["encoder.resnet.bn1.num_batches_tracked"]) == int(g["nbt"]) == 2
