@@ -1,0 +1,211 @@
+/*
+ * uemda_hip.h -- C ABI of libuemda_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * UemDA hot path.  The reference has no FFI of its own: its "operator surface"
+ * is Python calling third-party native kernels (cuDNN through torch, torch_scatter).  Every entry
+ * point below replaces one such native call site; the reference file:line it replaces is cited.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocations); the library
+ *     allocates nothing and keeps no state; all launches are asynchronous on `stream`
+ *     (a hipStream_t passed as void*), safe for hipGraph capture.
+ *   - return value: 0 = launched, <0 = error (UEM_ERR_*); never throws, never syncs.
+ *   - activations are NHWC fp32 ("channels_last"): x[n][y][x][c]; conv weights are OHWI fp32:
+ *     w[o][ky][kx][i]  (= torch OIHW tensor in channels_last memory format).
+ *   - full-resolution class maps (soft labels) are NCHW planar fp32; label maps are int64.
+ */
+#ifndef UEMDA_HIP_H
+#define UEMDA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UEM_OK 0
+#define UEM_ERR_INVALID (-1)     /* bad shape / null pointer / misalignment */
+#define UEM_ERR_UNSUPPORTED (-2) /* configuration outside what the kernels cover */
+#define UEM_ERR_LAUNCH (-3)      /* hipGetLastError() != success after the launch */
+
+#define UEM_MAX_CLASSES 16
+
+int uem_version(void);
+const char* uem_last_error(void);
+
+/* ---- convolution: implicit GEMM on f32-input MFMA (v_mfma_f32_32x32x2_f32) ---------------------
+ * replaces cuDNN conv fwd/dgrad/wgrad behind nn.Conv2d at _resnets.py:95-110,149,209 and
+ * Encoder.py:74-75,81-83 (ASPP), Encoder.py:19,35-36,40 (PPM).                                   */
+typedef struct {
+    int N, H, W, Cin;      /* input  x[N][H][W][Cin]                      */
+    int Ho, Wo, Cout;      /* output y[N][Ho][Wo][Cout]                   */
+    int KH, KW;            /* filter taps                                 */
+    int stride, pad, dil;  /* same in both spatial dims                   */
+    int x_ld, y_ld;        /* channel stride (floats) of one pixel in x / y: >= Cin / Cout; lets a
+                              conv read / write a channel slice of a wider NHWC tensor (PPM concat) */
+} uem_conv_shape;
+
+/* flags for uem_conv2d_fwd / wgrad */
+#define UEM_CONV_IN_AFFINE 1   /* operand prologue: x' = x*in_scale[c] + in_shift[c]  (fused BN apply) */
+#define UEM_CONV_IN_RELU 2     /* operand prologue: x' = max(x', 0)                                  */
+#define UEM_CONV_ACCUMULATE 4  /* epilogue: y += result (ASPP branch sum, Encoder.py:83)               */
+#define UEM_CONV_TRANSPOSED 8  /* gather of the data-gradient of a strided conv: shape describes the
+                                  FORWARD conv, x is dY (N,Ho,Wo,Cout), y is dX (N,H,W,Cin), w is
+                                  W'[Cin][KH][KW][Cout] (uem_weight_transpose of the forward weights) */
+
+/* y = conv(x', w) (+ bias).  w: [Cout][KH][KW][Cin].  Requires Cin % 32 == 0 except the 7x7 stem,
+ * which is expressed as KH=7, KW=1, Cin=32 over an NHWC4 image (see uem_stem_pack_*).             */
+int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
+                   const float* in_shift, float* y, const uem_conv_shape* s, int flags, void* stream);
+/* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
+int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
+/* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */
+int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift,
+                     float* dw, const uem_conv_shape* s, int flags, void* stream);
+int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw8, int N, int H, int W, void* stream);
+/* weight re-layouts (tiny): transposed copy for dgrad; stem pack / unpack-add                     */
+int uem_weight_transpose(const float* w /*[Cout][KH][KW][Cin]*/, float* wt /*[Cin][KH][KW][Cout]*/, int Cout,
+                         int KH, int KW, int Cin, void* stream);
+int uem_stem_pack_weight(const float* w_ohwi /*[64][7][7][3]*/, float* w8, void* stream);
+int uem_stem_unpack_grad(const float* dw8, float* dw_ohwi /* += */, void* stream);
+int uem_nchw3_to_nhwc4(const float* x, float* x4, int N, int H, int W, void* stream);
+int uem_bias_grad(const float* dy, float* db /* += */, int M, int C, int ld, void* stream);
+
+/* ---- BatchNorm2d (training + eval), fused ReLU / residual -- _resnets.py:96-110, Encoder.py:20,37 --
+ * stats: per-channel batch mean / biased var of x[M][C]; also updates running stats
+ * (momentum, unbiased var) when running_mean != NULL; writes scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale (the conv prologue operands) and save_mean / save_invstd.            */
+int uem_bn_stats(const float* x, int M, int C, int ld, const float* gamma, const float* beta,
+                 float eps, float momentum, float* running_mean, float* running_var,
+                 float* save_mean, float* save_invstd, float* scale, float* shift,
+                 float* workspace /* >= 3*C*UEM_BN_SPLIT floats */, void* stream);
+#define UEM_BN_SPLIT 64
+int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
+/* y = act(x*scale + shift (+ r)); r = res, or res*res_scale + res_shift (downsample branch BN) when
+ * res_scale != NULL; act = relu if relu != 0.  In place allowed (y == x).                         */
+int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
+                   const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
+                   void* stream);
+/* backward of y = relu?(bn(x) (+res)):  given dy (grad wrt y).  relu mask: (ymask > 0) when ymask (the
+ * materialised y) is given, else (x*scale+shift > 0) recomputed (operand-prologue layers).
+ * pass 1: dgamma[c] = sum dp*xhat, dbeta[c] = sum dp   (dp = dy masked by relu)
+ * pass 2: dx = scale*(dp - dbeta/M - xhat*dgamma/M);  dres (optional) = dp                         */
+int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+                      const float* save_mean, const float* save_invstd, int M, int C, int relu,
+                      float* dgamma /* = */, float* dbeta /* = */, float* workspace, void* stream);
+int uem_bn_bwd_apply(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+                     const float* save_mean, const float* save_invstd, const float* dgamma,
+                     const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
+/* eval-mode / frozen-stat backward: dx = dp * scale                                              */
+int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, const float* scale,
+                       const float* shift, int64_t M, int C, int relu, float* dx, float* dres, void* stream);
+
+/* ---- MaxPool 3x3 s2 p1 (_resnets.py:153), InstanceNorm2d (Encoder.py:123,147) ---------------------- */
+int uem_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx /* argmax tap 0..8, may be NULL */, int N, int H,
+                         int W, int C, void* stream);
+int uem_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx /* = */, int N, int H, int W, int C,
+                         void* stream);
+int uem_instnorm_fwd(const float* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,
+                     float eps, void* stream);
+int uem_instnorm_bwd(const float* y, const float* dy, const float* save_invstd, float* dx, int N, int HW,
+                     int C, void* stream);
+/* ---- PPM head pieces: adaptive avg-pool + bilinear (align_corners=False) (Encoder.py:18,48-51) ------ */
+int uem_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int S, void* stream);
+int uem_adaptive_avgpool_bwd(const float* dy, float* dx /* += */, int N, int H, int W, int C, int S, void* stream);
+int uem_bilinear_up_fwd(const float* x, float* y, int N, int h, int w, int C, int H, int W, int y_ld,
+                        int align_corners, const float* scale, const float* shift, int relu, void* stream);
+int uem_bilinear_up_bwd(const float* dy, float* dx /* = */, int N, int h, int w, int C, int H, int W, int dy_ld,
+                        int align_corners, void* stream);
+int uem_dropout2d(const float* x, float* y, float* mask /*[N][C]*/, int N, int HW, int C, float p,
+                  uint64_t seed, void* stream);
+int uem_add_inplace(float* a, const float* b, int64_t n, void* stream);
+int uem_nhwc_to_nchw(const float* x, float* y, int N, int HW, int C, void* stream);
+int uem_nchw_to_nhwc(const float* x, float* y, int N, int HW, int C, void* stream);
+
+/* ---- pseudo-label mining ------------------------------------------------------------------------
+ * pearson_sim: sim[n][c] = 1 / pearson_dist(feat[n][:], protos[c][:])       alignment.py:216,424-451
+ *   feat is NHWC (n = B*h*w rows of k floats), protos [C][k].                                      */
+int uem_pearson_sim(const float* feat, const float* protos, float* sim, float* workspace /* C*k+C floats */,
+                    int n, int k, int C, void* stream);
+int uem_pearson_dist(const float* a, const float* b, float* dist, float* workspace /* m*k+m floats */, int n,
+                     int m, int k, void* stream);
+/* batch-global max of an int64 index map -> *out (device)                   alignment.py:241       */
+int uem_index_max(const int64_t* idx, int64_t count, int64_t* out, void* stream);
+/* torch_scatter.scatter(src, index, dim=1, reduce) for src (B,N,C) / index (B,N,1)
+ * alignment.py:187,245.  reduce: 0 = max, 1 = sum, 2 = mean.  out (B,S,C) is fully written.        */
+int uem_scatter(const float* src, const int64_t* index, float* out, float* workspace /* B*S floats */,
+                int B, int N, int C, int S, int reduce, void* stream);
+/* per-superpixel max of an NCHW-planar soft label: seg_keys[b][s][c] (order-preserving uint keys,
+ * caller zero-fills), LDS-table pre-reduction per 64x16 pixel tile.         alignment.py:244-245   */
+int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_keys, int B, int C,
+                           int H, int W, int S, void* stream);
+/* fused three-view refinement (alignment.py:209-293) for modes all / s / p / l:
+ *   soft_out = normalise( weight * soft ), and per-(b,c) max of soft_out into plane_max (uint bits of
+ *   non-negative floats, caller zero-fills) for the selection pass.  sim / logits are (B,h,w,C).    */
+#define UEM_REFINE_ALL 0
+#define UEM_REFINE_S 1
+#define UEM_REFINE_P 2
+#define UEM_REFINE_L 3
+int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
+                     const float* logits2 /* may be NULL */, const uint32_t* seg_keys,
+                     const int64_t* ignore_id /* device */, float* soft_out, uint32_t* plane_max,
+                     int B, int C, int h, int w, int H, int W, int S, float temp, int mode, void* stream);
+/* per-(b,c) max over H*W of an NCHW map                                pseudo_generation.py:76     */
+int uem_plane_max(const float* mask, uint32_t* plane_max, int B, int C, int64_t HW, void* stream);
+/* hard[b][p] = the unique c with mask > max(cutoff_top*max_c, cutoff_low), else ignore
+ * pseudo_generation.py:76-88.  range_flag (device int, caller zero-fills) is set to 1 if any value
+ * is outside [0,1] (the reference asserts, pseudo_generation.py:71).                               */
+int uem_pseudo_select(const float* mask, const uint32_t* plane_max, int64_t* hard, int* range_flag, int B,
+                      int C, int64_t HW, float cutoff_top, float cutoff_low, int64_t ignore_label, void* stream);
+/* DownscaleLabel: majority vote over scale x scale cells             alignment.py:484-509          */
+int uem_downscale_label(const int64_t* label, int64_t* out, int B, int H, int W, int scale, int n_classes,
+                        int64_t ignore_label, float min_ratio, void* stream);
+/* class-masked feature sums: sums[c][k], counts[c]                    alignment.py:340-348         */
+int uem_proto_sums(const float* feat, const int64_t* label_ds, float* sums, float* counts,
+                   float* workspace /* >= UEM_PROTO_SPLIT*C*k + UEM_PROTO_SPLIT*C floats */, int n, int k,
+                   int C, int64_t ignore_label, void* stream);
+#define UEM_PROTO_SPLIT 256
+/* local = sums/(n+eps) (kept where n<1); protos = (1-decay)*local + decay*protos   alignment.py:348-353 */
+int uem_proto_ema(const float* sums, const float* counts, float* protos, int k, int C, float decay, void* stream);
+
+/* ---- losses: bilinear(align_corners=True) upsample + CE / UVEM, forward AND backward in one pass -------
+ * logits are low-res (B,h,w,C); the full-resolution logits are never materialised.
+ * CE (tools.py:240-254 + balance.py:88-101): loss = mean over ALL pixels of CE(ignore);
+ *   dlogits (B,h,w,C) receives d(loss*loss_scale)/dlogits (gather form: written, not accumulated,
+ *   deterministic).  partial: >= 4*uem_loss_blocks(B,h,w) + 4 floats of workspace.                */
+int uem_ce_upsampled(const float* logits1, const float* logits2 /* NULL: one head */, const int64_t* label,
+                     const float* pixel_weight /* NULL */, float* loss_out /* [1] = mean over heads */,
+                     float* dlogits1, float* dlogits2, float* partial, int B, int C, int h, int w, int H, int W,
+                     int64_t ignore_label, float loss_scale, void* stream);
+/* UVEM (balance.py:356-423,437-451): u = entropy(soft); gate u>t; weight w(u); CE on `hard`;
+ *   loss = sum(w*ce) / (#{u<=t & hard!=ignore} + 1e-7).  One call handles BOTH heads (logits2 may
+ *   be NULL): loss_out[0] = mean over heads; dlogits1/2 get the gradient of loss*loss_scale.      */
+int uem_uvem_upsampled(const float* logits1, const float* logits2, const int64_t* hard, const float* soft,
+                       const float* pixel_weight /* NULL */, float* loss_out, float* dlogits1,
+                       float* dlogits2, float* partial, int B, int C, int h, int w, int H, int W,
+                       float m, float t, float gamma, int64_t ignore_label, float loss_scale, void* stream);
+int uem_loss_blocks(int B, int h, int w); /* = B*h*w: one gather block per low-res cell */
+/* a[i] *= *scalar (and b[i] when b != NULL); scalar lives on the device (no host sync)             */
+int uem_scale_by_scalar(float* a, float* b, int64_t n, const float* scalar, void* stream);
+/* eval-mode output: (softmax(up(x1)) + softmax(up(x2)))/2 -> NCHW prob        Encoder.py:153-155   */
+int uem_upsample_softmax_avg(const float* logits1, const float* logits2, float* prob, int B, int C, int h,
+                             int w, int H, int W, void* stream);
+/* uvem sample weight w(u) on a vector (UVEMLoss.get_weight, balance.py:396-423)                    */
+int uem_uvem_weight(const float* u, float* w, int64_t n, float m, float t, float gamma, void* stream);
+/* class histogram of a label map (ClassBalance._local_freq, balance.py:45-53): counts[C+1] (+=)     */
+int uem_class_count(const int64_t* label, int64_t n, int C, int64_t ignore_label, float* counts, void* stream);
+int uem_class_weight_gather(const int64_t* label, const float* class_w, float* out, int64_t n, int C,
+                            int64_t ignore_label, void* stream);
+
+/* ---- optimizer: clip_grad_norm_(max_norm, L2) + SGD(momentum, weight_decay) over a flat arena ----------
+ * train_ssl_uem.py:169-170,228-232.  sqnorm: partial sums (>= UEM_NORM_BLOCKS floats) -> norm_out[0].  */
+#define UEM_NORM_BLOCKS 1024
+int uem_grad_sqnorm(const float* grad, int64_t n, float* partial, float* norm_out, void* stream);
+int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n, const float* norm /* device */,
+                      float max_norm, float lr, float momentum, float weight_decay, int first_step,
+                      float grad_prescale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UEMDA_HIP_H */

@@ -1,0 +1,181 @@
+"""GPU parity of the mining / loss kernels against the oracle and the reference goldens (through the C ABI)."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+C = 6
+
+
+def dev(t):
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def aligner():
+    from uemda_amd.gast.alignment import Aligner
+    return Aligner(None, feat_channels=64, class_num=C, ignore_label=-1, decay=0.996)
+
+
+def test_native_library_is_the_one_running():
+    from uemda_amd import _lib
+    assert _lib.load().uem_version() >= 100
+
+
+def test_pseudo_selection_golden_bit_exact():
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    g = load_golden("pseudo_selection")
+    for m, h in zip(g["masks"], g["hards"]):
+        out = pseudo_selection(dev(m), 0.8, 0.6, "tensor", -1)
+        assert out.dtype == torch.int64
+        assert torch.equal(out.cpu(), h)
+    assert pseudo_selection(dev(g["masks"][0]), return_type="ndarray").shape == (2, 64, 64)
+    with pytest.raises(AssertionError):
+        pseudo_selection(dev(g["masks"][0]) * 3.0, return_type="tensor")
+
+
+def test_pearson_golden(aligner):
+    g = load_golden("pearson")
+    d = aligner._pearson_dist(dev(g["x"]), dev(g["protos"]))
+    torch.testing.assert_close(d.cpu(), g["dist"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["all", "s", "p", "l"])
+def test_label_refine_golden(aligner, mode):
+    g = load_golden("label_refine")
+    aligner.prototypes = dev(g["protos"]).contiguous()
+    aligner._sup_capacity = 0
+    out = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]), True, mode, 2.0)
+    torch.testing.assert_close(out.cpu(), g["out_" + mode], rtol=2e-5, atol=1e-6)
+
+
+def test_label_refine_irregular_single_pred_and_explicit_ignore(aligner):
+    g = load_golden("label_refine")
+    aligner.prototypes = dev(g["protos"]).contiguous()
+    aligner._sup_capacity = 0
+    out = aligner.label_refine(dev(g["sup_irregular"]), dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]), True, "all", 2.0)
+    torch.testing.assert_close(out.cpu(), g["out_all_irregular"], rtol=2e-5, atol=1e-6)
+    out = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), dev(g["p1"]), dev(g["soft"]), True, "l", 1.5)
+    torch.testing.assert_close(out.cpu(), g["out_single_pred"], rtol=2e-5, atol=1e-6)
+    out = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]), True, "all", 2.0,
+                               sup_ignore_id=int(g["sup"].max()))
+    torch.testing.assert_close(out.cpu(), g["out_all"], rtol=2e-5, atol=1e-6)
+    same = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), dev(g["p1"]), dev(g["soft"]), refine=False)
+    assert torch.equal(same.cpu(), g["soft"])
+
+
+def test_downscale_label_golden():
+    from uemda_amd.gast.alignment import DownscaleLabel
+    g = load_golden("downscale_label")
+    out = DownscaleLabel(16, C, -1, 0.75)(dev(g["label"]))
+    assert torch.equal(out.cpu(), g["out"])
+
+
+def test_update_prototype_golden(aligner):
+    g = load_golden("update_prototype")
+    aligner.prototypes = dev(g["protos_in"]).contiguous().clone()
+    ds = aligner.update_prototype(dev(g["feat"]), dev(g["label"]))
+    assert torch.equal(ds.cpu(), g["label_ds"])
+    torch.testing.assert_close(aligner.prototypes.cpu(), g["protos_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_losses_golden_forward_and_backward():
+    from uemda_amd.gast.balance import CrossEntropy, UVEMLoss, loss_calc_uvem
+    from uemda_amd.utils.tools import loss_calc
+    g = load_golden("losses")
+    l1 = dev(g["logits1"]).requires_grad_(True)
+    l2 = dev(g["logits2"]).requires_grad_(True)
+    uv = UVEMLoss(m=0.2, threshold=0.7, gamma=4, class_num=C, ignore_label=-1)
+    loss = loss_calc_uvem([l1, l2], dev(g["hard"]), dev(g["soft"]), uv, multi=True)
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g["uvem"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(l1.grad.cpu(), g["uvem_g1"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(l2.grad.cpu(), g["uvem_g2"], rtol=1e-4, atol=1e-8)
+    l3 = dev(g["logits1"]).requires_grad_(True)
+    l4 = dev(g["logits2"]).requires_grad_(True)
+    ce = loss_calc([l3, l4], dev(g["label_s"]), CrossEntropy(ignore_label=-1), multi=True)
+    (ce * 2.0).backward()                       # exercises the grad_output scaling path
+    torch.testing.assert_close(ce.detach().cpu(), g["ce"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(l3.grad.cpu(), 2.0 * g["ce_g1"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(l4.grad.cpu(), 2.0 * g["ce_g2"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(uv.get_weight(dev(g["u"])).cpu(), g["uvem_w"], rtol=1e-5, atol=1e-6)
+
+
+def test_class_balance_golden():
+    from uemda_amd.gast.balance import ClassBalance
+    g = load_golden("class_balance")
+    cb = ClassBalance(C, -1, 0.99, 2.0)
+    for lab, w in zip(g["labels"], g["weights"]):
+        torch.testing.assert_close(cb.get_class_weight_4pixel(dev(lab)).cpu(), w, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(cb.freq.cpu(), g["freq"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("reduce", ["max", "sum", "mean"])
+def test_scatter_matches_oracle(reduce):
+    from oracle import gast
+    from uemda_amd.scatter import scatter
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(3, 1000, 5, generator=g)            # negative values exercise the ordered-key max
+    idx = torch.randint(0, 37, (3, 1000, 1), generator=g)
+    idx[idx == 11] = 12                                   # leave a segment untouched -> 0
+    out = scatter(dev(src), dev(idx), dim=1, reduce=reduce)
+    ref = gast.scatter(src, idx, 1, reduce)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_ragged_and_empty_edges():
+    """non-multiple-of-tile sizes, a batch with every pixel ignored, all-ignored superpixels."""
+    from oracle import gast, synth
+    from uemda_amd.gast.alignment import Aligner, DownscaleLabel
+    from uemda_amd.gast.balance import CrossEntropy
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    from uemda_amd.utils.tools import loss_calc
+    b = synth.make_batch(B=3, H=80, W=48, C=C, k=64, seed=4)      # H, W not multiples of 64
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(3, 64, 5, 3, generator=g)
+    p1, p2 = torch.randn(3, C, 5, 3, generator=g), torch.randn(3, C, 5, 3, generator=g)
+    al = Aligner(None, 64, C, -1, 0.996)
+    al.prototypes = dev(b["prototypes"]).contiguous()
+    soft_ref = gast.label_refine(b["label_t_sup"], feat, [p1, p2], b["label_t_soft"], b["prototypes"])
+    soft, hard = al.refine_and_select(dev(b["label_t_sup"]), dev(feat), [dev(p1), dev(p2)], dev(b["label_t_soft"]))
+    torch.testing.assert_close(soft.cpu(), soft_ref, rtol=2e-5, atol=1e-6)
+    assert torch.equal(hard.cpu(), gast.pseudo_selection(soft.cpu()))       # bit-exact given identical soft input
+    assert torch.equal(pseudo_selection(soft, return_type="tensor").cpu(), hard.cpu())
+    all_ign = torch.full((2, 32, 32), -1, dtype=torch.int64)
+    assert (DownscaleLabel(16, C)(dev(all_ign)).cpu() == -1).all()
+    lg = torch.randn(2, C, 2, 2)
+    loss = loss_calc([dev(lg).requires_grad_(True)], dev(all_ign), CrossEntropy(-1), multi=True)
+    assert float(loss) == 0.0
+    sup_all_ign = torch.full((3, 1, 80, 48), 7, dtype=torch.int64)
+    al._sup_capacity = 0
+    out = al.label_refine(dev(sup_all_ign), dev(feat), [dev(p1), dev(p2)], dev(b["label_t_soft"]))
+    ref = gast.label_refine(sup_all_ign, feat, [p1, p2], b["label_t_soft"], b["prototypes"])
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=1e-6)
+
+
+def test_mining_at_benchmark_tile_size_vs_oracle_and_properties():
+    """512x512 tiles (BASELINE configs 2-3): B=2 against the oracle, then size-independent properties."""
+    from oracle import gast, synth
+    from uemda_amd.gast.alignment import Aligner
+    b = synth.make_batch(B=2, H=512, W=512, C=C, k=2048, seed=11)
+    g = torch.Generator().manual_seed(2)
+    feat = torch.randn(2, 2048, 32, 32, generator=g)
+    p1, p2 = 2 * torch.randn(2, C, 32, 32, generator=g), 2 * torch.randn(2, C, 32, 32, generator=g)
+    al = Aligner(None, 2048, C, -1, 0.996)
+    al.prototypes = dev(b["prototypes"]).contiguous()
+    soft, hard = al.refine_and_select(dev(b["label_t_sup"]), dev(feat), [dev(p1), dev(p2)], dev(b["label_t_soft"]))
+    ref = gast.label_refine(b["label_t_sup"], feat, [p1, p2], b["label_t_soft"], b["prototypes"])
+    torch.testing.assert_close(soft.cpu(), ref, rtol=5e-5, atol=2e-6)
+    ref_hard = gast.pseudo_selection(ref)
+    # end to end a pixel within 1 ulp of its threshold may flip: compare with a margin mask
+    thr = torch.maximum(ref.flatten(2).max(-1)[0] * 0.8, torch.tensor(0.6)).view(2, C, 1, 1)
+    safe = ((ref - thr).abs() > 1e-5).all(dim=1)
+    assert torch.equal(hard.cpu()[safe], ref_hard[safe]) and safe.float().mean() > 0.999
+    assert torch.equal(hard.cpu(), gast.pseudo_selection(soft.cpu()))       # exact on identical input
+    s = soft.sum(dim=1)
+    assert ((s - 1).abs() < 1e-5).all() and (soft >= 0).all()               # normalised probabilities
+    protos_ref, ds_ref = gast.update_prototype(feat, b["label_s"], b["prototypes"], C, 0.996)
+    ds = al.update_prototype(dev(feat), dev(b["label_s"]))
+    assert torch.equal(ds.cpu(), ds_ref)
+    torch.testing.assert_close(al.prototypes.cpu(), protos_ref, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,301 @@
+"""GPU parity of the convolution / normalisation kernels, the residual blocks and the full network
+against torch-CPU fp32 references, the oracle and the reference goldens (through the C ABI)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+C = 6
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).cpu()
+
+
+def ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 16, 16, 64, 64, 1, 1, 0, 1),
+    (2, 16, 16, 64, 256, 1, 1, 0, 1),
+    (2, 17, 13, 128, 128, 3, 1, 1, 1),       # ragged M
+    (2, 16, 16, 128, 128, 3, 2, 1, 1),
+    (2, 16, 16, 256, 512, 1, 2, 0, 1),
+    (1, 12, 12, 512, 512, 3, 1, 2, 2),
+    (2, 16, 16, 64, 32, 3, 1, 6, 6),         # ASPP-like: big dilation, N-tile 32
+    (2, 8, 8, 32, 64, 3, 1, 12, 12),
+    (3, 2, 2, 2048, 512, 1, 1, 0, 1),        # tiny M (PPM branch)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(case):
+    from uemda_amd import ops
+    N, H, W, Cin, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g)
+    y_ref = F.conv2d(x, w, bias, stride=s, padding=p, dilation=d)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y = ops.conv2d(nhwc(x.detach()), ohwi(w.detach()), bias.cuda(), stride=s, pad=p, dil=d)
+    torch.testing.assert_close(nchw(y), y_ref.detach(), rtol=1e-4, atol=1e-4)
+    dx = ops.conv2d_dgrad(nhwc(gy), ops.weight_transpose(ohwi(w.detach())), (N, H, W, Cin), stride=s, pad=p, dil=d)
+    torch.testing.assert_close(nchw(dx), x.grad, rtol=1e-4, atol=1e-4)
+    dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+    ops.conv2d_wgrad(nhwc(x.detach()), nhwc(gy), dw, stride=s, pad=p, dil=d)
+    torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), w.grad, rtol=1e-4, atol=2e-4 * gy.numel() ** 0.5 / 16)
+    # accumulate epilogue
+    y2 = ops.conv2d(nhwc(x.detach()), ohwi(w.detach()), None, stride=s, pad=p, dil=d, out=y.clone(), accumulate=True)
+    torch.testing.assert_close(nchw(y2), 2 * y_ref.detach() - bias.view(1, -1, 1, 1), rtol=1e-4, atol=2e-4)
+
+
+def test_conv_operand_prologue_affine_relu():
+    from uemda_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 12, 12, generator=g)
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    xa = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xa, wr, padding=1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y = ops.conv2d(nhwc(x), ohwi(w), None, pad=1, in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True)
+    torch.testing.assert_close(nchw(y), y_ref.detach(), rtol=1e-4, atol=1e-4)      # zero padding stays zero
+    dw = torch.zeros(128, 3, 3, 64, device="cuda")
+    ops.conv2d_wgrad(nhwc(x), nhwc(gy), dw, pad=1, in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True)
+    torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_stem_conv_and_wgrad():
+    from uemda_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 3, 38, 26, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 12).requires_grad_(True)
+    y_ref = F.conv2d(x, w, stride=2, padding=3)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    x4 = ops.nchw3_to_nhwc4(x.cuda())
+    y = ops.stem_conv(x4, ohwi(w.detach()))
+    torch.testing.assert_close(nchw(y), y_ref.detach(), rtol=1e-4, atol=1e-4)
+    dw = torch.zeros(64, 7, 7, 3, device="cuda")
+    ops.stem_wgrad(x4, nhwc(gy), dw)
+    torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), w.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("Cn,M", [(64, 1000), (256, 77), (2048, 300), (128, 40000)])
+def test_batchnorm_stats_apply_backward(Cn, M):
+    from uemda_amd import ops
+    g = torch.Generator().manual_seed(Cn + M)
+    x = (torch.randn(M, Cn, generator=g) * 2 + 5).requires_grad_(True)     # mean >> 0 stresses the variance
+    gamma = (torch.rand(Cn, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cn, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(Cn, generator=g), torch.rand(Cn, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.relu(F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    gy = torch.randn(M, Cn, generator=g)
+    y_ref.backward(gy)
+    xd, rmd, rvd = x.detach().cuda(), rm.cuda(), rv.cuda()
+    st = ops.bn_stats(xd.view(1, 1, M, Cn), gamma.detach().cuda(), beta.detach().cuda(), rmd, rvd, True)
+    y = ops.affine_act(xd, st, relu=True)
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-4, atol=1e-6)
+    gg, gb = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
+    for ymask in (None, y):                               # recomputed mask and materialised mask agree
+        gg.zero_(), gb.zero_()
+        dx = ops.bn_backward(xd, gy.cuda(), st, gg, gb, ymask=ymask, relu=True)
+        torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(gg.cpu(), gamma.grad, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(gb.cpu(), beta.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_maxpool_and_instnorm_vs_torch():
+    from uemda_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = F.relu(torch.randn(2, 64, 19, 14, generator=g)).requires_grad_(True)    # relu => many ties at 0
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    y, idx = ops.maxpool_fwd(nhwc(x.detach()), True)
+    assert torch.equal(nchw(y), y_ref.detach())
+    dx = ops.maxpool_bwd(nhwc(gy), idx, (2, 19, 14, 64))
+    torch.testing.assert_close(nchw(dx), x.grad, rtol=1e-6, atol=1e-6)
+    gi = load_golden("layer_instnorm")
+    xi = gi["x"]
+    xi2 = torch.cat([xi, xi], 1)                           # 64 channels
+    yi, inv = ops.instnorm_fwd(nhwc(xi2))
+    torch.testing.assert_close(nchw(yi)[:, :32], gi["y"], rtol=1e-5, atol=1e-6)
+    dxi = ops.instnorm_bwd(yi, nhwc(torch.cat([gi["gy"], gi["gy"]], 1)), inv)
+    torch.testing.assert_close(nchw(dxi)[:, :32], gi["gx"], rtol=1e-4, atol=1e-6)
+
+
+# ---------------- layer goldens from the reference ---------------------------------------------------------
+def _load_into(module, shapes_tag):
+    from oracle.weights import fill_like
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    module.load_state_dict(fill_like(shapes, shapes_tag))
+    return module
+
+
+class _Holder(torch.nn.Module):
+    """gives a lone block the flat arenas the full model normally provides"""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def flatten(self):
+        from uemda_amd.models.Encoder import Deeplabv2
+        Deeplabv2._flatten_parameters(self)
+        return self
+
+
+def _check_block(name, blk, rtol=2e-4, atol=5e-5):
+    from oracle.weights import subsample
+    g = load_golden(name)
+    _load_into(blk, name)
+    holder = _Holder(blk).cuda().flatten()
+    blk.train()
+    x = nhwc(g["x"]).requires_grad_(True)
+    y = blk(x)
+    torch.testing.assert_close(nchw(y.detach()), g["y"], rtol=rtol, atol=atol)
+    y.backward(nhwc(g["gy"]))
+    torch.testing.assert_close(nchw(x.grad), g["gx"], rtol=rtol * 10, atol=atol * 10)
+    named = dict(blk.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g:"):
+            torch.testing.assert_close(subsample(named[k[2:]].grad.cpu().contiguous()), v, rtol=rtol * 10, atol=atol * 40)
+    sd = blk.state_dict()
+    for k, v in g.items():
+        if k.startswith("post:"):
+            torch.testing.assert_close(sd[k[5:]].cpu(), v, rtol=1e-4, atol=1e-5)
+    return holder
+
+
+def test_layer_bottleneck_stride2_golden():
+    import torch.nn as nn
+    from uemda_amd.resnet import Bottleneck
+    ds = nn.Sequential(nn.Conv2d(64, 128, 1, 2, bias=False), nn.BatchNorm2d(128))
+    _check_block("layer_bottleneck_s2", Bottleneck(64, 32, stride=2, downsample=ds))
+
+
+def test_layer_bottleneck_dilation2_golden():
+    from uemda_amd.resnet import Bottleneck
+    _check_block("layer_bottleneck_d2", Bottleneck(128, 32, dilation=2))
+
+
+def test_layer_aspp_golden():
+    from uemda_amd.models import blocks
+    from uemda_amd.models.Encoder import Classifier_Module
+    from oracle.weights import subsample
+    g = load_golden("layer_aspp")
+    head = _load_into(Classifier_Module(32, [6, 12, 18, 24], [6, 12, 18, 24], C), "layer_aspp")
+    holder = _Holder(head).cuda().flatten()
+    x = nhwc(g["x"]).requires_grad_(True)
+    x1, x2 = blocks.ASPPHeadsFn.apply(x, head, head, *list(head.parameters()))     # same head twice
+    torch.testing.assert_close(nchw(x1.detach()), g["y"], rtol=2e-4, atol=5e-5)
+    torch.testing.assert_close(nchw(x2.detach()), g["y"], rtol=2e-4, atol=5e-5)
+    (x1 * nhwc(g["gy"])).sum().backward()
+    torch.testing.assert_close(nchw(x.grad), g["gx"], rtol=2e-3, atol=5e-4)
+    for k, v in g.items():
+        if k.startswith("g:"):
+            torch.testing.assert_close(subsample(dict(head.named_parameters())[k[2:]].grad.cpu().contiguous()), v, rtol=2e-3, atol=2e-3)
+
+
+def test_layer_stem_golden():
+    from uemda_amd.models import blocks
+    from uemda_amd.resnet import ResNet
+    from oracle.weights import fill_like, subsample
+    g = load_golden("layer_stem")
+    net = ResNet([1, 1, 1, 1])
+    shapes = {"0.weight": (64, 3, 7, 7), "1.weight": (64,), "1.bias": (64,), "1.running_mean": (64,),
+              "1.running_var": (64,), "1.num_batches_tracked": ()}
+    sd = fill_like(shapes, "layer_stem")
+    net.conv1.weight.data.copy_(sd["0.weight"])
+    for a, b in (("weight", "1.weight"), ("bias", "1.bias"), ("running_mean", "1.running_mean"), ("running_var", "1.running_var")):
+        getattr(net.bn1, a).data.copy_(sd[b])
+    holder = _Holder(net).cuda().flatten()
+    net.train()
+    y = blocks.StemFn.apply(g["x"].cuda(), net, net.conv1.weight, net.bn1.weight, net.bn1.bias)
+    torch.testing.assert_close(nchw(y.detach()), g["y"], rtol=2e-4, atol=5e-5)
+    y.backward(nhwc(g["gy"]))
+    torch.testing.assert_close(subsample(net.conv1.weight.grad.cpu().contiguous()), g["g:0.weight"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(net.bn1.weight.grad.cpu(), g["g:1.weight"], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(net.bn1.running_var.cpu(), g["post:1.running_var"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------- full network + one SSL step against the reference golden (BASELINE config 1) ------------------
+def _model(use_ppm=False):
+    from oracle.weights import det_state_dict
+    from uemda_amd.models.Encoder import Deeplabv2
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True,
+               cascade=False, use_ppm=use_ppm, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
+               inchannels=2048, num_classes=C, is_ins_norm=True)
+    m = Deeplabv2(cfg)
+    sd = det_state_dict("resnet50", C, use_ppm, seed=2333)
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def test_full_model_aspp_ssl_step_matches_reference_golden():
+    from oracle import synth
+    from oracle.weights import checksum, subsample
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    g = load_golden("model_aspp_r50_b2_256")
+    model = _model(False)
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
+    model.eval()
+    with torch.no_grad():
+        prob = model(batch["images_t"])
+    torch.testing.assert_close(prob[:, :, ::8, ::8].cpu(), g["eval_prob_sample"], rtol=1e-3, atol=1e-5)
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    al.prototypes = batch["prototypes"].clone()
+    opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    out = ssl_step(model, al, opt, StepState(C), batch, float(g["lr"]))
+    # north_star: fp logits within 1e-3 rel of the reference CPU path
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        ref = g[k]
+        err = (out[k].cpu() - ref).abs().max() / ref.abs().max()
+        assert err < 1e-3, (k, float(err))
+    torch.testing.assert_close(out["feat_t"].cpu().reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out["label_t_soft"][:, :, ::4, ::4].cpu(), g["soft_sample"], rtol=1e-3, atol=1e-5)
+    agree = (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item()
+    assert agree >= 0.9995, agree
+    torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(al.prototypes.cpu(), g["prototypes"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=5e-3, atol=1e-4)
+    named = dict(model.named_parameters())
+    for k, v in g.items():
+        if k.startswith("grad:"):            # fixture grads are post-clip; so are ours (the fused step scales .grad)
+            got = subsample(named[k[5:]].grad.cpu().contiguous())
+            err = (got - v).abs().max() / (v.abs().max() + 1e-12)
+            assert err < 2e-2, (k, float(err))
+    s, a = checksum([p.cpu().contiguous() for p in model.parameters()])
+    assert a == pytest.approx(float(g["post_checksum"][1]), rel=1e-5)
+    sd = model.state_dict()
+    torch.testing.assert_close(sd["encoder.resnet.bn1.running_mean"].cpu(), g["post_bn1_running_mean"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(sd["encoder.resnet.layer4.2.bn3.running_var"].cpu(), g["post_l4_bn3_running_var"], rtol=1e-3, atol=1e-5)
+    assert int(sd["encoder.resnet.bn1.num_batches_tracked"]) == 2
+    torch.testing.assert_close(sd["encoder.resnet.conv1.weight"].cpu().reshape(-1)[::7], g["post_conv1_sample"], rtol=1e-4, atol=1e-6)
+
+
+def test_cpu_tensors_fail_loudly():
+    from uemda_amd import UemError
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    with pytest.raises(UemError):
+        pseudo_selection(torch.rand(1, C, 8, 8), return_type="tensor")

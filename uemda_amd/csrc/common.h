@@ -1,0 +1,80 @@
+// Shared host/device helpers for libuemda_hip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "uemda_hip.h"
+
+#define UEM_WAVE 64
+
+int uem_fail(int code, const char* fmt, ...);
+int uem_check_launch(const char* what);
+
+#define UEM_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) return uem_fail(UEM_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline int64_t uem_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// grid for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, capped.
+static inline int uem_stream_grid(int64_t work_items, int block) {
+    int64_t g = uem_cdiv(work_items, block);
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// order-preserving float <-> uint key (key(a) < key(b)  <=>  a < b); key 0 is below every float.
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// bilinear source index / lambda, PyTorch area_pixel_compute_source_index semantics.
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_setup(int dst, int in_size, int out_size, bool align_corners) {
+    float src;
+    if (align_corners) {
+        float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+        src = scale * (float)dst;
+    } else {
+        float scale = (float)in_size / (float)out_size;
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+    }
+    int i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    Lerp r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    float l1 = src - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    r.l1 = l1;
+    r.l0 = 1.f - l1;
+    return r;
+}

@@ -1,0 +1,513 @@
+// Convolution as implicit GEMM on the exact-fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain).
+//
+//   forward / data-gradient:  Y[m][n] = sum_k A[m][k] * W[n][k]
+//        m = output pixel (NHWC => dense row index), n = output channel, k = (tap, input channel);
+//        A is gathered on the fly from the NHWC input (im2col never materialised), optionally
+//        pushed through the producer's BatchNorm affine + ReLU while it is staged (operand prologue).
+//   weight-gradient:          dW[o][tap][i] += sum_m dY[m][o] * A[m][tap, i]      (split-K, fp32 atomics)
+//
+// Block = 256 threads = 4 waves; BM = 128 output pixels x BN in {128, 64, 32} channels x BK = 32.
+// Global -> register prefetch of tile k+1 overlaps the MFMA phase of tile k; LDS tiles are [row][36]
+// floats (k contiguous, 16-B pad) read with ds_read_b128 (conflict-free).
+// Replaces cuDNN behind nn.Conv2d: reference _resnets.py:95-110,149,209; Encoder.py:19,35-36,40,74-75.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128
+#define BK 32
+#define LDS_LD 36   // floats per LDS row: 32 + 4 pad => 144-B stride, conflict-free b128 reads
+
+struct ConvP {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* in_scale;
+    const float* in_shift;
+    float* y;
+    int M;                 // rows of the GEMM = output pixels
+    int N, H, W, Cin;      // "input" tensor the gather reads (for TRANSPOSED: dY dims Ho,Wo,Cout)
+    int Ho, Wo, Cout;      // "output" tensor (for TRANSPOSED: dX dims H,W,Cin)
+    int KH, KW, stride, pad, dil;
+    int x_ld, y_ld;
+    int accumulate;
+    int relu;
+};
+
+// bijective XCD-aware remap (cdna guide T1): blocks sharing an XCD get consecutive tile ids
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// MODE: 0 = forward gather, 1 = transposed gather (data gradient), 2 = stem (NHWC4, 8 px x 4 ch per tap row)
+template <int BN, int WM, int WN, int MODE, bool AFFINE>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+    constexpr int BROWS = BN / 32;                      // B-tile rows per thread
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;    // loader: 8 threads per 128-B row
+
+    // ---- per-thread gather geometry for its 4 A rows ------------------------------------------------
+    int gy[4], gx[4], gpix[4];                          // gpix < 0 => row beyond M
+    {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + lrow + 32 * j;
+            if (m < p.M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                if (MODE == 1) { gy[j] = oy + p.pad; gx[j] = ox + p.pad; }
+                else { gy[j] = oy * p.stride - p.pad; gx[j] = ox * p.stride - p.pad; }
+                gpix[j] = n * p.H * p.W;
+            } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
+        }
+    }
+    const int cpb = p.Cin / BK;                         // channel blocks per tap
+    const int KT = p.KH * p.KW * cpb;
+    const int Ktot = KT * BK;
+
+    float4 ra[4], rb[BROWS];
+    auto load_tiles = [&](int kt) {
+        const int tap = kt / cpb, ci0 = (kt - tap * cpb) * BK;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        float4 sc, sh;
+        if (AFFINE) {
+            sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + lc4);
+            sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + lc4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = gpix[j] >= 0;
+            int iy, ix;
+            if (MODE == 1) {
+                const int ty = gy[j] - ky * p.dil, tx = gx[j] - kx * p.dil;
+                iy = ty / p.stride; ix = tx / p.stride;
+                ok = ok && ty >= 0 && tx >= 0 && (iy * p.stride == ty) && (ix * p.stride == tx) && iy < p.H && ix < p.W;
+            } else if (MODE == 2) {
+                iy = gy[j] + ky;                        // stem: tap = ky, 8 pixels along x in the row
+                ix = gx[j] + (lc4 >> 2);
+                ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            } else {
+                iy = gy[j] + ky * p.dil; ix = gx[j] + kx * p.dil;
+                ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            }
+            if (ok) {
+                const size_t pix = (size_t)gpix[j] + (size_t)iy * p.W + ix;
+                if (MODE == 2) v = *reinterpret_cast<const float4*>(p.x + pix * 4);
+                else v = *reinterpret_cast<const float4*>(p.x + pix * p.x_ld + ci0 + lc4);
+                if (AFFINE) {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            const int n = n0 + lrow + 32 * j;
+            rb[j] = (n < p.Cout) ? *reinterpret_cast<const float4*>(p.w + (size_t)n * Ktot + (size_t)kt * BK + lc4)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[(lrow + 32 * j) * LDS_LD + lc4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * j) * LDS_LD + lc4]) = rb[j];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_tiles(kt + 1);            // in flight during the MFMA phase
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float4 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < KT) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m < p.M) {
+                    float* dst = p.y + (size_t)m * p.y_ld + n;
+                    float v = acc[i][j][r] + bv;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+static int conv_check(const uem_conv_shape* s) {
+    if (!s) return uem_fail(UEM_ERR_INVALID, "conv: null shape");
+    if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->KH <= 0 || s->KW <= 0 || s->stride <= 0 || s->dil <= 0 || s->pad < 0)
+        return uem_fail(UEM_ERR_INVALID, "conv: bad shape");
+    const int ho = (s->H + 2 * s->pad - s->dil * (s->KH - 1) - 1) / s->stride + 1;
+    const int wo = (s->W + 2 * s->pad - s->dil * (s->KW - 1) - 1) / s->stride + 1;
+    if (ho != s->Ho || wo != s->Wo) return uem_fail(UEM_ERR_INVALID, "conv: Ho/Wo (%d,%d) inconsistent with input (expected %d,%d)", s->Ho, s->Wo, ho, wo);
+    if (s->x_ld < s->Cin || s->y_ld < s->Cout || (s->x_ld % 4) != 0) return uem_fail(UEM_ERR_INVALID, "conv: bad x_ld/y_ld");
+    return UEM_OK;
+}
+
+template <int MODE>
+static int conv_launch(const ConvP& p, bool affine, hipStream_t st) {
+    const int tiles_m = (int)uem_cdiv(p.M, BM);
+#define CONV_GO(BN_, WM_, WN_)                                                                   \
+    do {                                                                                         \
+        const int grid = tiles_m * (int)uem_cdiv(p.Cout, BN_);                                   \
+        if (affine) conv_fwd_kernel<BN_, WM_, WN_, MODE, true><<<grid, 256, 0, st>>>(p);        \
+        else conv_fwd_kernel<BN_, WM_, WN_, MODE, false><<<grid, 256, 0, st>>>(p);              \
+    } while (0)
+    if (p.Cout % 128 == 0) CONV_GO(128, 2, 2);
+    else if (p.Cout % 64 == 0) CONV_GO(64, 2, 2);
+    else CONV_GO(32, 4, 1);
+#undef CONV_GO
+    return uem_check_launch("conv2d");
+}
+
+extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
+                              const float* in_shift, float* y, const uem_conv_shape* s, int flags, void* stream) {
+    UEM_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+    int rc = conv_check(s);
+    if (rc) return rc;
+    const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
+    const bool transposed = (flags & UEM_CONV_TRANSPOSED) != 0;
+    UEM_REQUIRE(!affine || (in_scale && in_shift), "conv2d_fwd: affine prologue needs scale/shift");
+    UEM_REQUIRE(!(affine && transposed), "conv2d_fwd: prologue not supported on the transposed gather");
+    ConvP p;
+    p.x = x; p.w = w; p.bias = bias; p.in_scale = in_scale; p.in_shift = in_shift; p.y = y;
+    p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
+    p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0;
+    p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0;
+    if (!transposed) {
+        UEM_REQUIRE(s->Cin % BK == 0, "conv2d_fwd: Cin=%d must be a multiple of 32", s->Cin);
+        p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
+        p.x_ld = s->x_ld; p.y_ld = s->y_ld;
+        p.M = s->N * s->Ho * s->Wo;
+        return conv_launch<0>(p, affine, (hipStream_t)stream);
+    }
+    // data gradient: rows = input pixels (N,H,W), reduction over (tap, Cout), gather from dY (N,Ho,Wo,Cout)
+    UEM_REQUIRE(s->Cout % BK == 0, "conv2d dgrad: Cout=%d must be a multiple of 32", s->Cout);
+    p.N = s->N; p.H = s->Ho; p.W = s->Wo; p.Cin = s->Cout;       // what the gather reads
+    p.Ho = s->H; p.Wo = s->W; p.Cout = s->Cin;                   // what the kernel writes
+    p.x_ld = s->y_ld; p.y_ld = s->x_ld;
+    p.M = s->N * s->H * s->W;
+    return conv_launch<1>(p, false, (hipStream_t)stream);
+}
+
+extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream) {
+    UEM_REQUIRE(x4 && w8 && y && N > 0 && H >= 7 && W >= 7, "conv2d_stem_fwd: bad arguments");
+    ConvP p;
+    p.x = x4; p.w = w8; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = 32;               // one tap row = 8 px x 4 ch
+    p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
+    p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
+    p.accumulate = 0; p.relu = 0;
+    p.M = N * p.Ho * p.Wo;
+    return conv_launch<2>(p, false, (hipStream_t)stream);
+}
+
+// =========================================================================================================
+// weight gradient: dW[o][tap][i] += sum_m dY[m][o] * A[m][tap, i]
+//   GEMM rows = output channels (TM), cols = input channels of ONE tap (TN), reduction over pixels.
+//   LDS tiles are k-major ([pixel][channel]) exactly as they sit in NHWC memory; the MFMA operands
+//   A[i][k], B[k][j] are then plain ds_read_b32 with consecutive lanes on consecutive channels.
+//   grid = (tiles, splits); each block reduces a slice of the pixels and adds its tile with fp32 atomics.
+// =========================================================================================================
+struct WgradP {
+    const float* x;
+    const float* dy;
+    const float* in_scale;
+    const float* in_shift;
+    float* dw;
+    int M, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, x_ld, dy_ld, relu;
+    int rows_per_split;
+};
+
+template <int TM, int TN, int WM, int WN, int WK, int MODE, bool AFFINE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
+    constexpr int MT = TM / WM / 32, NT = TN / WN / 32;
+    constexpr int DTPR = TM / 4, DRPP = 256 / DTPR, DPASS = (BK + DRPP - 1) / DRPP;   // dY loader
+    constexpr int XTPR = TN / 4, XRPP = 256 / XTPR, XPASS = (BK + XRPP - 1) / XRPP;   // X loader
+    __shared__ __attribute__((aligned(16))) float Ds[BK * TM];
+    __shared__ __attribute__((aligned(16))) float Xs[BK * TN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci_tiles = (p.Cin + TN - 1) / TN;
+    const int taps = p.KH * p.KW;
+    int t = blockIdx.x;
+    const int ci_t = t % ci_tiles; t /= ci_tiles;
+    const int tap = t % taps;
+    const int co_t = t / taps;
+    const int co0 = co_t * TM, ci0 = ci_t * TN;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int mbeg = blockIdx.y * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    const int HoWo = p.Ho * p.Wo;
+
+    const int drow = tid / DTPR, dc4 = (tid % DTPR) * 4;
+    const int xrow = tid / XTPR, xc4 = (tid % XTPR) * 4;
+    float4 sc, sh;
+    if (AFFINE) {
+        sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + xc4);
+        sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xc4);
+    }
+    float4 rd[DPASS], rx[XPASS];
+    auto load_tiles = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < DPASS; ++j) {
+            const int r = drow + j * DRPP;
+            const int m = mb + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < BK && m < mend && (co0 + dc4) < p.Cout) v = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.dy_ld + co0 + dc4);
+            rd[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < XPASS; ++j) {
+            const int r = xrow + j * XRPP;
+            const int m = mb + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < BK && m < mend) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                int iy, ix;
+                if (MODE == 2) { iy = oy * 2 - 3 + ky; ix = ox * 2 - 3 + (xc4 >> 2); }
+                else { iy = oy * p.stride - p.pad + ky * p.dil; ix = ox * p.stride - p.pad + kx * p.dil; }
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const size_t pix = ((size_t)n * p.H + iy) * p.W + ix;
+                    if (MODE == 2) v = *reinterpret_cast<const float4*>(p.x + pix * 4);
+                    else v = *reinterpret_cast<const float4*>(p.x + pix * p.x_ld + ci0 + xc4);
+                    if (AFFINE) {
+                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    }
+                }
+            }
+            rx[j] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < DPASS; ++j) {
+            const int r = drow + j * DRPP;
+            if (r < BK) *reinterpret_cast<float4*>(&Ds[r * TM + dc4]) = rd[j];
+        }
+#pragma unroll
+        for (int j = 0; j < XPASS; ++j) {
+            const int r = xrow + j * XRPP;
+            if (r < BK) *reinterpret_cast<float4*>(&Xs[r * TN + xc4]) = rx[j];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wk = wave / (WM * WN), wmn = wave % (WM * WN);
+    const int wm = (wmn / WN) * (TM / WM), wn = (wmn % WN) * (TN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+    constexpr int KPW = BK / WK;                       // pixel rows of each step owned by this wave
+
+    if (mbeg < mend) {
+        load_tiles(mbeg);
+        store_tiles();
+        __syncthreads();
+        for (int mb = mbeg; mb < mend; mb += BK) {
+            if (mb + BK < mend) load_tiles(mb + BK);
+#pragma unroll
+            for (int kp = 0; kp < KPW / 2; ++kp) {
+                const int k = wk * KPW + kp * 2 + fh;
+                float a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = Ds[k * TM + wm + i * 32 + fr];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = Xs[k * TN + wn + j * 32 + fr];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (mb + BK < mend) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+    const size_t row_ld = (size_t)taps * p.Cin;         // dW[o][tap][i]
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int ci = ci0 + wn + j * 32 + fr;
+            if (ci >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (co < p.Cout) atomicAdd(p.dw + (size_t)co * row_ld + (size_t)tap * p.Cin + ci, acc[i][j][r]);
+            }
+        }
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int MODE>
+static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
+    WgradP p = p0;
+    const int tiles = (int)(uem_cdiv(p.Cout, TM) * p.KH * p.KW * uem_cdiv(p.Cin, TN));
+    int splits = (int)uem_cdiv(2048, tiles);            // aim for >= 2048 blocks (8 per CU)
+    const int max_splits = (int)uem_cdiv(p.M, 4 * BK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rps = (int)uem_cdiv(p.M, splits);
+    rps = (int)uem_cdiv(rps, BK) * BK;
+    splits = (int)uem_cdiv(p.M, rps);
+    p.rows_per_split = rps;
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (affine) conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, true><<<grid, 256, 0, st>>>(p);
+    else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false><<<grid, 256, 0, st>>>(p);
+}
+
+extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift, float* dw,
+                                const uem_conv_shape* s, int flags, void* stream) {
+    UEM_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+    int rc = conv_check(s);
+    if (rc) return rc;
+    const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
+    UEM_REQUIRE(!affine || (in_scale && in_shift), "conv2d_wgrad: affine prologue needs scale/shift");
+    UEM_REQUIRE(s->Cin % 32 == 0 && s->Cout % 4 == 0 && s->y_ld % 4 == 0, "conv2d_wgrad: Cin %% 32, Cout %% 4 required");
+    WgradP p;
+    p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
+    p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo;
+    p.Cout = s->Cout; p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
+    p.x_ld = s->x_ld; p.dy_ld = s->y_ld; p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0; p.rows_per_split = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->Cout % 128 == 0 && s->Cin % 128 == 0) wgrad_go<128, 128, 2, 2, 1, 0>(p, affine, st);
+    else if (s->Cout % 64 == 0 && s->Cin % 64 == 0) wgrad_go<64, 64, 2, 2, 1, 0>(p, affine, st);
+    else if (s->Cin % 128 == 0) wgrad_go<32, 128, 1, 4, 1, 0>(p, affine, st);
+    else wgrad_go<32, 32, 1, 1, 4, 0>(p, affine, st);
+    return uem_check_launch("conv2d_wgrad");
+}
+
+extern "C" int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw8, int N, int H, int W, void* stream) {
+    UEM_REQUIRE(x4 && dy && dw8 && N > 0 && H >= 7 && W >= 7, "conv2d_stem_wgrad: bad arguments");
+    WgradP p;
+    p.x = x4; p.dy = dy; p.in_scale = p.in_shift = nullptr; p.dw = dw8;
+    p.N = N; p.H = H; p.W = W; p.Cin = 32; p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
+    p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.dy_ld = 64; p.relu = 0; p.rows_per_split = 0;
+    p.M = N * p.Ho * p.Wo;
+    wgrad_go<64, 32, 2, 1, 2, 2>(p, false, (hipStream_t)stream);
+    return uem_check_launch("conv2d_stem_wgrad");
+}
+
+// =========================================================================================================
+// small weight re-layout helpers
+// =========================================================================================================
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int T, int Cin) {
+    // w[o][t][i] -> wt[i][t][o]
+    const int64_t total = (int64_t)Cout * T * Cin;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % Cout);
+        int64_t r = idx / Cout;
+        const int t = (int)(r % T);
+        const int i = (int)(r / T);
+        wt[idx] = w[((size_t)o * T + t) * Cin + i];
+    }
+}
+extern "C" int uem_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
+    UEM_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "weight_transpose: bad arguments");
+    const int64_t total = (int64_t)Cout * KH * KW * Cin;
+    weight_transpose_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w, wt, Cout, KH * KW, Cin);
+    return uem_check_launch("weight_transpose");
+}
+__global__ void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ w8) {
+    // w[64][7][7][3] (OHWI) -> w8[64][7][8][4], zero padded
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * 7 * 8 * 4) return;
+    const int c = idx & 3, kx = (idx >> 2) & 7, ky = (idx >> 5) % 7, o = idx / (7 * 32);
+    w8[idx] = (c < 3 && kx < 7) ? w[((o * 7 + ky) * 7 + kx) * 3 + c] : 0.f;
+}
+extern "C" int uem_stem_pack_weight(const float* w_ohwi, float* w8, void* stream) {
+    UEM_REQUIRE(w_ohwi && w8, "stem_pack_weight: null pointer");
+    stem_pack_kernel<<<(64 * 7 * 32 + 255) / 256, 256, 0, (hipStream_t)stream>>>(w_ohwi, w8);
+    return uem_check_launch("stem_pack_weight");
+}
+__global__ void stem_unpack_kernel(const float* __restrict__ dw8, float* __restrict__ dw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 64 * 7 * 7 * 3) return;
+    const int c = idx % 3, kx = (idx / 3) % 7, ky = (idx / 21) % 7, o = idx / 147;
+    dw[idx] += dw8[((o * 7 + ky) * 8 + kx) * 4 + c];
+}
+extern "C" int uem_stem_unpack_grad(const float* dw8, float* dw_ohwi, void* stream) {
+    UEM_REQUIRE(dw8 && dw_ohwi, "stem_unpack_grad: null pointer");
+    stem_unpack_kernel<<<(64 * 147 + 255) / 256, 256, 0, (hipStream_t)stream>>>(dw8, dw_ohwi);
+    return uem_check_launch("stem_unpack_grad");
+}
+__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int M, int C, int ld) {
+    // one block per channel group of 64... C is tiny (<= 32): block = 256 threads over rows, loop channels
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += 256) s += dy[(size_t)m * ld + c];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] += (red[0] + red[1]) + (red[2] + red[3]);
+}
+extern "C" int uem_bias_grad(const float* dy, float* db, int M, int C, int ld, void* stream) {
+    UEM_REQUIRE(dy && db && M > 0 && C > 0 && ld >= C, "bias_grad: bad arguments");
+    bias_grad_kernel<<<C, 256, 0, (hipStream_t)stream>>>(dy, db, M, C, ld);
+    return uem_check_launch("bias_grad");
+}

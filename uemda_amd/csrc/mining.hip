@@ -1,0 +1,601 @@
+// Pseudo-label mining kernels (HBM-bound): Pearson similarity, superpixel segment-max, fused
+// three-view label refinement, threshold selection, label downscale, prototype sums / EMA.
+// Reference call sites: uemda/gast/alignment.py:194-293,328-355,424-451,484-509,
+// uemda/gast/pseudo_generation.py:59-93.  See include/uemda_hip.h for the per-entry citations.
+#include "common.h"
+
+// ================================================================================================
+// Pearson similarity  sim[n][c] = 1 / (0.5 * (1 - cov/(k-1+eps) / (std_x*std_p + eps)))
+// One wave owns TWO feature rows at a time (k floats each, NHWC => contiguous); centred
+// prototypes live in LDS (C*k floats) and each LDS read feeds both rows.
+// ================================================================================================
+__global__ void proto_center_kernel(const float* __restrict__ protos, float* __restrict__ pc,
+                                    float* __restrict__ pstd, int k) {
+    // one wave per class: pc = p - mean(p); pstd = unbiased std
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* p = protos + (size_t)c * k;
+    float s = 0.f;
+    for (int j = lane; j < k; j += 64) s += p[j];
+    const float mean = wave_sum(s) / (float)k;
+    float ss = 0.f;
+    for (int j = lane; j < k; j += 64) {
+        float d = p[j] - mean;
+        pc[(size_t)c * k + j] = d;
+        ss += d * d;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) pstd[c] = sqrtf(ss / (float)(k - 1));
+}
+
+template <int CMAX, bool INVERT>
+__global__ __launch_bounds__(256) void pearson_kernel(const float* __restrict__ feat,
+                                                      const float* __restrict__ pc_g,
+                                                      const float* __restrict__ pstd,
+                                                      float* __restrict__ out, int n, int k, int C) {
+    extern __shared__ __attribute__((aligned(16))) float pc[];   // [C][k]
+    const int tid = threadIdx.x;
+    const int nvec = (C * k) >> 2;
+    for (int i = tid; i < nvec; i += 256)
+        reinterpret_cast<float4*>(pc)[i] = reinterpret_cast<const float4*>(pc_g)[i];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const float eps = 1e-7f;
+    for (int r0 = (blockIdx.x * 4 + wave) * 2; r0 < n; r0 += gridDim.x * 8) {
+        const bool has1 = (r0 + 1) < n;
+        const float* x0 = feat + (size_t)r0 * k;
+        const float* x1 = feat + (size_t)(has1 ? r0 + 1 : r0) * k;
+        float s0 = 0.f, s1 = 0.f;
+        for (int j = lane * 4; j < k; j += 256) {
+            float4 a = *reinterpret_cast<const float4*>(x0 + j);
+            float4 b = *reinterpret_cast<const float4*>(x1 + j);
+            s0 += (a.x + a.y) + (a.z + a.w);
+            s1 += (b.x + b.y) + (b.z + b.w);
+        }
+        const float m0 = wave_sum(s0) / (float)k, m1 = wave_sum(s1) / (float)k;
+        float ss0 = 0.f, ss1 = 0.f;
+        float d0[CMAX], d1[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) d0[c] = d1[c] = 0.f;
+        for (int j = lane * 4; j < k; j += 256) {
+            float4 a = *reinterpret_cast<const float4*>(x0 + j);   // second pass: L1/L2 hit
+            float4 b = *reinterpret_cast<const float4*>(x1 + j);
+            a.x -= m0; a.y -= m0; a.z -= m0; a.w -= m0;
+            b.x -= m1; b.y -= m1; b.z -= m1; b.w -= m1;
+            ss0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            ss1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c < C) {
+                    float4 p = *reinterpret_cast<const float4*>(pc + (size_t)c * k + j);
+                    d0[c] += a.x * p.x + a.y * p.y + a.z * p.z + a.w * p.w;
+                    d1[c] += b.x * p.x + b.y * p.y + b.z * p.z + b.w * p.w;
+                }
+            }
+        }
+        ss0 = wave_sum(ss0);
+        ss1 = wave_sum(ss1);
+        const float std0 = sqrtf(ss0 / (float)(k - 1)), std1 = sqrtf(ss1 / (float)(k - 1));
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C) {
+                float c0 = wave_sum(d0[c]), c1 = wave_sum(d1[c]);
+                if (lane == 0) {
+                    float ps = pstd[c];
+                    float dist0 = (-1.0f * (c0 / ((float)(k - 1) + eps)) / (std0 * ps + eps) + 1.0f) * 0.5f;
+                    out[(size_t)r0 * C + c] = INVERT ? 1.0f / dist0 : dist0;
+                    if (has1) {
+                        float dist1 = (-1.0f * (c1 / ((float)(k - 1) + eps)) / (std1 * ps + eps) + 1.0f) * 0.5f;
+                        out[(size_t)(r0 + 1) * C + c] = INVERT ? 1.0f / dist1 : dist1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int pearson_launch(const float* a, const float* b, float* out, float* scratch, int n, int m, int k,
+                          bool invert, hipStream_t st) {
+    // scratch: [m*k] centred b + [m] std
+    float* pc = scratch;
+    float* pstd = scratch + (size_t)m * k;
+    proto_center_kernel<<<m, 64, 0, st>>>(b, pc, pstd, k);
+    size_t lds = (size_t)m * k * sizeof(float);
+    int grid = (int)uem_cdiv(n, 8);
+    if (grid > 256 * 3) grid = 256 * 3;
+    if (grid < 1) grid = 1;
+#define LAUNCH_P(CM, INV)                                                                                \
+    do {                                                                                                 \
+        hipFuncSetAttribute((const void*)pearson_kernel<CM, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                   \
+        pearson_kernel<CM, INV><<<grid, 256, lds, st>>>(a, pc, pstd, out, n, k, m);                       \
+    } while (0)
+    if (m <= 8) {
+        if (invert) LAUNCH_P(8, true); else LAUNCH_P(8, false);
+    } else {
+        if (invert) LAUNCH_P(16, true); else LAUNCH_P(16, false);
+    }
+#undef LAUNCH_P
+    return uem_check_launch("pearson");
+}
+
+// workspace: (C*k + C) floats for the centred prototypes and their std (library keeps no state).
+extern "C" int uem_pearson_sim(const float* feat, const float* protos, float* sim, float* workspace,
+                                  int n, int k, int C, void* stream) {
+    UEM_REQUIRE(feat && protos && sim && workspace, "pearson_sim: null pointer");
+    UEM_REQUIRE(n > 0 && k >= 8 && (k % 4) == 0 && C >= 1 && C <= UEM_MAX_CLASSES, "pearson_sim: bad shape n=%d k=%d C=%d", n, k, C);
+    UEM_REQUIRE((size_t)C * k * 4 <= 150 * 1024, "pearson_sim: C*k too large for LDS");
+    return pearson_launch(feat, protos, sim, workspace, n, C, k, true, (hipStream_t)stream);
+}
+extern "C" int uem_pearson_dist(const float* a, const float* b, float* dist, float* workspace, int n, int m,
+                                   int k, void* stream) {
+    UEM_REQUIRE(a && b && dist && workspace, "pearson_dist: null pointer");
+    UEM_REQUIRE(n > 0 && k >= 8 && (k % 4) == 0 && m >= 1 && m <= UEM_MAX_CLASSES, "pearson_dist: bad shape");
+    UEM_REQUIRE((size_t)m * k * 4 <= 150 * 1024, "pearson_dist: m*k too large for LDS");
+    return pearson_launch(a, b, dist, workspace, n, m, k, false, (hipStream_t)stream);
+}
+
+// ================================================================================================
+// index max
+// ================================================================================================
+__global__ void index_max_kernel(const int64_t* __restrict__ idx, int64_t count, unsigned long long* out) {
+    long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        long long v = idx[i];
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        long long t = __shfl_xor(m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)m);
+}
+extern "C" int uem_index_max(const int64_t* idx, int64_t count, int64_t* out, void* stream) {
+    UEM_REQUIRE(idx && out && count > 0, "index_max: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(out, 0, sizeof(int64_t), st);
+    index_max_kernel<<<uem_stream_grid(count, 256 * 4), 256, 0, st>>>(idx, count, (unsigned long long*)out);
+    return uem_check_launch("index_max");
+}
+
+// ================================================================================================
+// superpixel segment max over an NCHW-planar soft label.
+// Block = 64x16 pixel tile; ids are spatially compact, so a tile touches a handful of segments:
+// an LDS open-addressing table (key = id) absorbs the per-pixel atomics, then one global
+// atomicMax per (segment, class) per tile.  Overflowing ids fall back to direct global atomics.
+// ================================================================================================
+#define SEG_SLOTS 128
+template <int CMAX>
+__global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ soft,
+                                                          const int64_t* __restrict__ sup,
+                                                          uint32_t* __restrict__ seg, int C, int H, int W, int S) {
+    __shared__ int keys[SEG_SLOTS];
+    __shared__ uint32_t vals[SEG_SLOTS][CMAX];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SEG_SLOTS; i += 256) {
+        keys[i] = -1;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) vals[i][c] = 0u;
+    }
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (tid & 63);
+    const size_t plane = (size_t)H * W;
+    const float* sb = soft + (size_t)b * C * plane;
+    const int64_t* ib = sup + (size_t)b * plane;
+    uint32_t* segb = seg + (size_t)b * S * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = blockIdx.y * 16 + (tid >> 6) + 4 * j;
+        if (x < W && y < H) {
+            const size_t p = (size_t)y * W + x;
+            const int id = (int)ib[p];
+            if (id >= 0 && id < S) {
+                uint32_t hsh = ((uint32_t)id * 2654435761u) >> 25;   // 7 bits
+                int slot = -1;
+                for (int probe = 0; probe < SEG_SLOTS; ++probe) {
+                    int prev = atomicCAS(&keys[hsh], -1, id);
+                    if (prev == -1 || prev == id) { slot = (int)hsh; break; }
+                    hsh = (hsh + 1) & (SEG_SLOTS - 1);
+                }
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c < C) {
+                        uint32_t kv = f2key(sb[(size_t)c * plane + p]);
+                        if (slot >= 0) atomicMax(&vals[slot][c], kv);
+                        else atomicMax(&segb[(size_t)id * C + c], kv);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < SEG_SLOTS * CMAX; i += 256) {
+        const int slot = i / CMAX, c = i % CMAX;
+        const int id = keys[slot];
+        if (id >= 0 && c < C) {
+            uint32_t kv = vals[slot][c];
+            if (kv) atomicMax(&segb[(size_t)id * C + c], kv);
+        }
+    }
+}
+extern "C" int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_keys, int B, int C,
+                                      int H, int W, int S, void* stream) {
+    UEM_REQUIRE(soft && sup && seg_keys, "segment_max: null pointer");
+    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && H > 0 && W > 0 && S > 0, "segment_max: bad shape");
+    dim3 grid((unsigned)uem_cdiv(W, 64), (unsigned)uem_cdiv(H, 16), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 8) segment_max_kernel<8><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S);
+    else segment_max_kernel<16><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S);
+    return uem_check_launch("segment_max");
+}
+
+// ================================================================================================
+// fused label refinement (one thread per full-resolution pixel)
+// ================================================================================================
+template <int CMAX>
+__device__ __forceinline__ void softmax_maxnorm(float (&v)[CMAX], int C, float inv_temp) {
+    // v <- softmax(v * inv_temp) / (max + 1e-7)     (alignment.py:221-222, 230-235, 252-253)
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= inv_temp; m = fmaxf(m, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - m); s += v[c]; }
+    float pm = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = v[c] / s; pm = fmaxf(pm, v[c]); }
+    const float d = pm + 1e-7f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] / d;
+}
+
+template <int CMAX>
+__device__ __forceinline__ void bilerp(const float* __restrict__ low, int C, int w, const Lerp& ly, const Lerp& lx,
+                                       float (&v)[CMAX]) {
+    // low: one image (h, w, C).  PyTorch order: ly.l0*(lx.l0*v00 + lx.l1*v01) + ly.l1*(lx.l0*v10 + lx.l1*v11)
+    const float* r0 = low + (size_t)ly.i0 * w * C;
+    const float* r1 = low + (size_t)ly.i1 * w * C;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+            float v00 = r0[lx.i0 * C + c], v01 = r0[lx.i1 * C + c];
+            float v10 = r1[lx.i0 * C + c], v11 = r1[lx.i1 * C + c];
+            v[c] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+        }
+    }
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void label_refine_kernel(
+    const float* __restrict__ soft, const int64_t* __restrict__ sup, const float* __restrict__ sim,
+    const float* __restrict__ lg1, const float* __restrict__ lg2, const uint32_t* __restrict__ seg,
+    const int64_t* __restrict__ ignore_id, float* __restrict__ out, uint32_t* __restrict__ plane_max, int C, int h,
+    int w, int H, int W, int S, float inv_temp, int mode) {
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = p < plane;
+    float o[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) o[c] = 0.f;
+    if (active) {
+        const int Y = (int)(p / W), X = (int)(p % W);
+        const Lerp ly = lerp_setup(Y, h, H, true), lx = lerp_setup(X, w, W, true);
+        float wgt[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) wgt[c] = 0.f;
+        if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_P) {          // prototype view
+            float v[CMAX];
+            bilerp<CMAX>(sim + (size_t)b * h * w * C, C, w, ly, lx, v);
+            softmax_maxnorm<CMAX>(v, C, 1.0f);
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) wgt[c] += v[c];
+        }
+        if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) {          // prediction view
+            float v[CMAX];
+            bilerp<CMAX>(lg1 + (size_t)b * h * w * C, C, w, ly, lx, v);
+            if (lg2 != nullptr) {
+                float u[CMAX];
+                bilerp<CMAX>(lg2 + (size_t)b * h * w * C, C, w, ly, lx, u);
+                // 0.5 * (softmax(x1/T) + softmax(x2/T)), then max-normalise
+                float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= inv_temp; u[c] *= inv_temp; m1 = fmaxf(m1, v[c]); m2 = fmaxf(m2, u[c]); }
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - m1); u[c] = expf(u[c] - m2); s1 += v[c]; s2 += u[c]; }
+                float pm = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = (v[c] / s1 + u[c] / s2) * 0.5f; pm = fmaxf(pm, v[c]); }
+                const float d = pm + 1e-7f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] / d;
+            } else {
+                softmax_maxnorm<CMAX>(v, C, inv_temp);
+            }
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) wgt[c] += v[c];
+        }
+        if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_S) {          // superpixel view
+            const int64_t id = sup[(size_t)b * plane + p];
+            const bool ignored = (id == *ignore_id);
+            float v[CMAX];
+            const uint32_t* sg = seg + ((size_t)b * S + (size_t)(id >= 0 && id < S ? id : 0)) * C;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) if (c < C) { uint32_t kv = sg[c]; v[c] = kv ? key2f(kv) : 0.f; }
+            softmax_maxnorm<CMAX>(v, C, inv_temp);
+            if (mode == UEM_REFINE_ALL) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) wgt[c] = ignored ? wgt[c] : wgt[c] * v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) wgt[c] = ignored ? 1.0f : v[c];
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = wgt[c] * soft[((size_t)b * C + c) * plane + p]; sum += o[c]; }
+        const float d = sum + 1e-7f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] / d; out[((size_t)b * C + c) * plane + p] = o[c]; }
+    }
+    // per-(b,c) running max for the selection pass (values are >= 0: uint order == float order)
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+            float m = wave_max(o[c]);
+            if ((threadIdx.x & 63) == 0) atomicMax(&plane_max[b * C + c], __float_as_uint(fmaxf(m, 0.f)));
+        }
+    }
+}
+
+extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
+                                const float* logits2, const uint32_t* seg_keys, const int64_t* ignore_id,
+                                float* soft_out, uint32_t* plane_max, int B, int C, int h, int w, int H, int W,
+                                int S, float temp, int mode, void* stream) {
+    UEM_REQUIRE(soft && soft_out && plane_max, "label_refine: null pointer");
+    UEM_REQUIRE(mode >= 0 && mode <= 3, "label_refine: bad mode %d", mode);
+    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H > 0 && W > 0, "label_refine: bad shape");
+    UEM_REQUIRE(temp > 0.f, "label_refine: temp must be > 0");
+    if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_P) UEM_REQUIRE(sim, "label_refine: sim required");
+    if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) UEM_REQUIRE(logits1, "label_refine: logits required");
+    if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_S) UEM_REQUIRE(sup && seg_keys && ignore_id && S > 0, "label_refine: superpixel inputs required");
+    dim3 grid((unsigned)uem_cdiv((int64_t)H * W, 256), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 8)
+        label_refine_kernel<8><<<grid, 256, 0, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
+                                                     plane_max, C, h, w, H, W, S, 1.0f / temp, mode);
+    else
+        label_refine_kernel<16><<<grid, 256, 0, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
+                                                      plane_max, C, h, w, H, W, S, 1.0f / temp, mode);
+    return uem_check_launch("label_refine");
+}
+
+// ================================================================================================
+// pseudo_selection
+// ================================================================================================
+__global__ __launch_bounds__(256) void plane_max_kernel(const float* __restrict__ mask, uint32_t* __restrict__ pm,
+                                                        int64_t HW) {
+    // grid: (chunks, B*C); monotone key so negative inputs still order correctly
+    const float* pl = mask + (size_t)blockIdx.y * HW;
+    float m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) m = fmaxf(m, pl[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(&pm[blockIdx.y], f2key(m));
+}
+__global__ void plane_max_decode_kernel(uint32_t* pm, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pm[i] = __float_as_uint(key2f(pm[i]));
+}
+extern "C" int uem_plane_max(const float* mask, uint32_t* plane_max, int B, int C, int64_t HW, void* stream) {
+    UEM_REQUIRE(mask && plane_max && B > 0 && C > 0 && HW > 0, "plane_max: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(plane_max, 0, sizeof(uint32_t) * B * C, st);
+    int chunks = (int)uem_cdiv(HW, 256 * 8);
+    if (chunks > 64) chunks = 64;
+    plane_max_kernel<<<dim3(chunks, B * C), 256, 0, st>>>(mask, plane_max, HW);
+    plane_max_decode_kernel<<<(int)uem_cdiv(B * C, 64), 64, 0, st>>>(plane_max, B * C);
+    return uem_check_launch("plane_max");
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void pseudo_select_kernel(const float* __restrict__ mask,
+                                                            const uint32_t* __restrict__ plane_max,
+                                                            int64_t* __restrict__ hard, int* __restrict__ range_flag,
+                                                            int C, int64_t HW, float top, float low, int64_t ignore) {
+    const int b = blockIdx.y;
+    float thr[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        thr[c] = c < C ? fmaxf(__fmul_rn(__uint_as_float(plane_max[b * C + c]), top), low) : INFINITY;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    int cnt = 0, lab = 0;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+            float v = mask[((size_t)b * C + c) * HW + p];
+            bad |= !(v >= 0.f && v <= 1.f);
+            if (v > thr[c]) { if (cnt == 0) lab = c; ++cnt; }
+        }
+    }
+    hard[(size_t)b * HW + p] = (cnt == 1) ? (int64_t)lab : ignore;
+    if (bad) atomicOr(range_flag, 1);
+}
+extern "C" int uem_pseudo_select(const float* mask, const uint32_t* plane_max, int64_t* hard, int* range_flag, int B,
+                                 int C, int64_t HW, float cutoff_top, float cutoff_low, int64_t ignore_label,
+                                 void* stream) {
+    UEM_REQUIRE(mask && plane_max && hard && range_flag, "pseudo_select: null pointer");
+    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && HW > 0, "pseudo_select: bad shape");
+    dim3 grid((unsigned)uem_cdiv(HW, 256), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 8) pseudo_select_kernel<8><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
+    else pseudo_select_kernel<16><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
+    return uem_check_launch("pseudo_select");
+}
+
+// ================================================================================================
+// DownscaleLabel: one block per output cell, LDS histogram over (n_classes + 1) bins
+// ================================================================================================
+__global__ __launch_bounds__(256) void downscale_label_kernel(const int64_t* __restrict__ label,
+                                                              int64_t* __restrict__ out, int H, int W, int scale,
+                                                              int n_classes, int64_t ignore, float min_ratio) {
+    __shared__ int hist[UEM_MAX_CLASSES + 2];
+    const int tid = threadIdx.x;
+    if (tid <= n_classes) hist[tid] = 0;
+    __syncthreads();
+    const int wo = W / scale, ho = H / scale;
+    const int cx = blockIdx.x % wo, cy = (blockIdx.x / wo) % ho, b = blockIdx.x / (wo * ho);
+    const int64_t* base = label + ((size_t)b * H + (size_t)cy * scale) * W + (size_t)cx * scale;
+    for (int i = tid; i < scale * scale; i += 256) {
+        int64_t v = base[(size_t)(i / scale) * W + (i % scale)];
+        int bin = (v == ignore || v < 0 || v >= n_classes) ? n_classes : (int)v;
+        atomicAdd(&hist[bin], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0, bc = hist[0];
+        for (int c = 1; c <= n_classes; ++c) if (hist[c] > bc) { bc = hist[c]; best = c; }   // first max wins
+        float ratio = (float)bc / (float)(scale * scale);
+        int64_t r = best;
+        if (best == n_classes) r = ignore;
+        if (ratio < min_ratio) r = ignore;
+        out[blockIdx.x] = r;
+    }
+}
+extern "C" int uem_downscale_label(const int64_t* label, int64_t* out, int B, int H, int W, int scale, int n_classes,
+                                   int64_t ignore_label, float min_ratio, void* stream) {
+    UEM_REQUIRE(label && out, "downscale_label: null pointer");
+    UEM_REQUIRE(B > 0 && scale > 1 && H % scale == 0 && W % scale == 0, "downscale_label: H, W must be multiples of scale");
+    UEM_REQUIRE(n_classes >= 1 && n_classes <= UEM_MAX_CLASSES, "downscale_label: bad n_classes");
+    int cells = B * (H / scale) * (W / scale);
+    downscale_label_kernel<<<cells, 256, 0, (hipStream_t)stream>>>(label, out, H, W, scale, n_classes, ignore_label, min_ratio);
+    return uem_check_launch("downscale_label");
+}
+
+// ================================================================================================
+// prototype sums: deterministic two-stage (row chunks -> partial slabs -> ordered reduce)
+// ================================================================================================
+template <int CMAX>
+__global__ __launch_bounds__(256) void proto_partial_kernel(const float* __restrict__ feat,
+                                                            const int64_t* __restrict__ lab, float* __restrict__ part,
+                                                            float* __restrict__ part_cnt, int n, int k, int C,
+                                                            int rows_per_chunk, int64_t ignore) {
+    const int chunk = blockIdx.y;
+    const int kk = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(n, r0 + rows_per_chunk);
+    float4 acc[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kk < k) {
+        for (int r = r0; r < r1; ++r) {
+            const int64_t l = lab[r];                      // block-uniform
+            if (l == ignore || l < 0 || l >= C) continue;
+            const float4 v = *reinterpret_cast<const float4*>(feat + (size_t)r * k + kk);
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c == (int)l) { acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) *reinterpret_cast<float4*>(part + ((size_t)chunk * C + c) * k + kk) = acc[c];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < C) {
+        float cnt = 0.f;
+        for (int r = r0; r < r1; ++r) cnt += (lab[r] == (int64_t)threadIdx.x) ? 1.f : 0.f;
+        part_cnt[chunk * C + threadIdx.x] = cnt;
+    }
+}
+__global__ void proto_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_cnt,
+                                    float* __restrict__ sums, float* __restrict__ counts, int chunks, int Ck, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Ck) {
+        float s = 0.f;
+        for (int j = 0; j < chunks; ++j) s += part[(size_t)j * Ck + i];
+        sums[i] = s;
+    }
+    if (i < C) {
+        float s = 0.f;
+        for (int j = 0; j < chunks; ++j) s += part_cnt[j * C + i];
+        counts[i] = s;
+    }
+}
+extern "C" int uem_proto_sums(const float* feat, const int64_t* label_ds, float* sums, float* counts, float* workspace,
+                              int n, int k, int C, int64_t ignore_label, void* stream) {
+    UEM_REQUIRE(feat && label_ds && sums && counts && workspace, "proto_sums: null pointer");
+    UEM_REQUIRE(n > 0 && k > 0 && (k % 4) == 0 && C >= 1 && C <= UEM_MAX_CLASSES, "proto_sums: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = UEM_PROTO_SPLIT;
+    const int rpc = (int)uem_cdiv(n, chunks);
+    float* part = workspace;
+    float* part_cnt = workspace + (size_t)chunks * C * k;
+    dim3 grid((unsigned)uem_cdiv(k, 1024), (unsigned)chunks);
+    if (C <= 8) proto_partial_kernel<8><<<grid, 256, 0, st>>>(feat, label_ds, part, part_cnt, n, k, C, rpc, ignore_label);
+    else proto_partial_kernel<16><<<grid, 256, 0, st>>>(feat, label_ds, part, part_cnt, n, k, C, rpc, ignore_label);
+    proto_reduce_kernel<<<(int)uem_cdiv((int64_t)C * k, 256), 256, 0, st>>>(part, part_cnt, sums, counts, chunks, C * k, C);
+    return uem_check_launch("proto_sums");
+}
+__global__ void proto_ema_kernel(const float* __restrict__ sums, const float* __restrict__ counts,
+                                 float* __restrict__ protos, int k, int C, float decay) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * k) return;
+    const float n = counts[i / k];
+    const float old = protos[i];
+    const float local = (n < 1.f) ? old : sums[i] / (n + 1e-7f);
+    protos[i] = (1.0f - decay) * local + decay * old;
+}
+extern "C" int uem_proto_ema(const float* sums, const float* counts, float* protos, int k, int C, float decay, void* stream) {
+    UEM_REQUIRE(sums && counts && protos && k > 0 && C > 0, "proto_ema: bad arguments");
+    UEM_REQUIRE(decay > 0.f && decay < 1.f, "proto_ema: decay must be in (0,1)");
+    proto_ema_kernel<<<(int)uem_cdiv((int64_t)C * k, 256), 256, 0, (hipStream_t)stream>>>(sums, counts, protos, k, C, decay);
+    return uem_check_launch("proto_ema");
+}
+
+// ================================================================================================
+// generic torch_scatter-style scatter (API completeness; not on the fused hot path)
+// ================================================================================================
+__global__ void scatter_kernel(const float* __restrict__ src, const int64_t* __restrict__ index, float* __restrict__ out,
+                               float* __restrict__ cnt, int N, int C, int S, int reduce) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const int64_t id = index[(size_t)b * N + p];
+    if (id < 0 || id >= S) return;
+    const float* s = src + ((size_t)b * N + p) * C;
+    float* o = out + ((size_t)b * S + id) * C;
+    if (reduce == 0) {
+        for (int c = 0; c < C; ++c) atomicMax(reinterpret_cast<uint32_t*>(o) + c, f2key(s[c]));
+    } else {
+        for (int c = 0; c < C; ++c) atomicAdd(o + c, s[c]);
+        if (reduce == 2) atomicAdd(cnt + (size_t)b * S + id, 1.0f);
+    }
+}
+__global__ void scatter_finish_kernel(float* __restrict__ out, const float* __restrict__ cnt, int64_t total, int C, int reduce) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (reduce == 0) {
+        uint32_t kv = reinterpret_cast<uint32_t*>(out)[i];
+        out[i] = kv ? key2f(kv) : 0.f;
+    } else if (reduce == 2) {
+        float n = cnt[i / C];
+        out[i] = out[i] / fmaxf(n, 1.f);
+    }
+}
+extern "C" int uem_scatter(const float* src, const int64_t* index, float* out, float* workspace, int B, int N, int C,
+                           int S, int reduce, void* stream) {
+    UEM_REQUIRE(src && index && out, "scatter: null pointer");
+    UEM_REQUIRE(B > 0 && N > 0 && C > 0 && S > 0 && reduce >= 0 && reduce <= 2, "scatter: bad arguments");
+    UEM_REQUIRE(reduce != 2 || workspace, "scatter: mean needs a B*S workspace");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * S * C, st);
+    if (reduce == 2) hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)B * S, st);
+    scatter_kernel<<<dim3((unsigned)uem_cdiv(N, 256), (unsigned)B), 256, 0, st>>>(src, index, out, workspace, N, C, S, reduce);
+    const int64_t total = (int64_t)B * S * C;
+    if (reduce != 1) scatter_finish_kernel<<<(int)uem_cdiv(total, 256), 256, 0, st>>>(out, workspace, total, C, reduce);
+    return uem_check_launch("scatter");
+}

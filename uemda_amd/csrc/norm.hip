@@ -1,0 +1,667 @@
+// Normalisation / pooling / resampling / layout kernels (all HBM-bound, NHWC fp32).
+// Reference: BatchNorm2d at _resnets.py:96-110 & Encoder.py:20,37; MaxPool2d _resnets.py:153;
+// InstanceNorm2d Encoder.py:123,147; AdaptiveAvgPool2d + bilinear(align_corners=False) Encoder.py:18,48-51;
+// Dropout2d Encoder.py:39.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// thread -> (channel vector, row group) mapping shared by the column-reduction kernels:
+// LPR lanes cover one row's channel segment (4 channels per lane), 256/LPR rows per pass.
+// ---------------------------------------------------------------------------------------------------------
+struct ColMap {
+    int lpr, rpp, cv, rg, c0;
+};
+__device__ __forceinline__ ColMap col_map(int C, int seg) {
+    ColMap m;
+    int cvecs = C >> 2;
+    m.lpr = cvecs < 64 ? cvecs : 64;
+    m.rpp = 256 / m.lpr;
+    m.cv = threadIdx.x % m.lpr;
+    m.rg = threadIdx.x / m.lpr;
+    m.c0 = seg * 256 + m.cv * 4;
+    return m;
+}
+static inline bool col_shape_ok(int C) {
+    // C/4 must be a power of two <= 64, or a multiple of 64 (so 256 % lpr == 0)
+    if (C % 4) return false;
+    int cv = C / 4;
+    if (cv >= 64) return cv % 64 == 0;
+    return (cv & (cv - 1)) == 0;
+}
+
+// Chan et al. parallel combination of (n, mean, M2)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+    if (nb == 0.f) return;
+    const float nt = n + nb;
+    const float delta = meanb - mean;
+    mean = mean + delta * (nb / nt);
+    m2 = m2 + m2b + delta * delta * (n * nb / nt);
+    n = nt;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm statistics (training mode)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int M, int C, int ld,
+                                                               int rows_per_chunk, float* __restrict__ ws) {
+    const ColMap cm = col_map(C, blockIdx.x);
+    const int chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+    float n = 0.f;
+    bool first = true;
+    for (int r = r0 + cm.rg; r < r1; r += cm.rpp) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + cm.c0);
+        if (first) { K = v; first = false; }
+        const float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
+        s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+        s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+        n += 1.f;
+    }
+    // per-thread (n, mean, M2) for 4 channels, then merge the row groups through LDS
+    __shared__ float sh[256][9];
+    float mean[4], m2[4];
+    const float inv = n > 0.f ? 1.f / n : 0.f;
+    mean[0] = K.x + s1.x * inv; mean[1] = K.y + s1.y * inv; mean[2] = K.z + s1.z * inv; mean[3] = K.w + s1.w * inv;
+    m2[0] = s2.x - s1.x * s1.x * inv; m2[1] = s2.y - s1.y * s1.y * inv;
+    m2[2] = s2.z - s1.z * s1.z * inv; m2[3] = s2.w - s1.w * s1.w * inv;
+    sh[threadIdx.x][0] = n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[threadIdx.x][1 + j] = mean[j]; sh[threadIdx.x][5 + j] = m2[j]; }
+    __syncthreads();
+    if (cm.rg == 0) {
+        float nn = n;
+        for (int g = 1; g < cm.rpp; ++g) {
+            const int t = g * cm.lpr + cm.cv;
+            const float nb = sh[t][0];
+            float ntmp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ntmp = nn; chan_merge(ntmp, mean[j], m2[j], nb, sh[t][1 + j], sh[t][5 + j]); }
+            nn += nb;
+        }
+        // ws layout: [chunk][3][C]  (n, mean, m2)
+        float* w = ws + (size_t)chunk * 3 * C;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w[cm.c0 + j] = nn;
+            w[C + cm.c0 + j] = mean[j];
+            w[2 * C + cm.c0 + j] = m2[j];
+        }
+    }
+}
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ ws, int chunks, int M, int C, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
+                                         float* __restrict__ rvar, float* __restrict__ smean, float* __restrict__ sinv,
+                                         float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int j = 0; j < chunks; ++j) {
+        const float* w = ws + (size_t)j * 3 * C;
+        const float nb = w[c];
+        if (n == 0.f) { n = nb; mean = w[C + c]; m2 = w[2 * C + c]; }
+        else chan_merge(n, mean, m2, nb, w[C + c], w[2 * C + c]);
+    }
+    const float var = m2 / (float)M;                       // biased (normalisation)
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (smean) smean[c] = mean;
+    if (sinv) sinv[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - mean * sc;
+    if (rmean) {
+        const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+    }
+}
+extern "C" int uem_bn_stats(const float* x, int M, int C, int ld, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* save_mean,
+                            float* save_invstd, float* scale, float* shift, float* workspace, void* stream) {
+    UEM_REQUIRE(x && scale && shift && workspace, "bn_stats: null pointer");
+    UEM_REQUIRE(M > 0 && col_shape_ok(C) && ld >= C && (ld % 4) == 0, "bn_stats: unsupported shape M=%d C=%d ld=%d", M, C, ld);
+    UEM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats must come in pairs");
+    hipStream_t st = (hipStream_t)stream;
+    int chunks = UEM_BN_SPLIT;
+    int rpc = (int)uem_cdiv(M, chunks);
+    if (rpc < 16) { rpc = 16; }
+    chunks = (int)uem_cdiv(M, rpc);
+    dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
+    bn_stats_partial_kernel<<<grid, 256, 0, st>>>(x, M, C, ld, rpc, workspace);
+    bn_stats_finalize_kernel<<<(int)uem_cdiv(C, 64), 64, 0, st>>>(workspace, chunks, M, C, gamma, beta, eps, momentum,
+                                                                  running_mean, running_var, save_mean, save_invstd, scale, shift);
+    return uem_check_launch("bn_stats");
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = (gamma ? gamma[c] : 1.f) / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+extern "C" int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+    UEM_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_affine: bad arguments");
+    bn_eval_affine_kernel<<<(int)uem_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, scale, shift, C);
+    return uem_check_launch("bn_eval_affine");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y = act(x*scale + shift (+ res))
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res,
+                                                         const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                         float* __restrict__ y, int64_t nvec, int C, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        if (res) {
+            float4 r = reinterpret_cast<const float4*>(res)[i];
+            if (rscale) {
+                const float4 rs = *reinterpret_cast<const float4*>(rscale + c);
+                const float4 rt = *reinterpret_cast<const float4*>(rshift + c);
+                r.x = r.x * rs.x + rt.x; r.y = r.y * rs.y + rt.y; r.z = r.z * rs.z + rt.z; r.w = r.w * rs.w + rt.w;
+            }
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+extern "C" int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
+                              const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
+                              void* stream) {
+    UEM_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && (C % 4) == 0, "affine_act: bad arguments");
+    UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act: bad residual affine");
+    const int64_t nvec = M * C / 4;
+    affine_act_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu);
+    return uem_check_launch("affine_act");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm backward (training stats).  dp = dy * [relu mask];  xhat = (x - mean) * invstd
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 relu_mask4(float4 dy, float4 x, float4 sc, float4 sh, const float* ymask, size_t off) {
+    float4 pre;
+    if (ymask) pre = *reinterpret_cast<const float4*>(ymask + off);       // materialised relu output
+    else { pre.x = x.x * sc.x + sh.x; pre.y = x.y * sc.y + sh.y; pre.z = x.z * sc.z + sh.z; pre.w = x.w * sc.w + sh.w; }
+    dy.x = pre.x > 0.f ? dy.x : 0.f; dy.y = pre.y > 0.f ? dy.y : 0.f;
+    dy.z = pre.z > 0.f ? dy.z : 0.f; dy.w = pre.w > 0.f ? dy.w : 0.f;
+    return dy;
+}
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ res, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ smean,
+                                                             const float* __restrict__ sinv, int M, int C, int relu,
+                                                             int rows_per_chunk, float* __restrict__ ws) {
+    const ColMap cm = col_map(C, blockIdx.x);
+    const int chunk = blockIdx.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + cm.c0);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + cm.c0);
+    const float4 mu = *reinterpret_cast<const float4*>(smean + cm.c0);
+    const float4 is = *reinterpret_cast<const float4*>(sinv + cm.c0);
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+    for (int r = r0 + cm.rg; r < r1; r += cm.rpp) {
+        const size_t off = (size_t)r * C + cm.c0;
+        const float4 xv = *reinterpret_cast<const float4*>(x + off);
+        float4 d = *reinterpret_cast<const float4*>(dy + off);
+        if (relu) d = relu_mask4(d, xv, sc, sh, res, off);
+        sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+        sg.x += d.x * ((xv.x - mu.x) * is.x); sg.y += d.y * ((xv.y - mu.y) * is.y);
+        sg.z += d.z * ((xv.z - mu.z) * is.z); sg.w += d.w * ((xv.w - mu.w) * is.w);
+    }
+    __shared__ float sh2[256][8];
+    sh2[threadIdx.x][0] = sb.x; sh2[threadIdx.x][1] = sb.y; sh2[threadIdx.x][2] = sb.z; sh2[threadIdx.x][3] = sb.w;
+    sh2[threadIdx.x][4] = sg.x; sh2[threadIdx.x][5] = sg.y; sh2[threadIdx.x][6] = sg.z; sh2[threadIdx.x][7] = sg.w;
+    __syncthreads();
+    if (cm.rg == 0) {
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = sh2[threadIdx.x][j];
+        for (int g = 1; g < cm.rpp; ++g) {
+            const int t = g * cm.lpr + cm.cv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += sh2[t][j];
+        }
+        float* w = ws + (size_t)chunk * 2 * C;      // [chunk][2][C] : dbeta, dgamma
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[cm.c0 + j] = a[j]; w[C + cm.c0 + j] = a[4 + j]; }
+    }
+}
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float b = 0.f, g = 0.f;
+    for (int j = 0; j < chunks; ++j) { b += ws[(size_t)j * 2 * C + c]; g += ws[(size_t)j * 2 * C + C + c]; }
+    dbeta[c] = b;
+    dgamma[c] = g;
+}
+extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+                                 const float* save_mean, const float* save_invstd, int M, int C, int relu, float* dgamma,
+                                 float* dbeta, float* workspace, void* stream) {
+    UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce: null pointer");
+    UEM_REQUIRE(M > 0 && col_shape_ok(C), "bn_bwd_reduce: unsupported shape M=%d C=%d", M, C);
+    hipStream_t st = (hipStream_t)stream;
+    int rpc = (int)uem_cdiv(M, UEM_BN_SPLIT);
+    if (rpc < 16) rpc = 16;
+    const int chunks = (int)uem_cdiv(M, rpc);
+    dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
+    bn_bwd_partial_kernel<<<grid, 256, 0, st>>>(x, dy, ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
+    bn_bwd_finalize_kernel<<<(int)uem_cdiv(C, 64), 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta);
+    return uem_check_launch("bn_bwd_reduce");
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ res, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ smean,
+                                                           const float* __restrict__ sinv, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, int64_t nvec, int C, float invM,
+                                                           int relu, float* __restrict__ dx, float* __restrict__ dres) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const size_t off = (size_t)i * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + off);
+        float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        if (relu) d = relu_mask4(d, xv, sc, *reinterpret_cast<const float4*>(shift + c), res, off);
+        if (dres) *reinterpret_cast<float4*>(dres + off) = d;
+        const float4 mu = *reinterpret_cast<const float4*>(smean + c);
+        const float4 is = *reinterpret_cast<const float4*>(sinv + c);
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + c);
+        const float4 db = *reinterpret_cast<const float4*>(dbeta + c);
+        float4 o;
+        o.x = sc.x * (d.x - db.x * invM - ((xv.x - mu.x) * is.x) * (dg.x * invM));
+        o.y = sc.y * (d.y - db.y * invM - ((xv.y - mu.y) * is.y) * (dg.y * invM));
+        o.z = sc.z * (d.z - db.z * invM - ((xv.z - mu.z) * is.z) * (dg.z * invM));
+        o.w = sc.w * (d.w - db.w * invM - ((xv.w - mu.w) * is.w) * (dg.w * invM));
+        *reinterpret_cast<float4*>(dx + off) = o;
+    }
+}
+extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+                                const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
+                                int M, int C, int relu, float* dx, float* dres, void* stream) {
+    UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && dx, "bn_bwd_apply: null pointer");
+    UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad shape");
+    const int64_t nvec = (int64_t)M * C / 4;
+    bn_bwd_apply_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
+        x, dy, ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
+    return uem_check_launch("bn_bwd_apply");
+}
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ res, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int64_t nvec, int C, int relu,
+                                                             float* __restrict__ dx, float* __restrict__ dres) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const size_t off = (size_t)i * 4;
+        float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        if (relu) d = relu_mask4(d, *reinterpret_cast<const float4*>(x + off), sc, *reinterpret_cast<const float4*>(shift + c), res, off);
+        if (dres) *reinterpret_cast<float4*>(dres + off) = d;
+        d.x *= sc.x; d.y *= sc.y; d.z *= sc.z; d.w *= sc.w;
+        *reinterpret_cast<float4*>(dx + off) = d;
+    }
+}
+extern "C" int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+                                  int64_t M, int C, int relu, float* dx, float* dres, void* stream) {
+    UEM_REQUIRE(x && dy && scale && shift && dx && M > 0 && C > 0 && (C % 4) == 0, "affine_act_bwd: bad arguments");
+    const int64_t nvec = M * C / 4;
+    affine_act_bwd_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, dy, ymask, scale, shift, nvec, C, relu, dx, dres);
+    return uem_check_launch("affine_act_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MaxPool 3x3 stride 2 pad 1 (first max in row-major window order wins, like torch CPU); idx in 0..8
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)N * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 4;
+        int64_t t = i / cv;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        uchar4 bi = make_uchar4(0, 0, 0, 0);
+        bool any = false;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                const unsigned char k = (unsigned char)(ky * 3 + kx);
+                if (!any) { best = v; bi = make_uchar4(k, k, k, k); any = true; }
+                else {
+                    if (v.x > best.x) { best.x = v.x; bi.x = k; }
+                    if (v.y > best.y) { best.y = v.y; bi.y = k; }
+                    if (v.z > best.z) { best.z = v.z; bi.z = k; }
+                    if (v.w > best.w) { best.w = v.w; bi.w = k; }
+                }
+            }
+        }
+        const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
+        *reinterpret_cast<float4*>(y + o) = best;
+        if (idx) *reinterpret_cast<uchar4*>(idx + o) = bi;
+    }
+}
+extern "C" int uem_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    UEM_REQUIRE(x && y && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_fwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    maxpool_fwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, idx, N, H, W, C, Ho, Wo);
+    return uem_check_launch("maxpool_fwd");
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    // gather form: input (iy, ix) collects from the <= 2x2 windows that contain it
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 4;
+        int64_t t = i / cv;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int oy0 = iy / 2, oy1 = (iy + 1) / 2;   // candidates: windows starting at 2*oy-1 covering iy
+        const int ox0 = ix / 2, ox1 = (ix + 1) / 2;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            if (oy >= Ho) continue;
+            const int ky = iy - (oy * 2 - 1);
+            if (ky < 0 || ky > 2) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                if (ox >= Wo) continue;
+                const int kx = ix - (ox * 2 - 1);
+                if (kx < 0 || kx > 2) continue;
+                const unsigned char k = (unsigned char)(ky * 3 + kx);
+                const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
+                const uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o);
+                const float4 g = *reinterpret_cast<const float4*>(dy + o);
+                if (bi.x == k) acc.x += g.x;
+                if (bi.y == k) acc.y += g.y;
+                if (bi.z == k) acc.z += g.z;
+                if (bi.w == k) acc.w += g.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (((size_t)n * H + iy) * W + ix) * C + c) = acc;
+    }
+}
+extern "C" int uem_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream) {
+    UEM_REQUIRE(dy && idx && dx && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_bwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    maxpool_bwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dy, idx, dx, N, H, W, C, Ho, Wo);
+    return uem_check_launch("maxpool_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// InstanceNorm2d (no affine, no running stats): block = (image n, 64-channel tile), 4 pixel groups
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           float* __restrict__ smean, float* __restrict__ sinv, int HW, int C,
+                                                           float eps) {
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const float* xb = x + (size_t)n * HW * C + c;
+    float K = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+    bool first = true;
+    for (int p = g; p < HW; p += 4) {
+        const float v = xb[(size_t)p * C];
+        if (first) { K = v; first = false; }
+        const float d = v - K;
+        s1 += d; s2 += d * d; cnt += 1.f;
+    }
+    __shared__ float sh[4][64][3];
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    sh[g][threadIdx.x & 63][0] = cnt;
+    sh[g][threadIdx.x & 63][1] = K + s1 * inv;
+    sh[g][threadIdx.x & 63][2] = s2 - s1 * s1 * inv;
+    __syncthreads();
+    const int l = threadIdx.x & 63;
+    float nn = sh[0][l][0], mean = sh[0][l][1], m2 = sh[0][l][2];
+    for (int j = 1; j < 4; ++j) chan_merge(nn, mean, m2, sh[j][l][0], sh[j][l][1], sh[j][l][2]);
+    const float invstd = 1.0f / sqrtf(m2 / (float)HW + eps);
+    if (g == 0) { smean[n * C + c] = mean; sinv[n * C + c] = invstd; }
+    float* yb = y + (size_t)n * HW * C + c;
+    for (int p = g; p < HW; p += 4) yb[(size_t)p * C] = (xb[(size_t)p * C] - mean) * invstd;
+}
+extern "C" int uem_instnorm_fwd(const float* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,
+                                float eps, void* stream) {
+    UEM_REQUIRE(x && y && save_mean && save_invstd && N > 0 && HW > 0 && C > 0 && (C % 64) == 0, "instnorm_fwd: bad arguments (C %% 64)");
+    instnorm_fwd_kernel<<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(x, y, save_mean, save_invstd, HW, C, eps);
+    return uem_check_launch("instnorm_fwd");
+}
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                           const float* __restrict__ sinv, float* __restrict__ dx, int HW, int C) {
+    const int n = blockIdx.y, l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
+    const size_t base = (size_t)n * HW * C + c;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = g; p < HW; p += 4) {
+        const float d = dy[base + (size_t)p * C];
+        s1 += d; s2 += d * y[base + (size_t)p * C];
+    }
+    __shared__ float sh[4][64][2];
+    sh[g][l][0] = s1; sh[g][l][1] = s2;
+    __syncthreads();
+    const float m1 = ((sh[0][l][0] + sh[1][l][0]) + (sh[2][l][0] + sh[3][l][0])) / (float)HW;
+    const float m2 = ((sh[0][l][1] + sh[1][l][1]) + (sh[2][l][1] + sh[3][l][1])) / (float)HW;
+    const float is = sinv[n * C + c];
+    for (int p = g; p < HW; p += 4) {
+        const size_t o = base + (size_t)p * C;
+        dx[o] = is * (dy[o] - m1 - y[o] * m2);
+    }
+}
+extern "C" int uem_instnorm_bwd(const float* y, const float* dy, const float* save_invstd, float* dx, int N, int HW, int C,
+                                void* stream) {
+    UEM_REQUIRE(y && dy && save_invstd && dx && N > 0 && HW > 0 && (C % 64) == 0, "instnorm_bwd: bad arguments");
+    instnorm_bwd_kernel<<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(y, dy, save_invstd, dx, HW, C);
+    return uem_check_launch("instnorm_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PPM pieces
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bin_lo(int i, int in, int out) { return (i * in) / out; }
+__device__ __forceinline__ int bin_hi(int i, int in, int out) { return ((i + 1) * in + out - 1) / out; }
+__global__ void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int S) {
+    const int64_t total = (int64_t)N * S * S * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int ox = (int)(t % S); t /= S;
+        const int oy = (int)(t % S);
+        const int n = (int)(t / S);
+        const int y0 = bin_lo(oy, H, S), y1 = bin_hi(oy, H, S), x0 = bin_lo(ox, W, S), x1 = bin_hi(ox, W, S);
+        float s = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) s += x[(((size_t)n * H + yy) * W + xx) * C + c];
+        y[i] = s / (float)((y1 - y0) * (x1 - x0));
+    }
+}
+extern "C" int uem_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int S, void* stream) {
+    UEM_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && S > 0 && S <= H && S <= W, "adaptive_avgpool_fwd: bad arguments");
+    const int64_t total = (int64_t)N * S * S * C;
+    adaptive_avgpool_fwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C, S);
+    return uem_check_launch("adaptive_avgpool_fwd");
+}
+__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int S) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        float s = 0.f;
+        for (int oy = 0; oy < S; ++oy) {
+            const int y0 = bin_lo(oy, H, S), y1 = bin_hi(oy, H, S);
+            if (yy < y0 || yy >= y1) continue;
+            for (int ox = 0; ox < S; ++ox) {
+                const int x0 = bin_lo(ox, W, S), x1 = bin_hi(ox, W, S);
+                if (xx < x0 || xx >= x1) continue;
+                s += dy[(((size_t)n * S + oy) * S + ox) * C + c] / (float)((y1 - y0) * (x1 - x0));
+            }
+        }
+        dx[i] += s;
+    }
+}
+extern "C" int uem_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int S, void* stream) {
+    UEM_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && S > 0, "adaptive_avgpool_bwd: bad arguments");
+    const int64_t total = (int64_t)N * H * W * C;
+    adaptive_avgpool_bwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dy, dx, N, H, W, C, S);
+    return uem_check_launch("adaptive_avgpool_bwd");
+}
+
+__global__ void bilinear_up_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int h, int w, int C, int H,
+                                       int W, int y_ld, int align, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, int relu) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int X = (int)(t % W); t /= W;
+        const int Y = (int)(t % H);
+        const int n = (int)(t / H);
+        const Lerp ly = lerp_setup(Y, h, H, align != 0), lx = lerp_setup(X, w, W, align != 0);
+        const float* xb = x + (size_t)n * h * w * C + c;
+        float v00 = xb[((size_t)ly.i0 * w + lx.i0) * C], v01 = xb[((size_t)ly.i0 * w + lx.i1) * C];
+        float v10 = xb[((size_t)ly.i1 * w + lx.i0) * C], v11 = xb[((size_t)ly.i1 * w + lx.i1) * C];
+        if (scale) {
+            const float sc = scale[c], sh = shift[c];
+            v00 = v00 * sc + sh; v01 = v01 * sc + sh; v10 = v10 * sc + sh; v11 = v11 * sc + sh;
+        }
+        if (relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+        y[(((size_t)n * H + Y) * W + X) * y_ld + c] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    }
+}
+extern "C" int uem_bilinear_up_fwd(const float* x, float* y, int N, int h, int w, int C, int H, int W, int y_ld,
+                                   int align_corners, const float* scale, const float* shift, int relu, void* stream) {
+    UEM_REQUIRE(x && y && N > 0 && h > 0 && w > 0 && C > 0 && H > 0 && W > 0 && y_ld >= C, "bilinear_up_fwd: bad arguments");
+    UEM_REQUIRE((scale == nullptr) == (shift == nullptr), "bilinear_up_fwd: scale/shift come in pairs");
+    const int64_t total = (int64_t)N * H * W * C;
+    bilinear_up_fwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, N, h, w, C, H, W, y_ld, align_corners, scale, shift, relu);
+    return uem_check_launch("bilinear_up_fwd");
+}
+__global__ void bilinear_up_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int h, int w, int C, int H,
+                                       int W, int dy_ld, int align) {
+    // gather: each low-res cell scans all destination pixels whose lerp touches it (h, w are tiny: PPM bins)
+    const int64_t total = (int64_t)N * h * w * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        int64_t t = i / C;
+        const int cx = (int)(t % w); t /= w;
+        const int cy = (int)(t % h);
+        const int n = (int)(t / h);
+        float s = 0.f;
+        for (int Y = 0; Y < H; ++Y) {
+            const Lerp ly = lerp_setup(Y, h, H, align != 0);
+            const float wy = (ly.i0 == cy ? ly.l0 : 0.f) + (ly.i1 == cy ? ly.l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = 0; X < W; ++X) {
+                const Lerp lx = lerp_setup(X, w, W, align != 0);
+                const float wx = (lx.i0 == cx ? lx.l0 : 0.f) + (lx.i1 == cx ? lx.l1 : 0.f);
+                if (wx == 0.f) continue;
+                s += wy * wx * dy[(((size_t)n * H + Y) * W + X) * dy_ld + c];
+            }
+        }
+        dx[i] = s;
+    }
+}
+extern "C" int uem_bilinear_up_bwd(const float* dy, float* dx, int N, int h, int w, int C, int H, int W, int dy_ld,
+                                   int align_corners, void* stream) {
+    UEM_REQUIRE(dy && dx && N > 0 && h > 0 && w > 0 && C > 0 && H > 0 && W > 0 && dy_ld >= C, "bilinear_up_bwd: bad arguments");
+    const int64_t total = (int64_t)N * h * w * C;
+    bilinear_up_bwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dy, dx, N, h, w, C, H, W, dy_ld, align_corners);
+    return uem_check_launch("bilinear_up_bwd");
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void dropout2d_mask_kernel(float* __restrict__ mask, int NC, float p, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    const float u = (float)(splitmix64(seed ^ ((uint64_t)i * 0x2545F4914F6CDD1Dull)) >> 40) * (1.0f / 16777216.0f);
+    mask[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.f;
+}
+__global__ void dropout2d_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mask,
+                                       int64_t total, int HW, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((int64_t)HW * C));
+        y[i] = x[i] * mask[n * C + c];
+    }
+}
+extern "C" int uem_dropout2d(const float* x, float* y, float* mask, int N, int HW, int C, float p, uint64_t seed, void* stream) {
+    UEM_REQUIRE(x && y && mask && N > 0 && HW > 0 && C > 0 && p >= 0.f && p < 1.f, "dropout2d: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (seed != 0) dropout2d_mask_kernel<<<(int)uem_cdiv(N * C, 256), 256, 0, st>>>(mask, N * C, p, seed);   // seed 0: reuse mask (backward)
+    const int64_t total = (int64_t)N * HW * C;
+    dropout2d_apply_kernel<<<uem_stream_grid(total, 256), 256, 0, st>>>(x, y, mask, total, HW, C);
+    return uem_check_launch("dropout2d");
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+extern "C" int uem_add_inplace(float* a, const float* b, int64_t n, void* stream) {
+    UEM_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
+    add_inplace_kernel<<<uem_stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n);
+    return uem_check_launch("add_inplace");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// layout transforms at the API edge (LDS-tiled transposes)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int Cc) {
+    // per image: x[R][Cc] -> y[Cc][R]; 32x32 tiles, block (32, 8)
+    __shared__ float tile[32][33];
+    const size_t img = (size_t)blockIdx.z * R * Cc;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < Cc) tile[j][tx] = x[img + (size_t)(r0 + j) * Cc + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < Cc && r0 + tx < R) y[img + (size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+extern "C" int uem_nhwc_to_nchw(const float* x, float* y, int N, int HW, int C, void* stream) {
+    UEM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "nhwc_to_nchw: bad arguments");
+    transpose_kernel<<<dim3((unsigned)uem_cdiv(C, 32), (unsigned)uem_cdiv(HW, 32), (unsigned)N), 256, 0, (hipStream_t)stream>>>(x, y, HW, C);
+    return uem_check_launch("nhwc_to_nchw");
+}
+extern "C" int uem_nchw_to_nhwc(const float* x, float* y, int N, int HW, int C, void* stream) {
+    UEM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "nchw_to_nhwc: bad arguments");
+    transpose_kernel<<<dim3((unsigned)uem_cdiv(HW, 32), (unsigned)uem_cdiv(C, 32), (unsigned)N), 256, 0, (hipStream_t)stream>>>(x, y, C, HW);
+    return uem_check_launch("nchw_to_nhwc");
+}
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ x4, int64_t HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / HW, p = i % HW;
+        const float* xb = x + n * 3 * HW + p;
+        reinterpret_cast<float4*>(x4)[i] = make_float4(xb[0], xb[HW], xb[2 * HW], 0.f);
+    }
+}
+extern "C" int uem_nchw3_to_nhwc4(const float* x, float* x4, int N, int H, int W, void* stream) {
+    UEM_REQUIRE(x && x4 && N > 0 && H > 0 && W > 0, "nchw3_to_nhwc4: bad arguments");
+    const int64_t HW = (int64_t)H * W, total = HW * N;
+    nchw3_to_nhwc4_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, x4, HW, total);
+    return uem_check_launch("nchw3_to_nhwc4");
+}

@@ -1,0 +1,173 @@
+"""Aligner (prototypes + online pseudo-label refinement) and DownscaleLabel on the MI355X.
+
+Drop-in for the parts of reference `uemda/gast/alignment.py` that `tools/train_ssl_uem.py` uses:
+`Aligner.__init__` (:26-77), `label_refine` (:194-293, modes all / s / p / l), `update_prototype`
+(:86-90, 328-355), `update_avg` / `init_avg` (:107-126), `_pearson_dist` (:424-451), `DownscaleLabel`
+(:484-509).  Stage-2-only losses (CORAL, whitening, class / instance alignment) are out of scope.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from ..ops import UemError, call, ptr, stream
+from ..scatter import index_max
+from . import pseudo_generation
+
+_MODES = {"all": 0, "s": 1, "p": 2, "l": 3}
+
+
+class DownscaleLabel(nn.Module):
+    def __init__(self, scale_factor=16, n_classes=7, ignore_label=-1, min_ratio=0.75):
+        super().__init__()
+        assert scale_factor > 1
+        self.scale_factor, self.n_classes = scale_factor, n_classes
+        self.ignore_label, self.min_ratio = ignore_label, min_ratio
+
+    def forward(self, label):
+        ops.need_gpu(label)
+        if label.dim() == 4:
+            label = label.squeeze(dim=1)
+        assert label.dim() == 3
+        label = label.contiguous().long()
+        b, H, W = label.shape
+        s = self.scale_factor
+        out = torch.empty((b, 1, H // s, W // s), device=label.device, dtype=torch.int64)
+        call("uem_downscale_label", ptr(label), ptr(out), b, H, W, s, self.n_classes, int(self.ignore_label),
+             float(self.min_ratio), stream())
+        return out
+
+
+class Aligner:
+    def __init__(self, logger=None, feat_channels=64, class_num=7, ignore_label=-1, decay=0.999, topk=32,
+                 resume=None, device="cuda", process_group=None):
+        self.feat_channels, self.class_num, self.ignore_label = feat_channels, class_num, ignore_label
+        self.decay, self.logger, self.eps, self.topk = decay, logger, 1e-7, topk
+        self.device = torch.device(device)
+        self.process_group = process_group
+        if resume:
+            self.prototypes = torch.load(resume, map_location='cpu').to(self.device).float().contiguous()
+            if logger is not None:
+                logger.info('finish init prototypes!')
+        else:
+            self.prototypes = torch.zeros([class_num, feat_channels], device=self.device)
+        self.downscale_gt = DownscaleLabel(scale_factor=16, n_classes=class_num, ignore_label=ignore_label,
+                                           min_ratio=0.75)
+        self._data_sum = torch.zeros([class_num, feat_channels], device=self.device)
+        self._data_cnt = torch.zeros([class_num, 1], device=self.device)
+
+    # ---- distances ------------------------------------------------------------------------------------
+    def _pearson_dist(self, feat1, feat2):
+        """(n, k) x (m, k) -> (n, m) Pearson distance in [0, 1]  (alignment.py:424-451)."""
+        ops.need_gpu(feat1, feat2)
+        a, b = feat1.detach().contiguous().float(), feat2.detach().contiguous().float()
+        n, k = a.shape
+        m = b.shape[0]
+        out = torch.empty((n, m), device=a.device, dtype=torch.float32)
+        ws = torch.empty(m * k + m, device=a.device, dtype=torch.float32)
+        call("uem_pearson_dist", ptr(a), ptr(b), ptr(out), ptr(ws), n, m, k, stream())
+        return out
+
+    def _pearson_sim_map(self, feat_nhwc):
+        n, h, w, k = feat_nhwc.shape
+        C = self.class_num
+        sim = torch.empty((n, h, w, C), device=feat_nhwc.device, dtype=torch.float32)
+        ws = torch.empty(C * k + C, device=feat_nhwc.device, dtype=torch.float32)
+        call("uem_pearson_sim", ptr(feat_nhwc), ptr(self.prototypes), ptr(sim), ptr(ws), n * h * w, k, C, stream())
+        return sim
+
+    # ---- label refinement ------------------------------------------------------------------------------
+    def label_refine(self, label_t_sup, feat_t, preds_t, label_t_soft, refine=True, mode='all', temp=2.0,
+                     sup_ignore_id=None, return_plane_max=False):
+        """Three-view refinement of the soft pseudo label (alignment.py:194-293).
+
+        `sup_ignore_id`: the ignored superpixel id; None reproduces the reference's batch-global
+        `label_t_sup.max()` (computed on the device, no host sync); pass H/16*W/16 under data parallel."""
+        if mode == 'n':
+            raise UemError("label_refine(mode='n'): the kNN view is an n x n cdist over n = B*h*w pixels, "
+                           "infeasible at the benchmark batch and flagged unusable by the reference author")
+        assert mode in _MODES
+        if not refine:
+            return label_t_soft
+        ops.need_gpu(feat_t, label_t_soft)
+        soft = label_t_soft.detach().contiguous().float()
+        B, C, H, W = soft.shape
+        feat = ops.as_nhwc(feat_t.detach())
+        _, h, w, k = feat.shape
+        dev = soft.device
+        sim = lg1 = lg2 = sup = seg = ign = None
+        S = 1
+        if mode in ('all', 'p'):
+            sim = self._pearson_sim_map(feat)
+        if mode in ('all', 'l'):
+            if isinstance(preds_t, (list, tuple)):
+                assert len(preds_t) == 2
+                lg1, lg2 = ops.as_nhwc(preds_t[0].detach()).contiguous(), ops.as_nhwc(preds_t[1].detach()).contiguous()
+            else:
+                lg1 = ops.as_nhwc(preds_t.detach()).contiguous()
+        if mode in ('all', 's'):
+            sup = label_t_sup.detach().contiguous().long()
+            if sup_ignore_id is None:
+                ign = index_max(sup)                                   # alignment.py:241 (device scalar)
+                S = (H // 16) * (W // 16) + 1
+                if getattr(self, "_sup_capacity", 0) < 1:
+                    self._sup_capacity = max(S, int(ign.item()) + 1)   # one-time host sync to size the table
+                S = max(S, self._sup_capacity)
+            else:
+                ign = torch.full((), int(sup_ignore_id), device=dev, dtype=torch.int64)
+                S = int(sup_ignore_id) + 1
+            seg = torch.zeros((B, S, C), device=dev, dtype=torch.int32)
+            call("uem_segment_max_planar", ptr(soft), ptr(sup), ptr(seg), B, C, H, W, S, stream())
+        out = torch.empty_like(soft)
+        plane_max = torch.zeros((B, C), device=dev, dtype=torch.int32)
+        call("uem_label_refine", ptr(soft), ptr(sup), ptr(sim), ptr(lg1), ptr(lg2), ptr(seg), ptr(ign), ptr(out),
+             ptr(plane_max), B, C, h, w, H, W, S, float(temp), _MODES[mode], stream())
+        self._last_plane_max = plane_max
+        return (out, plane_max) if return_plane_max else out
+
+    def refine_and_select(self, label_t_sup, feat_t, preds_t, label_t_soft, mode='all', temp=2.0, cutoff_top=0.8,
+                          cutoff_low=0.6, sup_ignore_id=None):
+        """label_refine + pseudo_selection sharing the per-class maxima computed inside the fused kernel
+        (saves one full pass over the (B,C,H,W) map); identical results to calling the two in sequence."""
+        soft, pm = self.label_refine(label_t_sup, feat_t, preds_t, label_t_soft, True, mode, temp, sup_ignore_id, True)
+        hard = pseudo_generation.pseudo_selection(soft, cutoff_top, cutoff_low, 'tensor', self.ignore_label,
+                                                  _plane_max=pm, check_range=False)
+        return soft, hard
+
+    # ---- prototypes --------------------------------------------------------------------------------------
+    def _class_sums(self, feat, label_ds):
+        feat = ops.as_nhwc(feat.detach())
+        n, h, w, k = feat.shape
+        C = self.class_num
+        lab = label_ds.contiguous().view(-1)
+        sums = torch.empty((C, k), device=feat.device, dtype=torch.float32)
+        cnts = torch.empty((C,), device=feat.device, dtype=torch.float32)
+        ws = torch.empty(_lib.UEM_PROTO_SPLIT * C * (k + 1), device=feat.device, dtype=torch.float32)
+        call("uem_proto_sums", ptr(feat), ptr(lab), ptr(sums), ptr(cnts), ptr(ws), n * h * w, k, C,
+             int(self.ignore_label), stream())
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(self.process_group) > 1:
+            # replicas must see the same prototypes: reduce the partial sums BEFORE the division / EMA
+            packed = torch.cat([sums.view(-1), cnts])
+            torch.distributed.all_reduce(packed, group=self.process_group)
+            sums, cnts = packed[:C * k].view(C, k), packed[C * k:]
+        return sums, cnts
+
+    def update_prototype(self, feat, label):
+        """EMA update from source features + labels; returns the downscaled label (alignment.py:86-90)."""
+        label = self.downscale_gt(label)
+        sums, cnts = self._class_sums(feat, label)
+        k = sums.shape[1]
+        self.prototypes = self.prototypes.contiguous()
+        call("uem_proto_ema", ptr(sums), ptr(cnts), ptr(self.prototypes), k, self.class_num, float(self.decay), stream())
+        return label
+
+    def update_avg(self, feat, label):
+        label = self.downscale_gt(label)                                       # alignment.py:107-119
+        sums, cnts = self._class_sums(feat, label)
+        ops.add_(self._data_sum, sums)
+        ops.add_(self._data_cnt, cnts.view(-1, 1).contiguous())
+
+    def init_avg(self):
+        # prototypes = sum / (cnt + eps): expressed with the EMA kernel is not possible (decay in (0,1));
+        # this runs once per stage, on (C, k) values, through the proto_ema kernel with counts forced >= 1
+        raise UemError("init_avg belongs to tools/init_prototypes.py (SURVEY section 8 f3, 'next'); not built yet")

@@ -1,0 +1,34 @@
+"""pseudo_selection on the MI355X (reference uemda/gast/pseudo_generation.py:59-93)."""
+import torch
+
+from .. import ops
+from ..ops import UemError, call, ptr, stream
+
+
+def _select(mask, plane_max, cutoff_top, cutoff_low, ignore_label, check_range=True):
+    B, C, H, W = mask.shape
+    hard = torch.empty((B, H, W), device=mask.device, dtype=torch.int64)
+    flag = torch.zeros((), device=mask.device, dtype=torch.int32)
+    call("uem_pseudo_select", ptr(mask), ptr(plane_max), ptr(hard), ptr(flag), B, C, H * W, float(cutoff_top),
+         float(cutoff_low), int(ignore_label), stream())
+    if check_range and int(flag.item()) != 0:
+        # the reference asserts 0 <= mask <= 1 (pseudo_generation.py:71), which is a host sync there too
+        raise AssertionError("pseudo_selection: mask values outside [0, 1]")
+    return hard
+
+
+def pseudo_selection(mask, cutoff_top=0.8, cutoff_low=0.6, return_type='ndarray', ignore_label=-1,
+                     _plane_max=None, check_range=True):
+    """(b, c, h, w) probabilities -> (b, h, w) int64 labels: the unique class above its per-image,
+    per-class threshold max(cutoff_top * max_p, cutoff_low), else `ignore_label`."""
+    assert return_type in ['ndarray', 'tensor']
+    ops.need_gpu(mask)
+    if mask.dim() != 4 or mask.dtype != torch.float32:
+        raise UemError("pseudo_selection expects a float32 (b, c, h, w) tensor")
+    m = mask.contiguous()
+    B, C, H, W = m.shape
+    if _plane_max is None:
+        _plane_max = torch.empty((B, C), device=m.device, dtype=torch.int32)
+        call("uem_plane_max", ptr(m), ptr(_plane_max), B, C, H * W, stream())
+    ret = _select(m, _plane_max, cutoff_top, cutoff_low, ignore_label, check_range)
+    return ret.cpu().numpy() if return_type == 'ndarray' else ret

@@ -1,0 +1,159 @@
+"""Deeplabv2 = ResNet encoder + InstanceNorm + two ASPP / PPM heads, MI355X-native.
+
+Drop-in for reference `uemda/models/Encoder.py:87-186` (same constructor dict, same forward contract,
+same `state_dict()` keys and OIHW layouts).  nn.Conv2d / nn.BatchNorm2d objects are
+used purely as parameter and buffer HOLDERS (so the key names match the reference); their torch
+`forward` is never called -- the forward/backward run through uemda_amd.models.blocks on hand-written
+HIP kernels.  There is no CPU path: calling the model with CPU tensors raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import UemError
+from ..resnet import ResNetEncoder
+from . import blocks
+from .config import AttrDict
+
+
+class Classifier_Module(nn.Module):
+    """ASPP head: parameter holder with the reference's layout (Encoder.py:68-84)."""
+
+    def __init__(self, inplanes, dilation_series, padding_series, num_classes):
+        super().__init__()
+        self.dilations = tuple(dilation_series)
+        self.conv2d_list = nn.ModuleList()
+        for dilation, padding in zip(dilation_series, padding_series):
+            if dilation != padding:
+                raise UemError("Classifier_Module: padding must equal dilation")
+            self.conv2d_list.append(nn.Conv2d(inplanes, num_classes, kernel_size=3, stride=1, padding=padding,
+                                              dilation=dilation, bias=True))
+        for m in self.conv2d_list:
+            m.weight.data.normal_(0, 0.01)                     # Encoder.py:77-78
+
+
+class PPMBilinear(nn.Module):
+    """PPM head: parameter holder with the reference's layout (Encoder.py:8-41)."""
+
+    def __init__(self, num_classes=7, fc_dim=2048, use_aux=False, pool_scales=(1, 2, 3, 6),
+                 norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        if use_aux:
+            raise UemError("PPMBilinear(use_aux=True) is not on the UemDA path (never set by the scripts)")
+        self.pool_scales = tuple(pool_scales)
+        self.ppm = nn.ModuleList([nn.Sequential(nn.AdaptiveAvgPool2d(s), nn.Conv2d(fc_dim, 512, 1, bias=False),
+                                                norm_layer(512), nn.ReLU(inplace=True)) for s in pool_scales])
+        self.conv_last = nn.Sequential(
+            nn.Conv2d(fc_dim + len(pool_scales) * 512, 512, kernel_size=3, padding=1, bias=False),
+            norm_layer(512), nn.ReLU(inplace=True), nn.Dropout2d(0.1), nn.Conv2d(512, num_classes, kernel_size=1))
+
+
+class Deeplabv2(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = AttrDict()
+        self.set_default_config()
+        self.config.update(config)
+        cfg = self.config
+        if not cfg.multi_layer or cfg.cascade:
+            raise UemError("only the multi_layer=True, cascade=False branch (the one every UemDA script "
+                           "instantiates, train_ssl_uem.py:91-108) is implemented")
+        self.encoder = ResNetEncoder(cfg.backbone)
+        if cfg.use_ppm:
+            ppm_cfg = {k: v for k, v in cfg.ppm.items() if k != "norm_layer"}
+            self.layer5 = PPMBilinear(**ppm_cfg)
+            self.layer6 = PPMBilinear(**ppm_cfg)
+        else:
+            self.layer5 = Classifier_Module(cfg.inchannels, [6, 12, 18, 24], [6, 12, 18, 24], cfg.num_classes)
+            self.layer6 = Classifier_Module(cfg.inchannels, [6, 12, 18, 24], [6, 12, 18, 24], cfg.num_classes)
+        if cfg.is_ins_norm:
+            self.instance_norm = nn.InstanceNorm2d(cfg.inchannels)      # holder (no parameters)
+        self._arena = None
+        self._grad_arena = None
+
+    def set_default_config(self):
+        self.config.update(dict(
+            backbone=dict(resnet_type='resnet50', output_stride=16, pretrained=True),
+            multi_layer=False, cascade=False, use_ppm=False,
+            ppm=dict(num_classes=7, use_aux=False, norm_layer=nn.BatchNorm2d),
+            inchannels=2048, num_classes=7, is_ins_norm=False))
+
+    # ---- flat parameter / gradient arenas ----------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten_parameters()
+        return out
+
+    def _flatten_parameters(self):
+        """Re-home every parameter in ONE flat fp32 buffer (conv weights in channels_last = OHWI order) and
+        give it a matching slot in a flat gradient buffer: the fused optimizer and the RCCL gradient
+        all-reduce then work on two contiguous arrays."""
+        params = [p for p in self.parameters()]
+        if not params:
+            return
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        total_pad = (total + 3) // 4 * 4
+        arena = torch.zeros(total_pad, device=dev, dtype=torch.float32)
+        garena = torch.zeros(total_pad, device=dev, dtype=torch.float32)
+        off = 0
+        for p in params:
+            n = p.numel()
+
+            def view_of(buf, p=p, off=off, n=n):
+                flat = buf[off:off + n]
+                if p.dim() == 4:
+                    o, i, kh, kw = p.shape
+                    return flat.view(o, kh, kw, i).permute(0, 3, 1, 2)
+                return flat.view(p.shape)
+            v = view_of(arena)
+            v.copy_(p.data)
+            p.data = v
+            had_grad = p.grad is not None
+            if had_grad:
+                gv = view_of(garena)
+                gv.copy_(p.grad)
+                p.grad = gv
+            p._uem_grad_view = (lambda vo=view_of, ga=garena: vo(ga))
+            p._uem_owner = self
+            off += n
+        self._arena, self._grad_arena, self._n_params = arena, garena, total
+
+    def flat_parameters(self):
+        return self._arena, self._grad_arena, self._n_params
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the flat gradient arena (one memset) and keep every .grad attached to it."""
+        if self._grad_arena is None:
+            return super().zero_grad(set_to_none)
+        self._grad_arena.zero_()
+        for p in self.parameters():
+            if p.grad is None:
+                p.grad = p._uem_grad_view()
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def _heads(self, feat):
+        if self.config.use_ppm:
+            from . import ppm
+            return ppm.ppm_head(feat, self.layer5), ppm.ppm_head(feat, self.layer6)
+        params = list(self.layer5.parameters()) + list(self.layer6.parameters())
+        return blocks.ASPPHeadsFn.apply(feat, self.layer5, self.layer6, *params)
+
+    def forward(self, x):
+        ops.need_gpu(x)
+        if self._arena is None:
+            raise UemError("Deeplabv2: move the model to the MI355X device first (model.cuda())")
+        feat = self.encoder.forward_nhwc(x)[-1]                               # Encoder.py:145
+        if self.config.is_ins_norm:
+            feat = blocks.InstNormFn.apply(feat, self.instance_norm.eps)      # Encoder.py:146-147
+        x1, x2 = self._heads(feat)
+        if self.training:
+            return ops.as_nchw_view(x1), ops.as_nchw_view(x2), ops.as_nchw_view(feat)   # Encoder.py:150-151
+        n, h, w, c = x1.shape
+        H, W = x.shape[-2:]
+        prob = torch.empty((n, c, H, W), device=x.device, dtype=torch.float32)
+        ops.call("uem_upsample_softmax_avg", ops.ptr(x1.contiguous()), ops.ptr(x2.contiguous()), ops.ptr(prob),
+                 n, c, h, w, H, W, ops.stream())                               # Encoder.py:153-155
+        return prob

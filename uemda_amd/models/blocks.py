@@ -1,0 +1,225 @@
+"""autograd nodes of the segmentation network.  One coarse node per residual block / stem / head so
+that every arithmetic step inside is a HIP kernel launch (uemda_amd.ops) and the saved state is
+exactly what the hand-written backward needs:
+
+  raw conv outputs z (pre-BatchNorm), the per-channel BN operands (scale/shift/mean/invstd) and the
+  materialised block outputs.  BN-apply + ReLU between convs is never materialised: it is the
+  operand prologue of the consuming conv (forward, wgrad) and is recomputed as a mask in backward.
+
+Parameter gradients are accumulated straight into `param.grad` (views of the model's flat gradient
+arena; conv wgrad lands there with fp32 atomics) and the nodes return None for them.
+Reference semantics: uemda/_resnets.py:72-112,149-153,205-212; uemda/models/Encoder.py:68-84,123.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import ops
+from ..ops import UemError
+
+
+def grad_buffer(p):
+    """The tensor wgrad kernels accumulate into: p.grad, (re)attached to the flat arena when None."""
+    if p.grad is None:
+        maker = getattr(p, "_uem_grad_view", None)
+        g = maker() if maker is not None else torch.zeros_like(p)
+        if maker is not None:
+            g.zero_()
+        p.grad = g
+    return p.grad
+
+
+def grad_ohwi(p):
+    g = grad_buffer(p).permute(0, 2, 3, 1)
+    if not g.is_contiguous():
+        raise UemError("conv weight .grad is not channels_last; let the model own its gradient arena")
+    return g
+
+
+class _BN:
+    """view of an nn.BatchNorm2d used as a parameter/buffer holder"""
+
+    @staticmethod
+    def stats(x, bn):
+        tr = bn.training or bn.running_mean is None
+        return ops.bn_stats(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, tr,
+                            bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+
+
+def _st_tensor(st):
+    # the four vectors of a BNState live in one (4, C) buffer: recover it from the first view
+    return st.scale._base if st.scale._base is not None else st.scale
+
+
+def _st_from(buf, training=True):
+    st = ops.BNState()
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    st.training = training
+    return st
+
+
+class StemFn(Function):
+    """conv7x7 s2 -> BN -> ReLU -> maxpool3x3 s2   (_resnets.py:149-153, resnet.py:142-143)"""
+
+    @staticmethod
+    def forward(ctx, x, resnet, *params):
+        x4 = ops.nchw3_to_nhwc4(x)
+        z = ops.stem_conv(x4, ops.weight_ohwi(resnet.conv1.weight))
+        st = _BN.stats(z, resnet.bn1)
+        a = ops.affine_act(z, st, relu=True)
+        need = any(ctx.needs_input_grad)
+        y, idx = ops.maxpool_fwd(a, need)
+        if resnet.bn1.training:
+            resnet.bn1.num_batches_tracked.add_(1)
+        if need:
+            ctx.resnet = resnet
+            ctx.training = st.training
+            ctx.save_for_backward(x4, z, _st_tensor(st), idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x4, z, stbuf, idx = ctx.saved_tensors
+        resnet = ctx.resnet
+        st = _st_from(stbuf, ctx.training)
+        da = ops.maxpool_bwd(dy.contiguous(), idx, z.shape)
+        dz = ops.bn_backward(z, da, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias), None, True, dx=da)
+        ops.stem_wgrad(x4, dz, grad_ohwi(resnet.conv1.weight))
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class BottleneckFn(Function):
+    """1x1 -> BN -> ReLU -> 3x3(stride, dilation) -> BN -> ReLU -> 1x1 -> BN (+ downsample) -> add -> ReLU
+    (_resnets.py:92-112).  `blk` carries conv1..3, bn1..3, downsample, stride, dilation."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        W = ops.weight_ohwi
+        s, d = blk.stride, blk.dilation
+        z1 = ops.conv2d(x, W(blk.conv1.weight))
+        st1 = _BN.stats(z1, blk.bn1)
+        z2 = ops.conv2d(z1, W(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
+        st2 = _BN.stats(z2, blk.bn2)
+        z3 = ops.conv2d(z2, W(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
+        st3 = _BN.stats(z3, blk.bn3)
+        has_ds = blk.downsample is not None
+        if has_ds:
+            zd = ops.conv2d(x, W(blk.downsample[0].weight), stride=s)
+            std = _BN.stats(zd, blk.downsample[1])
+            y = ops.affine_act(z3, st3, res=zd, res_st=std, relu=True)
+        else:
+            zd, std = None, None
+            y = ops.affine_act(z3, st3, res=x, relu=True)
+        if blk.bn1.training:
+            blk._nbt_add()
+        if any(ctx.needs_input_grad):
+            ctx.blk = blk
+            ctx.has_ds = has_ds
+            ctx.training = st1.training
+            saved = [x, y, z1, z2, z3, _st_tensor(st1), _st_tensor(st2), _st_tensor(st3)]
+            if has_ds:
+                saved += [zd, _st_tensor(std)]
+            ctx.save_for_backward(*saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        blk = ctx.blk
+        sv = ctx.saved_tensors
+        x, y, z1, z2, z3 = sv[:5]
+        st1, st2, st3 = (_st_from(b, ctx.training) for b in sv[5:8])
+        s, d = blk.stride, blk.dilation
+        W, G, gb = ops.weight_ohwi, grad_ohwi, grad_buffer
+        dy = dy.contiguous()
+        # BN3 + residual + ReLU: mask from the materialised output y; dp = grad of the pre-ReLU sum
+        dp = torch.empty_like(dy)
+        dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), ymask=y, relu=True, dres=dp)
+        ops.conv2d_wgrad(z2, dz3, G(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
+        da2 = ops.conv2d_dgrad(dz3, ops.weight_transpose(W(blk.conv3.weight)), z2.shape)
+        del dz3
+        dz2 = ops.bn_backward(z2, da2, st2, gb(blk.bn2.weight), gb(blk.bn2.bias), None, True, dx=da2)
+        ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
+        da1 = ops.conv2d_dgrad(dz2, ops.weight_transpose(W(blk.conv2.weight)), z1.shape, stride=s, pad=d, dil=d)
+        del dz2, da2
+        dz1 = ops.bn_backward(z1, da1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), None, True, dx=da1)
+        ops.conv2d_wgrad(x, dz1, G(blk.conv1.weight))
+        wt1 = ops.weight_transpose(W(blk.conv1.weight))
+        if ctx.has_ds:
+            zd, std = sv[8], _st_from(sv[9], ctx.training)
+            ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
+            dzd = ops.bn_backward(zd, dp, std, gb(ds_bn.weight), gb(ds_bn.bias), None, False, dx=dp)
+            ops.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s)
+            dx = ops.conv2d_dgrad(dz1, wt1, x.shape)
+            ops.conv2d_dgrad(dzd, ops.weight_transpose(W(ds_conv.weight)), x.shape, stride=s, out=dx, accumulate=True)
+        else:
+            dx = ops.conv2d_dgrad(dz1, wt1, x.shape, out=dp, accumulate=True)     # identity grad + conv1 dgrad
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class InstNormFn(Function):
+    """nn.InstanceNorm2d(affine=False, track_running_stats=False)  (Encoder.py:123,147)"""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, invstd = ops.instnorm_fwd(x, eps)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(y, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, invstd = ctx.saved_tensors
+        return ops.instnorm_bwd(y, dy.contiguous(), invstd), None
+
+
+class ASPPHeadsFn(Function):
+    """Both Classifier_Module heads (Encoder.py:68-84) in one pass over `feat`: per dilation the two
+    heads' filters are stacked into one 32-row (zero padded) filter bank, the four dilated convs
+    accumulate into one (N,h,w,32) buffer (the reference's `out += conv_i(x)`)."""
+
+    @staticmethod
+    def forward(ctx, feat, head5, head6, *params):
+        C = head5.conv2d_list[0].weight.shape[0]
+        cin = feat.shape[3]
+        if 2 * C > 32:
+            raise UemError("ASPP heads: more than 16 classes are not supported by the packed head")
+        dils = head5.dilations
+        wp = torch.zeros((len(dils), 32, 3, 3, cin), device=feat.device, dtype=torch.float32)
+        bp = torch.zeros((len(dils), 32), device=feat.device, dtype=torch.float32)
+        for i in range(len(dils)):
+            wp[i, 0:C].copy_(ops.weight_ohwi(head5.conv2d_list[i].weight))
+            wp[i, C:2 * C].copy_(ops.weight_ohwi(head6.conv2d_list[i].weight))
+            bp[i, 0:C].copy_(head5.conv2d_list[i].bias.detach())
+            bp[i, C:2 * C].copy_(head6.conv2d_list[i].bias.detach())
+        out = None
+        for i, d in enumerate(dils):
+            out = ops.conv2d(feat, wp[i], bp[i], pad=d, dil=d, out=out, accumulate=(i > 0))
+        x1 = out[..., 0:C].contiguous()
+        x2 = out[..., C:2 * C].contiguous()
+        if any(ctx.needs_input_grad):
+            ctx.heads = (head5, head6)
+            ctx.save_for_backward(feat, wp)
+        return x1, x2
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        feat, wp = ctx.saved_tensors
+        head5, head6 = ctx.heads
+        C = head5.conv2d_list[0].weight.shape[0]
+        dils = head5.dilations
+        n, h, w, cin = feat.shape
+        d32 = torch.zeros((n, h, w, 32), device=feat.device, dtype=torch.float32)
+        d32[..., 0:C].copy_(d1)
+        d32[..., C:2 * C].copy_(d2)
+        db = torch.zeros(32, device=feat.device, dtype=torch.float32)
+        ops.bias_grad(d32, db, 32, 32)
+        dfeat = None
+        for i, d in enumerate(dils):
+            dwp = torch.zeros((32, 3, 3, cin), device=feat.device, dtype=torch.float32)
+            ops.conv2d_wgrad(feat, d32, dwp, pad=d, dil=d)
+            for head, lo in ((head5, 0), (head6, C)):
+                conv = head.conv2d_list[i]
+                ops.add_(grad_ohwi(conv.weight), dwp[lo:lo + C])
+                ops.add_(grad_buffer(conv.bias), db[lo:lo + C])
+            dfeat = ops.conv2d_dgrad(d32, ops.weight_transpose(wp[i]), feat.shape, pad=d, dil=d, out=dfeat,
+                                     accumulate=(i > 0))
+        return (dfeat, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

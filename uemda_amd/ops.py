@@ -1,0 +1,273 @@
+"""Tensor-level wrappers over the C ABI (raw pointers + sizes).  torch is plumbing only: it owns the
+device allocations and the stream; every arithmetic step is a `uem_*` HIP kernel.
+
+Internal activation layout is NHWC: tensors of shape (N, H, W, C), contiguous, fp32.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CONV_ACCUMULATE, CONV_IN_AFFINE, CONV_IN_RELU, CONV_TRANSPOSED, ConvShape, UemError, call
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise UemError("uemda_amd: the HIP path needs tensors on the MI355X device "
+                           "(there is no CPU / PyTorch fallback)")
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise UemError(f"{what}: expected a contiguous float32 tensor, got {t.dtype} strides={t.stride()}")
+    return t
+
+
+def conv_out_size(h, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def weight_ohwi(w):
+    """Physical OHWI view of a conv weight whose logical shape is OIHW (channels_last storage)."""
+    v = w.detach().permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise UemError("conv weight is not in channels_last (OHWI) storage; call model._flatten_parameters()")
+    return v
+
+
+def _shape(x, cout, kh, kw, stride, pad, dil, x_ld=None, y_ld=None):
+    n, h, w, cin = x.shape
+    s = ConvShape()
+    s.N, s.H, s.W, s.Cin = n, h, w, cin
+    s.Ho, s.Wo, s.Cout = conv_out_size(h, kh, stride, pad, dil), conv_out_size(w, kw, stride, pad, dil), cout
+    s.KH, s.KW, s.stride, s.pad, s.dil = kh, kw, stride, pad, dil
+    s.x_ld = cin if x_ld is None else x_ld
+    s.y_ld = cout if y_ld is None else y_ld
+    return s
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+def conv2d(x, w_ohwi, bias=None, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
+           out=None, accumulate=False):
+    """y = conv(prologue(x), w) + bias.  x (N,H,W,Cin); w (Cout,KH,KW,Cin); returns (N,Ho,Wo,Cout)."""
+    need_gpu(x, w_ohwi)
+    _f32c(x, "conv2d x"), _f32c(w_ohwi, "conv2d w")
+    cout, kh, kw, cin = w_ohwi.shape
+    if cin != x.shape[3]:
+        raise UemError(f"conv2d: Cin mismatch {cin} vs {x.shape[3]}")
+    s = _shape(x, cout, kh, kw, stride, pad, dil)
+    if out is None:
+        out = torch.empty((s.N, s.Ho, s.Wo, cout), device=x.device, dtype=torch.float32)
+    flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0) | \
+            (CONV_ACCUMULATE if accumulate else 0)
+    call("uem_conv2d_fwd", ptr(x), ptr(w_ohwi), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(out),
+         ctypes.byref(s), flags, stream())
+    return out
+
+
+def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False):
+    """dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout); w_t = weight_transpose(w) of shape (Cin,KH,KW,Cout)."""
+    need_gpu(dy, w_t)
+    _f32c(dy, "dgrad dy"), _f32c(w_t, "dgrad w_t")
+    cin, kh, kw, cout = w_t.shape
+    n, h, w, _ = x_shape
+    s = ConvShape()
+    s.N, s.H, s.W, s.Cin = n, h, w, cin
+    s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], cout
+    s.KH, s.KW, s.stride, s.pad, s.dil = kh, kw, stride, pad, dil
+    s.x_ld, s.y_ld = cin, cout
+    if out is None:
+        out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
+    flags = CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0)
+    call("uem_conv2d_fwd", ptr(dy), ptr(w_t), None, None, None, ptr(out), ctypes.byref(s), flags, stream())
+    return out
+
+
+def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False):
+    """dw (Cout,KH,KW,Cin) += dy^T * im2col(prologue(x)).  dw must be contiguous (atomics land in it)."""
+    need_gpu(x, dy, dw_ohwi)
+    _f32c(x, "wgrad x"), _f32c(dy, "wgrad dy"), _f32c(dw_ohwi, "wgrad dw")
+    cout, kh, kw, cin = dw_ohwi.shape
+    s = _shape(x, cout, kh, kw, stride, pad, dil)
+    if (s.Ho, s.Wo) != (dy.shape[1], dy.shape[2]):
+        raise UemError("conv2d_wgrad: dy spatial size mismatch")
+    flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0)
+    call("uem_conv2d_wgrad", ptr(x), ptr(dy), ptr(in_scale), ptr(in_shift), ptr(dw_ohwi), ctypes.byref(s),
+         flags, stream())
+
+
+def weight_transpose(w_ohwi):
+    cout, kh, kw, cin = w_ohwi.shape
+    wt = torch.empty((cin, kh, kw, cout), device=w_ohwi.device, dtype=torch.float32)
+    call("uem_weight_transpose", ptr(w_ohwi), ptr(wt), cout, kh, kw, cin, stream())
+    return wt
+
+
+def nchw3_to_nhwc4(x):
+    need_gpu(x)
+    x = _f32c(x.contiguous(), "image")
+    n, c, h, w = x.shape
+    if c != 3:
+        raise UemError("stem expects 3 input channels")
+    x4 = torch.empty((n, h, w, 4), device=x.device, dtype=torch.float32)
+    call("uem_nchw3_to_nhwc4", ptr(x), ptr(x4), n, h, w, stream())
+    return x4
+
+
+def stem_conv(x4, w_ohwi):
+    n, h, w, _ = x4.shape
+    w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+    call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
+    y = torch.empty((n, conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1), 64), device=x4.device,
+                    dtype=torch.float32)
+    call("uem_conv2d_stem_fwd", ptr(x4), ptr(w8), ptr(y), n, h, w, stream())
+    return y
+
+
+def stem_wgrad(x4, dy, dw_ohwi):
+    n, h, w, _ = x4.shape
+    dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+    call("uem_conv2d_stem_wgrad", ptr(x4), ptr(dy), ptr(dw8), n, h, w, stream())
+    call("uem_stem_unpack_grad", ptr(dw8), ptr(dw_ohwi), stream())
+
+
+def bias_grad(dy2d, db, C, ld):
+    call("uem_bias_grad", ptr(dy2d), ptr(db), dy2d.numel() // ld, C, ld, stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+class BNState:
+    """Per-call BatchNorm operands: scale/shift (conv prologue form) and the saved statistics."""
+    __slots__ = ("scale", "shift", "mean", "invstd", "training")
+
+
+def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Batch statistics of x (.., C) -> BNState; updates the running stats in training mode."""
+    need_gpu(x)
+    C = x.shape[-1]
+    M = x.numel() // C
+    st = BNState()
+    st.training = training
+    dev = x.device
+    buf = torch.empty((4, C), device=dev, dtype=torch.float32)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    if training:
+        ws = torch.empty(3 * C * _lib.UEM_BN_SPLIT, device=dev, dtype=torch.float32)
+        call("uem_bn_stats", ptr(x), M, C, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+             ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws), stream())
+    else:
+        call("uem_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps,
+             ptr(st.scale), ptr(st.shift), C, stream())
+    return st
+
+
+def affine_act(x, st, res=None, res_st=None, relu=True, out=None):
+    C = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    call("uem_affine_act", ptr(x), ptr(st.scale), ptr(st.shift), ptr(res),
+         ptr(res_st.scale) if res_st is not None else None, ptr(res_st.shift) if res_st is not None else None,
+         ptr(out), x.numel() // C, C, 1 if relu else 0, stream())
+    return out
+
+
+def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None, dres=None):
+    """BatchNorm(+ReLU) backward.  Accumulates into gamma_grad/beta_grad; returns dx (may alias dy)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x) if dx is None else dx
+    if st.training:
+        tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * C * _lib.UEM_BN_SPLIT, device=x.device, dtype=torch.float32)
+        call("uem_bn_bwd_reduce", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+             ptr(st.invstd), M, C, 1 if relu else 0, ptr(tmp[0]), ptr(tmp[1]), ptr(ws), stream())
+        call("uem_bn_bwd_apply", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+             ptr(st.invstd), ptr(tmp[0]), ptr(tmp[1]), M, C, 1 if relu else 0, ptr(dx), ptr(dres), stream())
+        if gamma_grad is not None:
+            call("uem_add_inplace", ptr(gamma_grad), ptr(tmp[0]), C, stream())
+            call("uem_add_inplace", ptr(beta_grad), ptr(tmp[1]), C, stream())
+    else:
+        # frozen statistics (eval-mode BN inside a graph): dx = dp * scale; dgamma/dbeta via the reduce
+        raise UemError("backward through eval-mode BatchNorm is not supported (reference never does it)")
+    return dx
+
+
+def maxpool_fwd(x, want_idx):
+    n, h, w, c = x.shape
+    ho, wo = conv_out_size(h, 3, 2, 1, 1), conv_out_size(w, 3, 2, 1, 1)
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    idx = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_idx else None
+    call("uem_maxpool3x3s2_fwd", ptr(x), ptr(y), ptr(idx), n, h, w, c, stream())
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape):
+    n, h, w, c = in_shape
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    call("uem_maxpool3x3s2_bwd", ptr(dy), ptr(idx), ptr(dx), n, h, w, c, stream())
+    return dx
+
+
+def instnorm_fwd(x, eps=1e-5):
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((2, n, c), device=x.device, dtype=torch.float32)
+    call("uem_instnorm_fwd", ptr(x), ptr(y), ptr(stats[0]), ptr(stats[1]), n, h * w, c, eps, stream())
+    return y, stats[1]
+
+
+def instnorm_bwd(y, dy, invstd):
+    n, h, w, c = y.shape
+    dx = torch.empty_like(y)
+    call("uem_instnorm_bwd", ptr(y), ptr(dy), ptr(invstd), ptr(dx), n, h * w, c, stream())
+    return dx
+
+
+def add_(a, b):
+    call("uem_add_inplace", ptr(a), ptr(b), a.numel(), stream())
+    return a
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    call("uem_nhwc_to_nchw", ptr(x), ptr(y), n, h * w, c, stream())
+    return y
+
+
+def nchw_to_nhwc(x):
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+    call("uem_nchw_to_nhwc", ptr(x), ptr(y), n, h * w, c, stream())
+    return y
+
+
+def as_nhwc(t):
+    """(N,C,H,W) logical tensor -> dense (N,H,W,C) fp32 tensor (zero-copy when already channels_last)."""
+    need_gpu(t)
+    if t.dtype != torch.float32:
+        raise UemError("expected float32")
+    v = t.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    return nchw_to_nhwc(t.contiguous())
+
+
+def as_nchw_view(x_nhwc):
+    """dense (N,H,W,C) -> logical (N,C,H,W) view (channels_last strides, zero-copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)

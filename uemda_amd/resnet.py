@@ -1,0 +1,138 @@
+"""ResNet-50/101 encoder (OS16: layer4 de-strided and dilated), MI355X-native.
+
+Mirrors reference `uemda/resnet.py:43-208` (ResNetEncoder) and `uemda/_resnets.py:72-227` (Bottleneck,
+ResNet): same module tree => same state_dict keys.  The modules hold parameters; the arithmetic runs in
+uemda_amd.models.blocks (HIP kernels)."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .models import blocks
+from .models.config import AttrDict
+from .ops import UemError
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    @property
+    def stride(self):
+        return self.conv2.stride[0]
+
+    @property
+    def dilation(self):
+        return self.conv2.dilation[0]
+
+    def _bns(self):
+        bns = [self.bn1, self.bn2, self.bn3]
+        if self.downsample is not None:
+            bns.append(self.downsample[1])
+        return bns
+
+    def _nbt_add(self):
+        for bn in self._bns():
+            bn.num_batches_tracked.add_(1)
+
+    def forward(self, x):                      # x: (N,H,W,C) dense NHWC
+        return blocks.BottleneckFn.apply(x, self, *list(self.parameters()))
+
+
+class ResNet(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        for m in self.modules():                                   # _resnets.py:164-169
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, nblocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, nblocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+
+_LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}
+
+
+class ResNetEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = AttrDict()
+        self.config.update(dict(resnet_type='resnet50', include_conv5=True, batchnorm_trainable=True,
+                                pretrained=False, freeze_at=0, output_stride=32,
+                                with_cp=(False, False, False, False)))          # resnet.py:170-181
+        self.config.update(config)
+        cfg = self.config
+        if cfg.output_stride not in (8, 16, 32):
+            raise ValueError('output_stride must be 8, 16 or 32.')               # resnet.py:48-51
+        if cfg.resnet_type not in _LAYERS:
+            raise UemError(f"resnet_type {cfg.resnet_type!r} not supported (resnet50 / resnet101)")
+        if cfg.freeze_at != 0 or not cfg.batchnorm_trainable or any(cfg.with_cp):
+            raise UemError("freeze_at / frozen BN / checkpointing are not used by the UemDA scripts; not implemented")
+        self.resnet = ResNet(_LAYERS[cfg.resnet_type])
+        if isinstance(cfg.pretrained, str):
+            # no network on the box: a local torchvision-format checkpoint path may be given instead of True
+            sd = torch.load(cfg.pretrained, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            self.resnet.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+        if cfg.output_stride == 16:                                              # resnet.py:62-63
+            self.resnet.layer4.apply(partial(self._nostride_dilate, dilate=2))
+        elif cfg.output_stride == 8:
+            self.resnet.layer3.apply(partial(self._nostride_dilate, dilate=2))
+            self.resnet.layer4.apply(partial(self._nostride_dilate, dilate=4))
+
+    @staticmethod
+    def _nostride_dilate(m, dilate):                                            # resnet.py:192-207
+        if isinstance(m, nn.Conv2d):
+            if m.stride == (2, 2):
+                m.stride = (1, 1)
+                if m.kernel_size == (3, 3):
+                    m.dilation = (dilate // 2, dilate // 2)
+                    m.padding = (dilate // 2, dilate // 2)
+            elif m.kernel_size == (3, 3):
+                m.dilation = (dilate, dilate)
+                m.padding = (dilate, dilate)
+
+    def forward_nhwc(self, x):
+        r = self.resnet
+        params = [r.conv1.weight, r.bn1.weight, r.bn1.bias]
+        y = blocks.StemFn.apply(x, r, *params)
+        outs = []
+        for layer in (r.layer1, r.layer2, r.layer3, r.layer4):
+            for blk in layer:
+                y = blk(y)
+            outs.append(y)
+        return outs
+
+    def forward(self, inputs):                                                  # resnet.py:140-166
+        return [ops.as_nchw_view(t) for t in self.forward_nhwc(inputs)]

@@ -1,0 +1,58 @@
+"""One training iteration of the hot path, reproducing the caller's order and hyper-parameters:
+  ssl_step : reference tools/train_ssl_uem.py:193-232
+  src_step : reference tools/train_src.py:112-141
+Used by bench.py, __graft_entry__.smoke() and the parity tests; a reference-style script can equally call
+the same operator surface itself."""
+from .gast.balance import CrossEntropy, UVEMLoss, loss_calc_uvem
+from .utils.tools import loss_calc
+
+HYPER = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=32.0, cutoff_top=0.8, cutoff_low=0.6,
+             refine_mode="all", refine_temp=2.0, uvem_m=0.2, uvem_t=0.7, uvem_g=4.0, proto_decay=0.996,
+             ignore_label=-1)
+
+
+class StepState:
+    """loss objects the reference builds once before its loop (train_ssl_uem.py:129-137)."""
+
+    def __init__(self, class_num=6, hp=HYPER):
+        self.hp = hp
+        self.loss_fn_s = CrossEntropy(ignore_label=hp["ignore_label"])
+        self.loss_fn_t = UVEMLoss(m=hp["uvem_m"], threshold=hp["uvem_t"], gamma=hp["uvem_g"], class_num=class_num,
+                                  ignore_label=hp["ignore_label"])
+
+
+def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None):
+    hp = state.hp
+    model.train()
+    optimizer.param_groups[0]["lr"] = lr
+    pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # :205
+    pred_t1, pred_t2, feat_t = model(batch["images_t"])                         # :207
+    soft, hard = aligner.refine_and_select(batch["label_t_sup"], feat_t, [pred_t1, pred_t2], batch["label_t_soft"],
+                                           mode=hp["refine_mode"], temp=hp["refine_temp"], cutoff_top=hp["cutoff_top"],
+                                           cutoff_low=hp["cutoff_low"], sup_ignore_id=sup_ignore_id)   # :209-214
+    label_ds = aligner.update_prototype(feat_s, batch["label_s"])               # :216
+    loss_source = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :219
+    loss_target = loss_calc_uvem([pred_t1, pred_t2], hard, soft, loss_fn=state.loss_fn_t, multi=True)    # :221
+    loss = loss_source + loss_target
+    optimizer.zero_grad()
+    loss.backward()
+    prescale = dp.reduce_gradients() if dp is not None else 1.0
+    optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)             # :230-232 (clip 32 + SGD)
+    return dict(loss_source=loss_source.detach(), loss_target=loss_target.detach(), label_t_soft=soft,
+                label_t_hard=hard, label_s_ds=label_ds, pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
+                pred_t1=pred_t1.detach(), pred_t2=pred_t2.detach(), feat_s=feat_s.detach(), feat_t=feat_t.detach(),
+                grad_norm=optimizer.last_grad_norm)
+
+
+def src_step(model, optimizer, state, batch, lr, dp=None):
+    hp = state.hp
+    model.train()
+    optimizer.param_groups[0]["lr"] = lr
+    pred_s1, pred_s2, _feat = model(batch["images_s"])                          # train_src.py:116
+    loss = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :132
+    optimizer.zero_grad()
+    loss.backward()
+    prescale = dp.reduce_gradients() if dp is not None else 1.0
+    optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
+    return dict(loss_source=loss.detach(), pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
+                grad_norm=optimizer.last_grad_norm)
