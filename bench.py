@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Benchmark of the UemDA hot path on MI355X: one `train_ssl_uem.py`-style iteration per step
+(2 forwards, label_refine + pseudo_selection, prototype EMA, CE + UVEM, backward, clip + SGD) on synthetic
+512x512 tiles, ResNet50-ASPP, per-GPU batch 32 source + 32 target tiles (BASELINE.json configs[2] = configs[1]
+plus the mining the metric names).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = tiles (source + target) per second over all ranks, inputs resident in
+HBM when the timed region starts.  `roofline` is for the dominant kernel family (the f32-MFMA implicit-GEMM
+convolution), from HIP events around every one of its launches inside the timed region.  `cpu_baseline` is the
+oracle (CPU restatement of the reference, `kind: "port"`) timed on the host cores at BASELINE config 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+F32_MATRIX_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+GFLOP_PER_TILE = {("resnet50", "aspp", 512): (66.66, 198.8)}       # BASELINE.md section 3 (fwd, fwd+bwd)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle's SSL step at BASELINE config 1 (R50-ASPP, B=2, 256x256) on the host cores."""
+    from oracle import synth
+    from oracle.model import OracleDeeplabv2
+    from oracle.step import HYPER, SGDState, ssl_step
+    from oracle.weights import det_state_dict
+    threads = min(16, os.cpu_count() or 1)            # the one-GPU box's CPU share
+    torch.set_num_threads(threads)
+    sd = det_state_dict("resnet50", 6, False, seed=2333)
+    model = OracleDeeplabv2(sd, "resnet50", 6, False)
+    opt = SGDState(model.parameters(), 0.9, 5e-4)
+    batch = synth.make_batch(B=2, H=256, W=256, C=6, k=2048, seed=2333)
+    protos = batch["prototypes"]
+    out = ssl_step(model, opt, protos, batch, 1e-3, HYPER)           # warm-up
+    times = []
+    t_end = time.time() + seconds_budget
+    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
+        t0 = time.time()
+        out = ssl_step(model, opt, out["prototypes"], batch, 1e-3, HYPER)
+        times.append(time.time() - t0)
+    best = min(times)
+    return dict(value=round(4.0 / best, 3), unit="256x256 tiles/s (source+target)", cores=threads, kind="port",
+                sample=f"oracle ssl_step, R50-ASPP B=2+2 256x256 fp32, best of {len(times)} steps "
+                       f"({best:.3f} s/step), {os.cpu_count()} host CPUs visible")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU source batch (= target batch)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--workload", default="ssl", choices=["ssl", "src"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    from uemda_amd import dp as udp, ops
+    rank, world, local = udp.init("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    from oracle import synth                      # input generator only (seeded synthetic tiles)
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, src_step, ssl_step
+    from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
+
+    C, B, S = 6, args.batch, args.size
+    seed_torch(2333)
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True,
+               cascade=False, use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048,
+               num_classes=C, is_ins_norm=True)
+    model = Deeplabv2(cfg).cuda()                 # random init of the reference's architecture (no checkpoints)
+    wrapper = udp.DataParallel(model) if world > 1 else None
+    # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
+    pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + rank)
+    rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]
+    batch = {k: (v.cuda().repeat((rep,) + (1,) * (v.dim() - 1))[:B].contiguous() if k != "prototypes" else v.cuda())
+             for k, v in pool.items()}
+    aligner = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    aligner.prototypes = batch["prototypes"].clone()
+    opt = FusedSGD(model, lr=HYPER["lr"], momentum=HYPER["momentum"], weight_decay=HYPER["weight_decay"])
+    state = StepState(C)
+    sup_ignore = (S // 16) * (S // 16)            # explicit ignored superpixel id (DP-safe)
+    stop_steps = 6000
+
+    def lr_at(i):                                 # train_ssl_uem.py:82-84 + tools.py:191-207
+        pre = int(stop_steps / 20)
+        return lr_warmup(HYPER["lr"], i, pre) if i < pre else lr_poly(HYPER["lr"], i, stop_steps * 1.5, 0.9)
+
+    def one_step(i):
+        if args.workload == "ssl":
+            return ssl_step(model, aligner, opt, state, batch, lr_at(i + 1), dp=wrapper, sup_ignore_id=sup_ignore)
+        return src_step(model, opt, state, batch, lr_at(i + 1), dp=wrapper)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    ops.PROF.enabled = not args.no_kernel_events
+    ops.PROF.records = []
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROF.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tiles_per_step = (2 * B if args.workload == "ssl" else B) * world
+    value = tiles_per_step * args.steps / elapsed
+
+    if rank == 0:
+        roof = None
+        prof = ops.PROF.summary()
+        if prof:
+            fam, agg = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            ach = agg["flops"] / (agg["ms"] * 1e-3) / 1e12
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get(fam)
+            roof = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / F32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic,
+                        launches_per_step=agg["launches"] // args.steps,
+                        avg_launch_ms=round(agg["ms"] / agg["launches"], 4),
+                        algorithmic_gflop_per_launch=round(agg["flops"] / agg["launches"] / 1e9, 3),
+                        families={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                          ms_per_step=round(v["ms"] / args.steps, 2)) for k, v in prof.items()})
+        line = {
+            "metric": "512x512 tiles/sec (fwd+bwd+pseudo-label) ResNet50-ASPP bs=32",
+            "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_ssl_uem step ({args.workload}): ResNet50-ASPP 6-class, per-GPU {B} source + "
+                                   f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, fp32 (f32 MFMA), "
+                                   f"random init; tiles counted = source + target",
+                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}"},
+            "loss_source": round(float(out["loss_source"]), 5),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

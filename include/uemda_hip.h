@@ -69,6 +69,14 @@ int uem_stem_pack_weight(const float* w_ohwi /*[64][7][7][3]*/, float* w8, void*
 int uem_stem_unpack_grad(const float* dw8, float* dw_ohwi /* += */, void* stream);
 int uem_nchw3_to_nhwc4(const float* x, float* x4, int N, int H, int W, void* stream);
 int uem_bias_grad(const float* dy, float* db /* += */, int M, int C, int ld, void* stream);
+/* ASPP heads (Encoder.py:68-84) as one dense 1x1 GEMM G = feat x Wall plus a gather:
+ *   out[n,y,x,j] = sum_d ( bias[d][j] + sum_tap G[n, y+(ky-1)*dil_d, x+(kx-1)*dil_d, (d*9+tap)*K2 + j] )
+ * G is (N,h,w,R) with R >= nd*9*K2 (padded to the GEMM tile); K2 = heads*classes; dil is a HOST array.
+ * bwd fills dG (all R columns; the padding gets zeros) from dout (N,h,w,K2).                         */
+int uem_aspp_gather_fwd(const float* G, const float* bias /* [nd][K2] */, float* out, int N, int h, int w, int K2,
+                        int R, int nd, const int* dil, void* stream);
+int uem_aspp_gather_bwd(const float* dout, float* dG, int N, int h, int w, int K2, int R, int nd, const int* dil,
+                        void* stream);
 
 /* ---- BatchNorm2d (training + eval), fused ReLU / residual -- _resnets.py:96-110, Encoder.py:20,37 --
  * stats: per-channel batch mean / biased var of x[M][C]; also updates running stats
@@ -77,8 +85,8 @@ int uem_bias_grad(const float* dy, float* db /* += */, int M, int C, int ld, voi
 int uem_bn_stats(const float* x, int M, int C, int ld, const float* gamma, const float* beta,
                  float eps, float momentum, float* running_mean, float* running_var,
                  float* save_mean, float* save_invstd, float* scale, float* shift,
-                 float* workspace /* >= 3*C*UEM_BN_SPLIT floats */, void* stream);
-#define UEM_BN_SPLIT 64
+                 float* workspace /* >= uem_bn_workspace_floats(M, C) floats */, void* stream);
+int64_t uem_bn_workspace_floats(int M, int C); /* also covers uem_bn_bwd_reduce's workspace */
 int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
 /* y = act(x*scale + shift (+ r)); r = res, or res*res_scale + res_shift (downsample branch BN) when

@@ -8,6 +8,9 @@ import os
 import subprocess
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
+import torch  # noqa: F401  -- MUST precede dlopen: torch brings its own libamdhip64.so.7; loading ours first
+#                              would put a second HIP runtime in the process that cannot see torch's device state
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuemda_hip.so")
 _lib = None
@@ -37,7 +40,10 @@ SIGNATURES = {
     "uem_stem_unpack_grad": [P, P, P],
     "uem_nchw3_to_nhwc4": [P, P, I, I, I, P],
     "uem_bias_grad": [P, P, I, I, I, P],
+    "uem_aspp_gather_fwd": [P, P, P, I, I, I, I, I, I, POINTER(c_int), P],
+    "uem_aspp_gather_bwd": [P, P, I, I, I, I, I, I, POINTER(c_int), P],
     "uem_bn_stats": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P, P],
+    "uem_bn_workspace_floats": [I, I],
     "uem_bn_eval_affine": [P, P, P, P, F, P, P, I, P],
     "uem_affine_act": [P, P, P, P, P, P, P, L, I, I, P],
     "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P],
@@ -77,11 +83,10 @@ SIGNATURES = {
     "uem_grad_sqnorm": [P, L, P, P, P],
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
 }
-_RESTYPE = {"uem_last_error": c_char_p}
+_RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64}
 
 # compile-time constants mirrored from the header
 UEM_MAX_CLASSES = 16
-UEM_BN_SPLIT = 64
 UEM_PROTO_SPLIT = 256
 UEM_NORM_BLOCKS = 1024
 CONV_IN_AFFINE, CONV_IN_RELU, CONV_ACCUMULATE, CONV_TRANSPOSED = 1, 2, 4, 8

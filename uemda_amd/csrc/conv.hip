@@ -33,6 +33,11 @@ struct ConvP {
     int x_ld, y_ld;
     int accumulate;
     int relu;
+    // strided data-gradient only: one launch per output-parity class (py, px); rows enumerate the pixels
+    // (sub*yy + py, sub*xx + px) and only the taps that can reach that class are walked.
+    int sub, py, px, Hs, Ws;          // sub == 1: dense rows (every other use)
+    int ntaps;                        // number of taps walked
+    unsigned long long tapmask;       // 4 bits per walked tap: tap id = ky*KW + kx (3x3 at most)
 };
 
 // bijective XCD-aware remap (cdna guide T1): blocks sharing an XCD get consecutive tile ids
@@ -58,26 +63,28 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     // ---- per-thread gather geometry for its 4 A rows ------------------------------------------------
     int gy[4], gx[4], gpix[4];                          // gpix < 0 => row beyond M
     {
-        const int HoWo = p.Ho * p.Wo;
+        const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
+        const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + lrow + 32 * j;
             if (m < p.M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
-                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                if (MODE == 1) { gy[j] = oy + p.pad; gx[j] = ox + p.pad; }
+                const int oy = rem / Wrow, ox = rem - oy * Wrow;
+                if (MODE == 1) { gy[j] = oy * p.sub + p.py + p.pad; gx[j] = ox * p.sub + p.px + p.pad; }
                 else { gy[j] = oy * p.stride - p.pad; gx[j] = ox * p.stride - p.pad; }
                 gpix[j] = n * p.H * p.W;
             } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
         }
     }
     const int cpb = p.Cin / BK;                         // channel blocks per tap
-    const int KT = p.KH * p.KW * cpb;
-    const int Ktot = KT * BK;
+    const int KT = p.ntaps * cpb;
+    const int Ktot = p.KH * p.KW * p.Cin;               // row length of the filter bank
 
     float4 ra[4], rb[BROWS];
     auto load_tiles = [&](int kt) {
-        const int tap = kt / cpb, ci0 = (kt - tap * cpb) * BK;
+        const int t = kt / cpb, ci0 = (kt - t * cpb) * BK;
+        const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
         float4 sc, sh;
         if (AFFINE) {
@@ -91,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
             int iy, ix;
             if (MODE == 1) {
                 const int ty = gy[j] - ky * p.dil, tx = gx[j] - kx * p.dil;
-                iy = ty / p.stride; ix = tx / p.stride;
-                ok = ok && ty >= 0 && tx >= 0 && (iy * p.stride == ty) && (ix * p.stride == tx) && iy < p.H && ix < p.W;
+                if (p.stride == 1) { iy = ty; ix = tx; }
+                else { iy = ty / p.stride; ix = tx / p.stride; ok = ok && (iy * p.stride == ty) && (ix * p.stride == tx); }
+                ok = ok && ty >= 0 && tx >= 0 && iy < p.H && ix < p.W;
             } else if (MODE == 2) {
                 iy = gy[j] + ky;                        // stem: tap = ky, 8 pixels along x in the row
                 ix = gx[j] + (lc4 >> 2);
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
             const int n = n0 + lrow + 32 * j;
-            rb[j] = (n < p.Cout) ? *reinterpret_cast<const float4*>(p.w + (size_t)n * Ktot + (size_t)kt * BK + lc4)
+            rb[j] = (n < p.Cout) ? *reinterpret_cast<const float4*>(p.w + (size_t)n * Ktot + (size_t)tap * p.Cin + ci0 + lc4)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -137,8 +145,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
 
-    load_tiles(0);
-    store_tiles();
+    if (KT > 0) {
+        load_tiles(0);
+        store_tiles();
+    }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) load_tiles(kt + 1);            // in flight during the MFMA phase
@@ -178,7 +188,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m < p.M) {
-                    float* dst = p.y + (size_t)m * p.y_ld + n;
+                    size_t opix = (size_t)m;
+                    if (MODE == 1 && p.sub > 1) {
+                        const int hw = p.Hs * p.Ws;
+                        const int ni = m / hw, rem = m - ni * hw;
+                        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
+                        opix = ((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px);
+                    }
+                    float* dst = p.y + opix * p.y_ld + n;
                     float v = acc[i][j][r] + bv;
                     if (p.accumulate) v += *dst;
                     *dst = v;
@@ -229,6 +246,7 @@ extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0;
     p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0;
     if (!transposed) {
         UEM_REQUIRE(s->Cin % BK == 0, "conv2d_fwd: Cin=%d must be a multiple of 32", s->Cin);
         p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
@@ -236,13 +254,37 @@ extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias,
         p.M = s->N * s->Ho * s->Wo;
         return conv_launch<0>(p, affine, (hipStream_t)stream);
     }
-    // data gradient: rows = input pixels (N,H,W), reduction over (tap, Cout), gather from dY (N,Ho,Wo,Cout)
+    // data gradient: rows = input pixels (N,H,W), reduction over (tap, Cout), gather from dY (N,Ho,Wo,Cout).
+    // dX[y,x] += dY[(y+pad-ky*d)/s, (x+pad-kx*d)/s] * W[ky,kx] only where the division is exact, so the
+    // pixels split into s*s parity classes, each reached by its own subset of taps: one launch per class
+    // walks exactly those taps (a 3x3 stride-2 conv: 1 + 2 + 2 + 4 taps instead of 4 x 9).
     UEM_REQUIRE(s->Cout % BK == 0, "conv2d dgrad: Cout=%d must be a multiple of 32", s->Cout);
+    UEM_REQUIRE(s->KH * s->KW <= 16, "conv2d dgrad: at most 16 taps (4-bit tap ids in a 64-bit list)");
     p.N = s->N; p.H = s->Ho; p.W = s->Wo; p.Cin = s->Cout;       // what the gather reads
     p.Ho = s->H; p.Wo = s->W; p.Cout = s->Cin;                   // what the kernel writes
     p.x_ld = s->y_ld; p.y_ld = s->x_ld;
-    p.M = s->N * s->H * s->W;
-    return conv_launch<1>(p, false, (hipStream_t)stream);
+    p.sub = s->stride;
+    for (int py = 0; py < s->stride; ++py) {
+        for (int px = 0; px < s->stride; ++px) {
+            p.py = py; p.px = px;
+            p.Hs = (s->H - py + s->stride - 1) / s->stride;
+            p.Ws = (s->W - px + s->stride - 1) / s->stride;
+            if (p.Hs <= 0 || p.Ws <= 0) continue;
+            p.ntaps = 0; p.tapmask = 0;
+            for (int ky = 0; ky < s->KH; ++ky) {
+                if ((py + s->pad - ky * s->dil) % s->stride != 0) continue;      // C % keeps the sign: 0 is still exact
+                for (int kx = 0; kx < s->KW; ++kx) {
+                    if ((px + s->pad - kx * s->dil) % s->stride != 0) continue;
+                    p.tapmask |= (unsigned long long)(ky * s->KW + kx) << (4 * p.ntaps);
+                    ++p.ntaps;
+                }
+            }
+            p.M = s->N * p.Hs * p.Ws;
+            rc = conv_launch<1>(p, false, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    }
+    return UEM_OK;
 }
 
 extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream) {
@@ -253,6 +295,7 @@ extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, i
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
     p.accumulate = 0; p.relu = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0;
     p.M = N * p.Ho * p.Wo;
     return conv_launch<2>(p, false, (hipStream_t)stream);
 }
@@ -510,4 +553,91 @@ extern "C" int uem_bias_grad(const float* dy, float* db, int M, int C, int ld, v
     UEM_REQUIRE(dy && db && M > 0 && C > 0 && ld >= C, "bias_grad: bad arguments");
     bias_grad_kernel<<<C, 256, 0, (hipStream_t)stream>>>(dy, db, M, C, ld);
     return uem_check_launch("bias_grad");
+}
+
+// =========================================================================================================
+// ASPP heads as ONE dense GEMM + a gather (Encoder.py:68-84).
+//   sum_d conv3x3_dil_d(feat; W_d)[p] = sum_d sum_tap (feat . W_d,tap)[p + off_d,tap]
+// so G = feat x Wall (a 1x1 conv with R = n_dil*9*K2 output columns, K2 = heads*classes) is computed once
+// by the MFMA kernel (feat read ONCE instead of 36 times, no 12->32 column padding), and the dilated
+// 3x3 structure becomes a 36-term gather of K2-float rows of G.  Backward: dG is the transposed gather
+// of dOut, then dfeat / dWall are plain 1x1 dgrad / wgrad GEMMs.
+// G column r = (d*9 + ky*3 + kx)*K2 + j,  j = head*C + class.
+// =========================================================================================================
+struct AsppP {
+    int N, h, w, K2, R, nd;
+    int dil[8];
+};
+__global__ __launch_bounds__(256) void aspp_gather_fwd_kernel(const float* __restrict__ G, const float* __restrict__ bias,
+                                                              float* __restrict__ out, const AsppP p) {
+    // one thread per (pixel, j); out is (N,h,w,K2)
+    const int64_t total = (int64_t)p.N * p.h * p.w * p.K2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i % p.K2);
+        int64_t t = i / p.K2;
+        const int x = (int)(t % p.w); t /= p.w;
+        const int y = (int)(t % p.h);
+        const int n = (int)(t / p.h);
+        float acc = 0.f;
+        for (int d = 0; d < p.nd; ++d) {
+            acc += bias[d * p.K2 + j];
+            const int dl = p.dil[d];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = y + (ky - 1) * dl;
+                if (yy < 0 || yy >= p.h) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = x + (kx - 1) * dl;
+                    if (xx < 0 || xx >= p.w) continue;
+                    acc += G[(((size_t)n * p.h + yy) * p.w + xx) * p.R + (size_t)((d * 9 + ky * 3 + kx) * p.K2 + j)];
+                }
+            }
+        }
+        out[i] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void aspp_gather_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dG, const AsppP p) {
+    // one thread per (pixel q, column r): dG[q][r] = dOut[q - off][j] when that pixel exists (its tap lands on q)
+    const int64_t total = (int64_t)p.N * p.h * p.w * p.R;
+    const int used = p.nd * 9 * p.K2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i % p.R);
+        float v = 0.f;
+        if (r < used) {
+            int64_t t = i / p.R;
+            const int x = (int)(t % p.w); t /= p.w;
+            const int y = (int)(t % p.h);
+            const int n = (int)(t / p.h);
+            const int j = r % p.K2, tap = (r / p.K2) % 9, d = r / (9 * p.K2);
+            const int yo = y - (tap / 3 - 1) * p.dil[d], xo = x - (tap % 3 - 1) * p.dil[d];
+            if (yo >= 0 && yo < p.h && xo >= 0 && xo < p.w) v = dout[(((size_t)n * p.h + yo) * p.w + xo) * p.K2 + j];
+        }
+        dG[i] = v;
+    }
+}
+static int aspp_params(AsppP* p, int N, int h, int w, int K2, int R, int nd, const int* dil) {
+    if (N <= 0 || h <= 0 || w <= 0 || K2 <= 0 || nd <= 0 || nd > 8 || !dil || R < nd * 9 * K2)
+        return uem_fail(UEM_ERR_INVALID, "aspp_gather: bad shape (R=%d must be >= nd*9*K2=%d)", R, nd * 9 * K2);
+    p->N = N; p->h = h; p->w = w; p->K2 = K2; p->R = R; p->nd = nd;
+    for (int i = 0; i < 8; ++i) p->dil[i] = i < nd ? dil[i] : 0;
+    return UEM_OK;
+}
+extern "C" int uem_aspp_gather_fwd(const float* G, const float* bias, float* out, int N, int h, int w, int K2, int R,
+                                   int nd, const int* dil, void* stream) {
+    UEM_REQUIRE(G && bias && out, "aspp_gather_fwd: null pointer");
+    AsppP p;
+    int rc = aspp_params(&p, N, h, w, K2, R, nd, dil);
+    if (rc) return rc;
+    aspp_gather_fwd_kernel<<<uem_stream_grid((int64_t)N * h * w * K2, 256), 256, 0, (hipStream_t)stream>>>(G, bias, out, p);
+    return uem_check_launch("aspp_gather_fwd");
+}
+extern "C" int uem_aspp_gather_bwd(const float* dout, float* dG, int N, int h, int w, int K2, int R, int nd, const int* dil,
+                                   void* stream) {
+    UEM_REQUIRE(dout && dG, "aspp_gather_bwd: null pointer");
+    AsppP p;
+    int rc = aspp_params(&p, N, h, w, K2, R, nd, dil);
+    if (rc) return rc;
+    aspp_gather_bwd_kernel<<<uem_stream_grid((int64_t)N * h * w * R, 256), 256, 0, (hipStream_t)stream>>>(dout, dG, p);
+    return uem_check_launch("aspp_gather_bwd");
 }

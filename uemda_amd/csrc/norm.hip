@@ -89,19 +89,50 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         }
     }
 }
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ ws, int chunks, int M, int C, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
-                                         float* __restrict__ rvar, float* __restrict__ smean, float* __restrict__ sinv,
-                                         float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// chunking shared by the column reductions: enough (segment x chunk) blocks to fill 256 CUs several times
+static inline void col_chunks(int M, int C, int* chunks, int* rows_per_chunk) {
+    const int segs = (int)uem_cdiv(C, 256);
+    int ch = (int)uem_cdiv(2048, segs);
+    int rpc = (int)uem_cdiv(M, ch);
+    if (rpc < 64) rpc = 64;
+    *rows_per_chunk = rpc;
+    *chunks = (int)uem_cdiv(M, rpc);
+}
+extern "C" int64_t uem_bn_workspace_floats(int M, int C) {
+    int chunks, rpc;
+    col_chunks(M, C, &chunks, &rpc);
+    return (int64_t)3 * C * chunks;
+}
+
+// one wave per channel: lanes merge chunks lane, lane+64, ... then a shuffle tree (fixed order => deterministic)
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __restrict__ ws, int chunks, int M, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float momentum, float* __restrict__ rmean,
+                                                               float* __restrict__ rvar, float* __restrict__ smean,
+                                                               float* __restrict__ sinv, float* __restrict__ scale,
+                                                               float* __restrict__ shift) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int j = 0; j < chunks; ++j) {
+    for (int j = lane; j < chunks; j += 64) {
         const float* w = ws + (size_t)j * 3 * C;
         const float nb = w[c];
         if (n == 0.f) { n = nb; mean = w[C + c]; m2 = w[2 * C + c]; }
         else chan_merge(n, mean, m2, nb, w[C + c], w[2 * C + c]);
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+        // symmetric merge so that both partners end with the same value
+        const float nt = n + nb;
+        if (nt > 0.f) {
+            const float delta = mb - mean;
+            const float mnew = (n * mean + nb * mb) / nt;
+            m2 = m2 + qb + delta * delta * (n * nb / nt);
+            mean = mnew;
+        }
+        n = nt;
+    }
+    if (lane != 0) return;
     const float var = m2 / (float)M;                       // biased (normalisation)
     const float invstd = 1.0f / sqrtf(var + eps);
     if (smean) smean[c] = mean;
@@ -123,14 +154,12 @@ extern "C" int uem_bn_stats(const float* x, int M, int C, int ld, const float* g
     UEM_REQUIRE(M > 0 && col_shape_ok(C) && ld >= C && (ld % 4) == 0, "bn_stats: unsupported shape M=%d C=%d ld=%d", M, C, ld);
     UEM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats must come in pairs");
     hipStream_t st = (hipStream_t)stream;
-    int chunks = UEM_BN_SPLIT;
-    int rpc = (int)uem_cdiv(M, chunks);
-    if (rpc < 16) { rpc = 16; }
-    chunks = (int)uem_cdiv(M, rpc);
+    int chunks, rpc;
+    col_chunks(M, C, &chunks, &rpc);
     dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
     bn_stats_partial_kernel<<<grid, 256, 0, st>>>(x, M, C, ld, rpc, workspace);
-    bn_stats_finalize_kernel<<<(int)uem_cdiv(C, 64), 64, 0, st>>>(workspace, chunks, M, C, gamma, beta, eps, momentum,
-                                                                  running_mean, running_var, save_mean, save_invstd, scale, shift);
+    bn_stats_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, M, C, gamma, beta, eps, momentum, running_mean, running_var,
+                                               save_mean, save_invstd, scale, shift);
     return uem_check_launch("bn_stats");
 }
 
@@ -237,14 +266,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         for (int j = 0; j < 4; ++j) { w[cm.c0 + j] = a[j]; w[C + cm.c0 + j] = a[4 + j]; }
     }
 }
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     float b = 0.f, g = 0.f;
-    for (int j = 0; j < chunks; ++j) { b += ws[(size_t)j * 2 * C + c]; g += ws[(size_t)j * 2 * C + C + c]; }
-    dbeta[c] = b;
-    dgamma[c] = g;
+    for (int j = lane; j < chunks; j += 64) { b += ws[(size_t)j * 2 * C + c]; g += ws[(size_t)j * 2 * C + C + c]; }
+    b = wave_sum(b);
+    g = wave_sum(g);
+    if (lane == 0) { dbeta[c] = b; dgamma[c] = g; }
 }
 extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                                  const float* save_mean, const float* save_invstd, int M, int C, int relu, float* dgamma,
@@ -252,12 +281,11 @@ extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* y
     UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce: null pointer");
     UEM_REQUIRE(M > 0 && col_shape_ok(C), "bn_bwd_reduce: unsupported shape M=%d C=%d", M, C);
     hipStream_t st = (hipStream_t)stream;
-    int rpc = (int)uem_cdiv(M, UEM_BN_SPLIT);
-    if (rpc < 16) rpc = 16;
-    const int chunks = (int)uem_cdiv(M, rpc);
+    int chunks, rpc;
+    col_chunks(M, C, &chunks, &rpc);
     dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
     bn_bwd_partial_kernel<<<grid, 256, 0, st>>>(x, dy, ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
-    bn_bwd_finalize_kernel<<<(int)uem_cdiv(C, 64), 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta);
+    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta);
     return uem_check_launch("bn_bwd_reduce");
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,

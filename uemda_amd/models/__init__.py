@@ -1,1 +1,1 @@
-from .Encoder import Classifier_Module, Deeplabv2, PPMBilinear  # noqa: F401
+"""Mirror of the reference package `uemda.models` (import `uemda_amd.models.Encoder`)."""

@@ -171,55 +171,69 @@ class InstNormFn(Function):
         return ops.instnorm_bwd(y, dy.contiguous(), invstd), None
 
 
+def _aspp_pack(head5, head6, feat):
+    """Wall (R, 1, 1, cin): row (d*9 + tap)*2C + head*C + c = W_head,d[c, tap, :]; bias (nd, 2C)."""
+    C = head5.conv2d_list[0].weight.shape[0]
+    cin = feat.shape[3]
+    nd = len(head5.dilations)
+    used = nd * 9 * 2 * C
+    R = (used + 63) // 64 * 64                       # GEMM N tile (64) and dgrad K block (32)
+    wall = torch.zeros((R, cin), device=feat.device, dtype=torch.float32)
+    wv = wall[:used].view(nd, 9, 2, C, cin)
+    bias = torch.empty((nd, 2, C), device=feat.device, dtype=torch.float32)
+    for i in range(nd):
+        for hd, head in enumerate((head5, head6)):
+            conv = head.conv2d_list[i]
+            wv[i, :, hd].copy_(ops.weight_ohwi(conv.weight).reshape(C, 9, cin).permute(1, 0, 2))
+            bias[i, hd].copy_(conv.bias.detach())
+    return wall.view(R, 1, 1, cin), bias, C, nd, R, used
+
+
 class ASPPHeadsFn(Function):
-    """Both Classifier_Module heads (Encoder.py:68-84) in one pass over `feat`: per dilation the two
-    heads' filters are stacked into one 32-row (zero padded) filter bank, the four dilated convs
-    accumulate into one (N,h,w,32) buffer (the reference's `out += conv_i(x)`)."""
+    """Both Classifier_Module heads (Encoder.py:68-84): the 2 heads x 4 dilations x 9 taps are the columns of
+    ONE 1x1 GEMM G = feat x Wall on the MFMA kernel (feat is read once), then a 36-term gather rebuilds the
+    dilated 3x3 sums; see uem_aspp_gather_* in include/uemda_hip.h."""
 
     @staticmethod
     def forward(ctx, feat, head5, head6, *params):
-        C = head5.conv2d_list[0].weight.shape[0]
-        cin = feat.shape[3]
-        if 2 * C > 32:
-            raise UemError("ASPP heads: more than 16 classes are not supported by the packed head")
-        dils = head5.dilations
-        wp = torch.zeros((len(dils), 32, 3, 3, cin), device=feat.device, dtype=torch.float32)
-        bp = torch.zeros((len(dils), 32), device=feat.device, dtype=torch.float32)
-        for i in range(len(dils)):
-            wp[i, 0:C].copy_(ops.weight_ohwi(head5.conv2d_list[i].weight))
-            wp[i, C:2 * C].copy_(ops.weight_ohwi(head6.conv2d_list[i].weight))
-            bp[i, 0:C].copy_(head5.conv2d_list[i].bias.detach())
-            bp[i, C:2 * C].copy_(head6.conv2d_list[i].bias.detach())
-        out = None
-        for i, d in enumerate(dils):
-            out = ops.conv2d(feat, wp[i], bp[i], pad=d, dil=d, out=out, accumulate=(i > 0))
+        import ctypes
+        wall, bias, C, nd, R, used = _aspp_pack(head5, head6, feat)
+        n, h, w, cin = feat.shape
+        dil = (ctypes.c_int * nd)(*head5.dilations)
+        G = ops.conv2d(feat, wall, algo_cout=used)
+        out = torch.empty((n, h, w, 2 * C), device=feat.device, dtype=torch.float32)
+        ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(out), n, h, w, 2 * C, R, nd, dil, ops.stream())
         x1 = out[..., 0:C].contiguous()
         x2 = out[..., C:2 * C].contiguous()
         if any(ctx.needs_input_grad):
             ctx.heads = (head5, head6)
-            ctx.save_for_backward(feat, wp)
+            ctx.save_for_backward(feat, wall)
         return x1, x2
 
     @staticmethod
     def backward(ctx, d1, d2):
-        feat, wp = ctx.saved_tensors
+        import ctypes
+        feat, wall = ctx.saved_tensors
         head5, head6 = ctx.heads
         C = head5.conv2d_list[0].weight.shape[0]
-        dils = head5.dilations
+        nd = len(head5.dilations)
         n, h, w, cin = feat.shape
-        d32 = torch.zeros((n, h, w, 32), device=feat.device, dtype=torch.float32)
-        d32[..., 0:C].copy_(d1)
-        d32[..., C:2 * C].copy_(d2)
-        db = torch.zeros(32, device=feat.device, dtype=torch.float32)
-        ops.bias_grad(d32, db, 32, 32)
-        dfeat = None
-        for i, d in enumerate(dils):
-            dwp = torch.zeros((32, 3, 3, cin), device=feat.device, dtype=torch.float32)
-            ops.conv2d_wgrad(feat, d32, dwp, pad=d, dil=d)
-            for head, lo in ((head5, 0), (head6, C)):
+        R = wall.shape[0]
+        used = nd * 9 * 2 * C
+        dout = torch.cat([d1, d2], dim=3).contiguous()
+        db = torch.zeros(2 * C, device=feat.device, dtype=torch.float32)
+        ops.bias_grad(dout, db, 2 * C, 2 * C)
+        dG = torch.empty((n, h, w, R), device=feat.device, dtype=torch.float32)
+        dil = (ctypes.c_int * nd)(*head5.dilations)
+        ops.call("uem_aspp_gather_bwd", ops.ptr(dout), ops.ptr(dG), n, h, w, 2 * C, R, nd, dil, ops.stream())
+        dwall = torch.zeros((R, 1, 1, cin), device=feat.device, dtype=torch.float32)
+        ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
+        dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
+        dwv = dwall.view(R, cin)[:used].view(nd, 9, 2, C, cin)
+        for i in range(nd):
+            for hd, head in enumerate((head5, head6)):
                 conv = head.conv2d_list[i]
-                ops.add_(grad_ohwi(conv.weight), dwp[lo:lo + C])
-                ops.add_(grad_buffer(conv.bias), db[lo:lo + C])
-            dfeat = ops.conv2d_dgrad(d32, ops.weight_transpose(wp[i]), feat.shape, pad=d, dil=d, out=dfeat,
-                                     accumulate=(i > 0))
+                g = grad_ohwi(conv.weight)                                  # (C, 3, 3, cin) contiguous
+                ops.add_(g, dwv[i, :, hd].permute(1, 0, 2).contiguous())     # (9, C, cin) -> (C, 9, cin)
+                ops.add_(grad_buffer(conv.bias), db[hd * C:(hd + 1) * C])
         return (dfeat, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

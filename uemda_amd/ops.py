@@ -18,6 +18,38 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _Profiler:
+    """Optional per-launch HIP-event timing of the conv kernels (bench.py's `roofline` leg).  Events are
+    recorded on torch's current stream, which is the stream every kernel here is launched on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (family, algorithmic flops, start event, end event)
+
+    def run(self, family, flops, launch):
+        if not self.enabled:
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = launch()
+        e.record()
+        self.records.append((family, flops, s, e))
+        return out
+
+    def summary(self):
+        """family -> dict(launches, flops, ms); call after torch.cuda.synchronize()."""
+        agg = {}
+        for fam, fl, s, e in self.records:
+            a = agg.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
+            a["launches"] += 1
+            a["flops"] += fl
+            a["ms"] += s.elapsed_time(e)
+        return agg
+
+
+PROF = _Profiler()
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -62,7 +94,7 @@ def _shape(x, cout, kh, kw, stride, pad, dil, x_ld=None, y_ld=None):
 # convolution
 # ------------------------------------------------------------------------------------------------
 def conv2d(x, w_ohwi, bias=None, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
-           out=None, accumulate=False):
+           out=None, accumulate=False, algo_cout=None):
     """y = conv(prologue(x), w) + bias.  x (N,H,W,Cin); w (Cout,KH,KW,Cin); returns (N,Ho,Wo,Cout)."""
     need_gpu(x, w_ohwi)
     _f32c(x, "conv2d x"), _f32c(w_ohwi, "conv2d w")
@@ -74,12 +106,13 @@ def conv2d(x, w_ohwi, bias=None, stride=1, pad=0, dil=1, in_scale=None, in_shift
         out = torch.empty((s.N, s.Ho, s.Wo, cout), device=x.device, dtype=torch.float32)
     flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0) | \
             (CONV_ACCUMULATE if accumulate else 0)
-    call("uem_conv2d_fwd", ptr(x), ptr(w_ohwi), ptr(bias), ptr(in_scale), ptr(in_shift), ptr(out),
-         ctypes.byref(s), flags, stream())
+    flops = 2.0 * s.N * s.Ho * s.Wo * (algo_cout or cout) * kh * kw * cin
+    PROF.run("conv_fwd", flops, lambda: call("uem_conv2d_fwd", ptr(x), ptr(w_ohwi), ptr(bias), ptr(in_scale),
+                                             ptr(in_shift), ptr(out), ctypes.byref(s), flags, stream()))
     return out
 
 
-def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False):
+def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, algo_cout=None):
     """dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout); w_t = weight_transpose(w) of shape (Cin,KH,KW,Cout)."""
     need_gpu(dy, w_t)
     _f32c(dy, "dgrad dy"), _f32c(w_t, "dgrad w_t")
@@ -93,11 +126,14 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     if out is None:
         out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
     flags = CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0)
-    call("uem_conv2d_fwd", ptr(dy), ptr(w_t), None, None, None, ptr(out), ctypes.byref(s), flags, stream())
+    flops = 2.0 * n * dy.shape[1] * dy.shape[2] * (algo_cout or cout) * kh * kw * cin
+    PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_fwd", ptr(dy), ptr(w_t), None, None, None, ptr(out),
+                                               ctypes.byref(s), flags, stream()))
     return out
 
 
-def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False):
+def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
+                 algo_cout=None):
     """dw (Cout,KH,KW,Cin) += dy^T * im2col(prologue(x)).  dw must be contiguous (atomics land in it)."""
     need_gpu(x, dy, dw_ohwi)
     _f32c(x, "wgrad x"), _f32c(dy, "wgrad dy"), _f32c(dw_ohwi, "wgrad dw")
@@ -106,8 +142,9 @@ def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift
     if (s.Ho, s.Wo) != (dy.shape[1], dy.shape[2]):
         raise UemError("conv2d_wgrad: dy spatial size mismatch")
     flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0)
-    call("uem_conv2d_wgrad", ptr(x), ptr(dy), ptr(in_scale), ptr(in_shift), ptr(dw_ohwi), ctypes.byref(s),
-         flags, stream())
+    flops = 2.0 * s.N * s.Ho * s.Wo * (algo_cout or cout) * kh * kw * cin
+    PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad", ptr(x), ptr(dy), ptr(in_scale), ptr(in_shift),
+                                               ptr(dw_ohwi), ctypes.byref(s), flags, stream()))
 
 
 def weight_transpose(w_ohwi):
@@ -134,14 +171,16 @@ def stem_conv(x4, w_ohwi):
     call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
     y = torch.empty((n, conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1), 64), device=x4.device,
                     dtype=torch.float32)
-    call("uem_conv2d_stem_fwd", ptr(x4), ptr(w8), ptr(y), n, h, w, stream())
+    flops = 2.0 * y.numel() * 147
+    PROF.run("conv_fwd", flops, lambda: call("uem_conv2d_stem_fwd", ptr(x4), ptr(w8), ptr(y), n, h, w, stream()))
     return y
 
 
 def stem_wgrad(x4, dy, dw_ohwi):
     n, h, w, _ = x4.shape
     dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
-    call("uem_conv2d_stem_wgrad", ptr(x4), ptr(dy), ptr(dw8), n, h, w, stream())
+    PROF.run("conv_wgrad", 2.0 * dy.numel() * 147,
+             lambda: call("uem_conv2d_stem_wgrad", ptr(x4), ptr(dy), ptr(dw8), n, h, w, stream()))
     call("uem_stem_unpack_grad", ptr(dw8), ptr(dw_ohwi), stream())
 
 
@@ -168,7 +207,7 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=BN_EPS, mo
     buf = torch.empty((4, C), device=dev, dtype=torch.float32)
     st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
     if training:
-        ws = torch.empty(3 * C * _lib.UEM_BN_SPLIT, device=dev, dtype=torch.float32)
+        ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, C), device=dev, dtype=torch.float32)
         call("uem_bn_stats", ptr(x), M, C, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
              ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws), stream())
     else:
@@ -193,7 +232,7 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None
     dx = torch.empty_like(x) if dx is None else dx
     if st.training:
         tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
-        ws = torch.empty(2 * C * _lib.UEM_BN_SPLIT, device=x.device, dtype=torch.float32)
+        ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
         call("uem_bn_bwd_reduce", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
              ptr(st.invstd), M, C, 1 if relu else 0, ptr(tmp[0]), ptr(tmp[1]), ptr(ws), stream())
         call("uem_bn_bwd_apply", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
