@@ -63,15 +63,19 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU source batch (= target batch)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", default="ssl", choices=["ssl", "src"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="force the CUDA device index (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
     from uemda_amd import dp as udp, ops
-    rank, world, local = udp.init("nccl")
+    if args.device is not None:
+        torch.cuda.set_device(args.device)
+    rank, world, local = udp.init(args.backend, device=args.device)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if args.device is None else args.device)
     from oracle import synth                      # input generator only (seeded synthetic tiles)
     from uemda_amd.gast.alignment import Aligner
     from uemda_amd.models.Encoder import Deeplabv2

@@ -44,11 +44,14 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--scale", type=int, default=1, help="divide spatial size (1 = 512^2 input)")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     B = args.batch
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'shape':24s} {'M':>8s} | {'fwd ms':>8s} {'TF/s':>6s} {'GB/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     for name, cin, cout, k, s, d, hin, cnt in SHAPES:
+        if args.only and args.only not in name:
+            continue
         h = hin // args.scale
         pad = d * (k - 1) // 2
         x = torch.randn(B, h, h, cin, device="cuda")

@@ -305,6 +305,67 @@ def test_full_model_aspp_ssl_step_matches_reference_golden():
     assert (upd - upd_ref).norm() / upd_ref.norm() < 6e-2
 
 
+def test_layer_ppm_golden():
+    from uemda_amd.models import ppm
+    from uemda_amd.models.Encoder import PPMBilinear
+    from oracle.weights import subsample
+    g = load_golden("layer_ppm")
+    head = _load_into(PPMBilinear(num_classes=C, fc_dim=32), "layer_ppm")
+    head.conv_last[3].p = 0.0                      # Dropout2d off for parity (stochastic in train mode)
+    holder = _Holder(head).cuda().flatten()
+    head.train()
+    x = nhwc(g["x"]).requires_grad_(True)
+    y = ppm.ppm_head(x, head)
+    torch.testing.assert_close(nchw(y.detach()), g["y"], rtol=1e-3, atol=2e-4)
+    y.backward(nhwc(g["gy"]))
+    torch.testing.assert_close(nchw(x.grad), g["gx"], rtol=5e-3, atol=2e-3)
+    named = dict(head.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g:"):
+            got = subsample(named[k[2:]].grad.cpu().contiguous())
+            assert (got - v).norm() / (v.norm() + 1e-12) < 5e-3, k
+    sd = head.state_dict()
+    for k, v in g.items():
+        if k.startswith("post:"):
+            torch.testing.assert_close(sd[k[5:]].cpu(), v, rtol=1e-4, atol=1e-5)
+    # dropout on: a fraction ~p of (n, channel) planes is zeroed and the rest scaled by 1/(1-p)
+    head.conv_last[3].p = 0.5
+    y2 = ppm.ppm_head(nhwc(g["x"]), head)
+    assert torch.isfinite(y2).all() and not torch.allclose(y2, y.detach())
+
+
+def test_full_model_ppm_ssl_step_matches_reference_golden():
+    """the configuration every UemDA script instantiates (use_ppm=True, train_ssl_uem.py:91-108)"""
+    from oracle import synth
+    from oracle.weights import checksum
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    g = load_golden("model_ppm_r50_b2_256")
+    model = _model(True)
+    model.layer5.conv_last[3].p = 0.0
+    model.layer6.conv_last[3].p = 0.0
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
+    model.eval()
+    with torch.no_grad():
+        prob = model(batch["images_t"])
+    torch.testing.assert_close(prob[:, :, ::8, ::8].cpu(), g["eval_prob_sample"], rtol=1e-3, atol=1e-5)
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    al.prototypes = batch["prototypes"].clone()
+    opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    out = ssl_step(model, al, opt, StepState(C), batch, float(g["lr"]))
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        err = (out[k].cpu() - g[k]).abs().max() / g[k].abs().max()
+        assert err < 1e-3, (k, float(err))
+    agree = (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item()
+    assert agree >= 0.9995, agree
+    torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=1e-2, atol=1e-4)
+    s, a = checksum([p.cpu().contiguous() for p in model.parameters()])
+    assert a == pytest.approx(float(g["post_checksum"][1]), rel=1e-5)
+
+
 def test_cpu_tensors_fail_loudly():
     from uemda_amd import UemError
     from uemda_amd.gast.pseudo_generation import pseudo_selection

@@ -12,6 +12,7 @@
 // floats (k contiguous, 16-B pad) read with ds_read_b128 (conflict-free).
 // Replaces cuDNN behind nn.Conv2d: reference _resnets.py:95-110,149,209; Encoder.py:19,35-36,40,74-75.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -82,15 +83,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     const int Ktot = p.KH * p.KW * p.Cin;               // row length of the filter bank
 
     float4 ra[4], rb[BROWS];
+    float4 psc, psh;                                    // prologue operands of the tile in flight
+    unsigned okmask = 0;                                // bit j: row j of the tile in flight is in bounds
+    int lt = 0, lci0 = 0;                               // loader position: tap slot, first channel
     auto load_tiles = [&](int kt) {
-        const int t = kt / cpb, ci0 = (kt - t * cpb) * BK;
+        (void)kt;                                       // (lt, lci0) walk the k-steps in order: no division here
+        const int t = lt, ci0 = lci0;
+        lci0 += BK;
+        if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        float4 sc, sh;
+        const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);   // tap/3 for tap < 16
+        const int kx = tap - ky * p.KW;
         if (AFFINE) {
-            sc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + lc4);
-            sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + lc4);
+            psc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + lc4);
+            psh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + lc4);
         }
+        okmask = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -113,10 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
                 const size_t pix = (size_t)gpix[j] + (size_t)iy * p.W + ix;
                 if (MODE == 2) v = *reinterpret_cast<const float4*>(p.x + pix * 4);
                 else v = *reinterpret_cast<const float4*>(p.x + pix * p.x_ld + ci0 + lc4);
-                if (AFFINE) {
-                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
+                okmask |= 1u << j;
             }
             ra[j] = v;
         }
@@ -127,9 +132,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // the BatchNorm-affine + ReLU prologue is applied here, AFTER the MFMA phase the loads overlapped with
+    // (touching the loaded registers earlier would force the s_waitcnt vmcnt in front of the MFMAs);
+    // zero padding stays zero: rows that were out of bounds are not transformed.
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[(lrow + 32 * j) * LDS_LD + lc4]) = ra[j];
+        for (int j = 0; j < 4; ++j) {
+            float4 v = ra[j];
+            if (AFFINE && ((okmask >> j) & 1u)) {
+                v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y; v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(&As[(lrow + 32 * j) * LDS_LD + lc4]) = v;
+        }
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * j) * LDS_LD + lc4]) = rb[j];
     };
@@ -159,15 +174,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
             for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+            // k outer, accumulators inner: consecutive MFMAs never depend on each other
+#define MFMA_STEP(C)                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].C, b[j].C, acc[i][j], 0, 0, 0);
+            MFMA_STEP(x) MFMA_STEP(y) MFMA_STEP(z) MFMA_STEP(w)
+#undef MFMA_STEP
         }
         __syncthreads();
         if (kt + 1 < KT) {
@@ -177,6 +190,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------
+    const bool dense_rows = !(MODE == 1 && p.sub > 1);
+    if (dense_rows && !p.accumulate && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        // full tile: 16*MT*NT unconditional stores per lane, addresses by constant strides
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn + j * 32 + fr;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float* base = p.y + (size_t)(m0 + wm + i * 32 + 4 * fh) * p.y_ld + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) base[(size_t)((r & 3) + 8 * (r >> 2)) * p.y_ld] = acc[i][j][r] + bv;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn + j * 32 + fr;
@@ -189,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m < p.M) {
                     size_t opix = (size_t)m;
-                    if (MODE == 1 && p.sub > 1) {
+                    if (!dense_rows) {
                         const int hw = p.Hs * p.Ws;
                         const int ni = m / hw, rem = m - ni * hw;
                         const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
@@ -346,7 +375,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         sh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + xc4);
     }
     float4 rd[DPASS], rx[XPASS];
+    unsigned xok = 0;
+    // (image, oy, ox) of this thread's X rows, advanced incrementally by BK rows per step (no divisions in the loop)
+    int xn[XPASS], xoy[XPASS], xox[XPASS];
+#pragma unroll
+    for (int j = 0; j < XPASS; ++j) {
+        const int m = mbeg + xrow + j * XRPP;
+        xn[j] = m / HoWo;
+        const int rem = m - xn[j] * HoWo;
+        xoy[j] = rem / p.Wo;
+        xox[j] = rem - xoy[j] * p.Wo;
+    }
     auto load_tiles = [&](int mb) {
+        xok = 0;
 #pragma unroll
         for (int j = 0; j < DPASS; ++j) {
             const int r = drow + j * DRPP;
@@ -361,8 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
             const int m = mb + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < BK && m < mend) {
-                const int n = m / HoWo, rem = m - n * HoWo;
-                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int n = xn[j], oy = xoy[j], ox = xox[j];
                 int iy, ix;
                 if (MODE == 2) { iy = oy * 2 - 3 + ky; ix = ox * 2 - 3 + (xc4 >> 2); }
                 else { iy = oy * p.stride - p.pad + ky * p.dil; ix = ox * p.stride - p.pad + kx * p.dil; }
@@ -370,13 +410,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
                     const size_t pix = ((size_t)n * p.H + iy) * p.W + ix;
                     if (MODE == 2) v = *reinterpret_cast<const float4*>(p.x + pix * 4);
                     else v = *reinterpret_cast<const float4*>(p.x + pix * p.x_ld + ci0 + xc4);
-                    if (AFFINE) {
-                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    }
+                    xok |= 1u << j;
                 }
             }
             rx[j] = v;
+            // advance this row slot by BK pixels for the next step
+            xox[j] += BK;
+            while (xox[j] >= p.Wo) { xox[j] -= p.Wo; ++xoy[j]; }
+            while (xoy[j] >= p.Ho) { xoy[j] -= p.Ho; ++xn[j]; }
         }
     };
     auto store_tiles = [&]() {
@@ -388,7 +429,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int j = 0; j < XPASS; ++j) {
             const int r = xrow + j * XRPP;
-            if (r < BK) *reinterpret_cast<float4*>(&Xs[r * TN + xc4]) = rx[j];
+            float4 v = rx[j];
+            if (AFFINE && ((xok >> j) & 1u)) {          // prologue applied after the MFMA phase (see conv_fwd_kernel)
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            if (r < BK) *reinterpret_cast<float4*>(&Xs[r * TN + xc4]) = v;
         }
     };
 
@@ -432,6 +478,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         }
     }
     const size_t row_ld = (size_t)taps * p.Cin;         // dW[o][tap][i]
+    float* wbase = p.dw + (size_t)tap * p.Cin;
+    if (co0 + TM <= p.Cout && ci0 + TN <= p.Cin) {      // full tile: unconditional atomics, constant strides
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float* base = wbase + (size_t)(co0 + wm + i * 32 + 4 * fh) * row_ld + (ci0 + wn + j * 32 + fr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(base + (size_t)((r & 3) + 8 * (r >> 2)) * row_ld, acc[i][j][r]);
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -441,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (co < p.Cout) atomicAdd(p.dw + (size_t)co * row_ld + (size_t)tap * p.Cin + ci, acc[i][j][r]);
+                if (co < p.Cout) atomicAdd(wbase + (size_t)co * row_ld + ci, acc[i][j][r]);
             }
         }
 }
@@ -450,7 +508,8 @@ template <int TM, int TN, int WM, int WN, int WK, int MODE>
 static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     WgradP p = p0;
     const int tiles = (int)(uem_cdiv(p.Cout, TM) * p.KH * p.KW * uem_cdiv(p.Cin, TN));
-    int splits = (int)uem_cdiv(2048, tiles);            // aim for >= 2048 blocks (8 per CU)
+    static const int target_blocks = getenv("UEM_WGRAD_BLOCKS") ? atoi(getenv("UEM_WGRAD_BLOCKS")) : 2048;
+    int splits = (int)uem_cdiv(target_blocks, tiles);   // aim for >= 2048 blocks (8 per CU)
     const int max_splits = (int)uem_cdiv(p.M, 4 * BK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

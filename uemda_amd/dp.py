@@ -13,8 +13,9 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise the default process group from the torchrun environment; returns (rank, world, local_rank)."""
+def init(backend=None, device=None):
+    """Initialise the default process group from the torchrun environment; returns (rank, world, local_rank).
+    `device` overrides LOCAL_RANK as the CUDA device index (single-GPU rehearsals with the gloo backend)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -24,7 +25,7 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local if device is None else device)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

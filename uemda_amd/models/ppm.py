@@ -1,0 +1,108 @@
+"""PPMBilinear head on the MI355X (reference uemda/models/Encoder.py:8-65): adaptive avg-pool at scales
+(1,2,3,6) -> 1x1 conv -> BN -> ReLU -> bilinear up (align_corners=False) -> concat with feat (4096 ch) ->
+3x3 conv -> BN -> ReLU -> Dropout2d(0.1) -> 1x1 conv (+bias).  One autograd node per head; every arithmetic
+step is a HIP kernel (the 3x3 4096->512 conv is the largest GEMM of the PPM network, 38.7 GFLOP/tile/head)."""
+import itertools
+
+import torch
+from torch.autograd import Function
+
+from .. import ops
+from ..ops import UemError, call, ptr, stream
+from .blocks import _BN, _st_from, _st_tensor, grad_buffer, grad_ohwi
+
+_drop_counter = itertools.count(1)
+
+
+def _avgpool(x, s):
+    n, h, w, c = x.shape
+    y = torch.empty((n, s, s, c), device=x.device, dtype=torch.float32)
+    call("uem_adaptive_avgpool_fwd", ptr(x), ptr(y), n, h, w, c, s, stream())
+    return y
+
+
+class PPMHeadFn(Function):
+    @staticmethod
+    def forward(ctx, feat, head, *params):
+        n, h, w, cin = feat.shape
+        scales = head.pool_scales
+        nb = len(scales)
+        ctot = cin + 512 * nb
+        training = head.training
+        cat = torch.empty((n, h, w, ctot), device=feat.device, dtype=torch.float32)
+        cat[..., :cin].copy_(feat)
+        saved_branch = []
+        for i, s in enumerate(scales):
+            conv, bn = head.ppm[i][1], head.ppm[i][2]
+            if training and n * s * s < 2:
+                raise ValueError("Expected more than 1 value per channel when training (PPM scale-1 branch needs B >= 2)")
+            p = _avgpool(feat, s)
+            z = ops.conv2d(p, ops.weight_ohwi(conv.weight))
+            st = _BN.stats(z, bn)
+            call("uem_bilinear_up_fwd", ptr(z), ptr(cat[..., cin + 512 * i:]), n, s, s, 512, h, w, ctot, 0,
+                 ptr(st.scale), ptr(st.shift), 1, stream())
+            saved_branch += [p, z, _st_tensor(st)]
+            if bn.training:
+                bn.num_batches_tracked.add_(1)
+        conv0, bn0, drop, conv4 = head.conv_last[0], head.conv_last[1], head.conv_last[3], head.conv_last[4]
+        zc = ops.conv2d(cat, ops.weight_ohwi(conv0.weight), pad=1)
+        stc = _BN.stats(zc, bn0)
+        if bn0.training:
+            bn0.num_batches_tracked.add_(1)
+        a = ops.affine_act(zc, stc, relu=True)
+        mask = None
+        if training and drop.p > 0:
+            mask = torch.empty((n, 512), device=feat.device, dtype=torch.float32)
+            seed = (torch.initial_seed() * 1000003 + next(_drop_counter)) % (2 ** 63 - 1) + 1
+            call("uem_dropout2d", ptr(a), ptr(a), ptr(mask), n, h * w, 512, float(drop.p), seed, stream())
+        C = conv4.weight.shape[0]
+        w4 = torch.zeros((32, 1, 1, 512), device=feat.device, dtype=torch.float32)
+        w4[:C].copy_(ops.weight_ohwi(conv4.weight))
+        b4 = torch.zeros(32, device=feat.device, dtype=torch.float32)
+        b4[:C].copy_(conv4.bias.detach())
+        out32 = ops.conv2d(a, w4, b4, algo_cout=C)
+        out = out32[..., :C].contiguous()
+        if any(ctx.needs_input_grad):
+            ctx.head, ctx.training, ctx.C = head, stc.training, C
+            ctx.has_mask = mask is not None
+            ctx.save_for_backward(feat, cat, zc, _st_tensor(stc), a, w4, mask if mask is not None else a.new_empty(0),
+                                  *saved_branch)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        head, C = ctx.head, ctx.C
+        feat, cat, zc, stcb, a, w4, mask = ctx.saved_tensors[:7]
+        branch = ctx.saved_tensors[7:]
+        n, h, w, cin = feat.shape
+        ctot = cat.shape[3]
+        conv0, bn0, conv4 = head.conv_last[0], head.conv_last[1], head.conv_last[4]
+        d32 = torch.zeros((n, h, w, 32), device=feat.device, dtype=torch.float32)
+        d32[..., :C].copy_(dout)
+        ops.bias_grad(d32, grad_buffer(conv4.bias), C, 32)
+        dw4 = torch.zeros((32, 1, 1, 512), device=feat.device, dtype=torch.float32)
+        ops.conv2d_wgrad(a, d32, dw4, algo_cout=C)
+        ops.add_(grad_ohwi(conv4.weight), dw4[:C])
+        da = ops.conv2d_dgrad(d32, ops.weight_transpose(w4), a.shape, algo_cout=C)
+        if ctx.has_mask:
+            call("uem_dropout2d", ptr(da), ptr(da), ptr(mask), n, h * w, 512, 0.0, 0, stream())   # seed 0: reuse mask
+        stc = _st_from(stcb, ctx.training)
+        dzc = ops.bn_backward(zc, da, stc, grad_buffer(bn0.weight), grad_buffer(bn0.bias), None, True, dx=da)
+        ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
+        dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose(ops.weight_ohwi(conv0.weight)), cat.shape, pad=1)
+        dfeat = dcat[..., :cin].contiguous()
+        for i, s in enumerate(head.pool_scales):
+            conv, bn = head.ppm[i][1], head.ppm[i][2]
+            p, z, stb = branch[3 * i:3 * i + 3]
+            st = _st_from(stb, ctx.training)
+            du = torch.empty((n, s, s, 512), device=feat.device, dtype=torch.float32)
+            call("uem_bilinear_up_bwd", ptr(dcat[..., cin + 512 * i:]), ptr(du), n, s, s, 512, h, w, ctot, 0, stream())
+            dz = ops.bn_backward(z, du, st, grad_buffer(bn.weight), grad_buffer(bn.bias), None, True, dx=du)
+            ops.conv2d_wgrad(p, dz, grad_ohwi(conv.weight))
+            dp = ops.conv2d_dgrad(dz, ops.weight_transpose(ops.weight_ohwi(conv.weight)), p.shape)
+            call("uem_adaptive_avgpool_bwd", ptr(dp), ptr(dfeat), n, h, w, cin, s, stream())
+        return (dfeat, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def ppm_head(feat, head):
+    return PPMHeadFn.apply(feat, head, *list(head.parameters()))
