@@ -48,12 +48,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // MODE: 0 = forward gather, 1 = transposed gather (data gradient), 2 = stem (NHWC4, 8 px x 4 ch per tap row)
-template <int BN, int WM, int WN, int MODE, bool AFFINE>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
+// NBUF: 1 = one LDS stage (two barriers per k-step, 3 blocks/CU); 2 = two LDS stages (one barrier per k-step,
+//       74 KB => 2 blocks/CU, so power-of-two grids fill the 512 block slots in whole rounds)
+template <int BN, int WM, int WN, int MODE, bool AFFINE, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const ConvP p) {
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int BROWS = BN / 32;                      // B-tile rows per thread
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+    constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const As0 = smem;                            // [NBUF][BM][LDS_LD]
+    float* const Bs0 = smem + NBUF * A_SZ;              // [NBUF][BN][LDS_LD]
+    float* const Ssc = Bs0 + NBUF * B_SZ;               // AFFINE only: [Cin] scale, then [Cin] shift
+    if (AFFINE) {
+        for (int i = threadIdx.x; i < p.Cin; i += 256) { Ssc[i] = p.in_scale[i]; Ssc[p.Cin + i] = p.in_shift[i]; }
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.Cout + BN - 1) / BN;
@@ -83,25 +91,24 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
     const int Ktot = p.KH * p.KW * p.Cin;               // row length of the filter bank
 
     float4 ra[4], rb[BROWS];
-    float4 psc, psh;                                    // prologue operands of the tile in flight
+    int pci0 = 0;                                       // first channel of the tile in flight (prologue operands)
     unsigned okmask = 0;                                // bit j: row j of the tile in flight is in bounds
-    int lt = 0, lci0 = 0;                               // loader position: tap slot, first channel
-    auto load_tiles = [&](int kt) {
-        (void)kt;                                       // (lt, lci0) walk the k-steps in order: no division here
-        const int t = lt, ci0 = lci0;
-        lci0 += BK;
-        if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
+    // Loader state.  Everything that depends on the tap only (bounds, row base pointers, filter column) is
+    // set up ONCE per tap; the Cin/32 channel blocks of that tap then advance the pointers by 32 floats.
+    int lt = 0, lci0 = 0;                               // tap slot, first channel of the next tile
+    unsigned tapok = 0;                                 // bit j: row j is in bounds for the current tap
+    unsigned aoff[4], boff[BROWS];                      // element offsets from p.x / p.w (every tensor here < 2^32 floats)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aoff[j] = 0;
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) boff[j] = 0;
+    auto setup_tap = [&](int t) {
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
         const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);   // tap/3 for tap < 16
         const int kx = tap - ky * p.KW;
-        if (AFFINE) {
-            psc = *reinterpret_cast<const float4*>(p.in_scale + ci0 + lc4);
-            psh = *reinterpret_cast<const float4*>(p.in_shift + ci0 + lc4);
-        }
-        okmask = 0;
+        tapok = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             bool ok = gpix[j] >= 0;
             int iy, ix;
             if (MODE == 1) {
@@ -118,24 +125,46 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
                 ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             }
             if (ok) {
-                const size_t pix = (size_t)gpix[j] + (size_t)iy * p.W + ix;
-                if (MODE == 2) v = *reinterpret_cast<const float4*>(p.x + pix * 4);
-                else v = *reinterpret_cast<const float4*>(p.x + pix * p.x_ld + ci0 + lc4);
-                okmask |= 1u << j;
+                const unsigned pix = (unsigned)(gpix[j] + iy * p.W + ix);
+                aoff[j] = (MODE == 2) ? pix * 4u : pix * (unsigned)p.x_ld + (unsigned)lc4;
+                tapok |= 1u << j;
             }
-            ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
             const int n = n0 + lrow + 32 * j;
-            rb[j] = (n < p.Cout) ? *reinterpret_cast<const float4*>(p.w + (size_t)n * Ktot + (size_t)tap * p.Cin + ci0 + lc4)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            boff[j] = (unsigned)(n < p.Cout ? n : 0) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc4);
         }
+    };
+    auto load_tiles = [&](int kt) {
+        (void)kt;                                       // tiles are walked strictly in order
+        if (lci0 == 0) setup_tap(lt);                   // block-uniform branch
+        pci0 = lci0;
+        okmask = tapok;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = ((tapok >> j) & 1u) ? *reinterpret_cast<const float4*>(p.x + aoff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            aoff[j] += BK;
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j) {
+            rb[j] = (n0 + lrow + 32 * j < p.Cout) ? *reinterpret_cast<const float4*>(p.w + boff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            boff[j] += BK;
+        }
+        lci0 += BK;
+        if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
     };
     // the BatchNorm-affine + ReLU prologue is applied here, AFTER the MFMA phase the loads overlapped with
     // (touching the loaded registers earlier would force the s_waitcnt vmcnt in front of the MFMAs);
     // zero padding stays zero: rows that were out of bounds are not transformed.
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
+        float* const As = As0 + buf * A_SZ;
+        float* const Bs = Bs0 + buf * B_SZ;
+        float4 psc, psh;
+        if (AFFINE) {                                   // per-channel operands live in LDS, not in registers
+            psc = *reinterpret_cast<const float4*>(&Ssc[pci0 + lc4]);
+            psh = *reinterpret_cast<const float4*>(&Ssc[p.Cin + pci0 + lc4]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = ra[j];
@@ -162,10 +191,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
 
     if (KT > 0) {
         load_tiles(0);
-        store_tiles();
+        store_tiles(0);
     }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
+        const int cur = (NBUF == 2) ? (kt & 1) : 0;
+        const float* const As = As0 + cur * A_SZ;
+        const float* const Bs = Bs0 + cur * B_SZ;
         if (kt + 1 < KT) load_tiles(kt + 1);            // in flight during the MFMA phase
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
@@ -182,10 +214,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvP p) {
             MFMA_STEP(x) MFMA_STEP(y) MFMA_STEP(z) MFMA_STEP(w)
 #undef MFMA_STEP
         }
-        __syncthreads();
-        if (kt + 1 < KT) {
-            store_tiles();
+        if (NBUF == 2) {
+            // the other stage was last read in iteration kt-1, which every wave left through the barrier below
+            if (kt + 1 < KT) store_tiles(cur ^ 1);
             __syncthreads();
+        } else {
+            __syncthreads();
+            if (kt + 1 < KT) {
+                store_tiles(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -245,19 +283,36 @@ static int conv_check(const uem_conv_shape* s) {
     return UEM_OK;
 }
 
+template <int BN_, int WM_, int WN_, int MODE, int NBUF>
+static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
+    size_t lds = (size_t)NBUF * (BM + BN_) * LDS_LD * sizeof(float);
+    if (affine) lds += (size_t)2 * p.Cin * sizeof(float);
+    if (affine) {
+        auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, true, NBUF>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k<<<grid, 256, lds, st>>>(p);
+    } else {
+        auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, false, NBUF>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k<<<grid, 256, lds, st>>>(p);
+    }
+}
+
 template <int MODE>
 static int conv_launch(const ConvP& p, bool affine, hipStream_t st) {
+    static const int nbuf = getenv("UEM_CONV_NBUF") ? atoi(getenv("UEM_CONV_NBUF")) : 1;
     const int tiles_m = (int)uem_cdiv(p.M, BM);
-#define CONV_GO(BN_, WM_, WN_)                                                                   \
-    do {                                                                                         \
-        const int grid = tiles_m * (int)uem_cdiv(p.Cout, BN_);                                   \
-        if (affine) conv_fwd_kernel<BN_, WM_, WN_, MODE, true><<<grid, 256, 0, st>>>(p);        \
-        else conv_fwd_kernel<BN_, WM_, WN_, MODE, false><<<grid, 256, 0, st>>>(p);              \
-    } while (0)
-    if (p.Cout % 128 == 0) CONV_GO(128, 2, 2);
-    else if (p.Cout % 64 == 0) CONV_GO(64, 2, 2);
-    else CONV_GO(32, 4, 1);
-#undef CONV_GO
+    if (p.Cout % 128 == 0) {
+        const int grid = tiles_m * (p.Cout / 128);
+        if (nbuf == 2) conv_go<128, 2, 2, MODE, 2>(p, affine, grid, st);
+        else conv_go<128, 2, 2, MODE, 1>(p, affine, grid, st);
+    } else if (p.Cout % 64 == 0) {
+        const int grid = tiles_m * (p.Cout / 64);
+        if (nbuf == 2) conv_go<64, 2, 2, MODE, 2>(p, affine, grid, st);
+        else conv_go<64, 2, 2, MODE, 1>(p, affine, grid, st);
+    } else {
+        conv_go<32, 4, 1, MODE, 1>(p, affine, tiles_m * (int)uem_cdiv(p.Cout, 32), st);
+    }
     return uem_check_launch("conv2d");
 }
 
