@@ -412,13 +412,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci_tiles = (p.Cin + TN - 1) / TN;
     const int taps = p.KH * p.KW;
-    int t = blockIdx.x;
+    // 1-D grid of tiles x splits, remapped so that one XCD walks consecutive ids = all tiles of one pixel
+    // chunk: the chunk's dY / X rows are then pulled into ONE L2 instead of eight
+    const int ntiles = ci_tiles * taps * ((p.Cout + TM - 1) / TM);
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lin / ntiles;
+    int t = lin - split * ntiles;
     const int ci_t = t % ci_tiles; t /= ci_tiles;
     const int tap = t % taps;
     const int co_t = t / taps;
     const int co0 = co_t * TM, ci0 = ci_t * TN;
     const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const int mbeg = blockIdx.y * p.rows_per_split;
+    const int mbeg = split * p.rows_per_split;
     const int mend = min(p.M, mbeg + p.rows_per_split);
     const int HoWo = p.Ho * p.Wo;
 
@@ -563,16 +568,27 @@ template <int TM, int TN, int WM, int WN, int WK, int MODE>
 static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     WgradP p = p0;
     const int tiles = (int)(uem_cdiv(p.Cout, TM) * p.KH * p.KW * uem_cdiv(p.Cin, TN));
-    static const int target_blocks = getenv("UEM_WGRAD_BLOCKS") ? atoi(getenv("UEM_WGRAD_BLOCKS")) : 2048;
-    int splits = (int)uem_cdiv(target_blocks, tiles);   // aim for >= 2048 blocks (8 per CU)
+    // split-K sizing: ~2048 blocks fill the chip, but every split adds one fp32-atomic pass over the whole
+    // filter bank (chip-wide atomic rate 1.3 TB/s).  With few output tiles that pass dominates (measured: 60 %
+    // of the kernel at 16 tiles x 128 splits), so there the split count is capped at M/1536 (atomics ~10 % of
+    // the MFMA time) but never below what yields 512 blocks.
+    static const int forced = getenv("UEM_WGRAD_SPLITS") ? atoi(getenv("UEM_WGRAD_SPLITS")) : 0;
     const int max_splits = (int)uem_cdiv(p.M, 4 * BK);
+    int splits = (int)uem_cdiv(2048, tiles);
+    if (tiles <= 32) {
+        int cap = p.M / 1536;
+        const int floor_splits = (int)uem_cdiv(512, tiles);
+        if (cap < floor_splits) cap = floor_splits;
+        if (splits > cap) splits = cap;
+    }
+    if (forced > 0) splits = forced;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rps = (int)uem_cdiv(p.M, splits);
     rps = (int)uem_cdiv(rps, BK) * BK;
     splits = (int)uem_cdiv(p.M, rps);
     p.rows_per_split = rps;
-    dim3 grid((unsigned)tiles, (unsigned)splits);
+    const unsigned grid = (unsigned)tiles * (unsigned)splits;
     if (affine) conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, true><<<grid, 256, 0, st>>>(p);
     else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false><<<grid, 256, 0, st>>>(p);
 }
