@@ -205,6 +205,21 @@ int uem_class_count(const int64_t* label, int64_t n, int C, int64_t ignore_label
 int uem_class_weight_gather(const int64_t* label, const float* class_w, float* out, int64_t n, int C,
                             int64_t ignore_label, void* stream);
 
+/* ---- rows either side of the step: sliding-window / TTA inference, evaluation, prototype init ----
+ * window_accumulate: dst[b,c,y1+i,x1+j] += src[b,c,i,j], cnt[b,y1+i,x1+j] += 1     tools.py:91-92
+ *   (src may be a padded tile of size src_h x src_w >= th x tw; tools.py:77,90)
+ * window_normalize: dst /= cnt                                                      tools.py:94          */
+int uem_window_accumulate(float* dst, float* cnt, const float* src, int B, int C, int H, int W, int y1, int x1,
+                          int th, int tw, int src_h, int src_w, void* stream);
+int uem_window_normalize(float* dst, const float* cnt, int B, int C, int H, int W, void* stream);
+int uem_scale(float* a, int64_t n, float s, void* stream);
+/* pred[b,p] = argmax_c prob[b,c,p] (NULL to skip) and cm[gt][pred] += 1 over pixels with 0 <= gt < C
+ * (cm: C*C int64, caller zero-fills; gt/cm NULL to skip)             utils/eval.py:41-50, metrics.py:26 */
+int uem_argmax_confusion(const float* prob, const int64_t* gt, int64_t* pred, int64_t* cm, int B, int C, int64_t HW,
+                         void* stream);
+/* prototypes = sums / (counts + 1e-7)   (Aligner.init_avg, alignment.py:121-122)                       */
+int uem_proto_mean(const float* sums, const float* counts, float* protos, int k, int C, void* stream);
+
 /* ---- optimizer: clip_grad_norm_(max_norm, L2) + SGD(momentum, weight_decay) over a flat arena ----------
  * train_ssl_uem.py:169-170,228-232.  sqnorm: partial sums (>= UEM_NORM_BLOCKS floats) -> norm_out[0].  */
 #define UEM_NORM_BLOCKS 1024

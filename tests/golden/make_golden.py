@@ -283,6 +283,13 @@ def main():
     its = [0, 1, 299, 300, 301, 3000, 5999]
     save("lr_schedule", iters=np.array(its), lrs=np.array([ref.tools.adjust_learning_rate(opt, i, cfg) for i in its]))
 
+    # pre_slide with a closed-form "model" (elementwise, so that the windowing is what is pinned)
+    def fake_model(x):
+        return torch.stack([x[:, 0] * 0.5 + x[:, 1], x[:, 2] - x[:, 0], x.sum(1) * 0.25], dim=1)
+    img = torch.randn(2, 3, 72, 88, generator=torch.Generator().manual_seed(4242))
+    save("pre_slide", image=img, out=ref.tools.pre_slide(fake_model, img, num_classes=3, tile_size=(32, 32), tta=False),
+         out_one_tile=ref.tools.pre_slide(fake_model, img[:, :, :32, :32], num_classes=3, tile_size=(32, 32), tta=False))
+
     # ---------------- G-layers ------------------------------------------------------------------
     print("G-layers")
     from oracle.weights import _rng, fill_like

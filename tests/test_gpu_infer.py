@@ -1,0 +1,91 @@
+"""GPU parity of the inference-side rows: sliding window, TTA, evaluation, prototype init."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+C = 6
+
+
+def fake_model(x):
+    return torch.stack([x[:, 0] * 0.5 + x[:, 1], x[:, 2] - x[:, 0], x.sum(1) * 0.25], dim=1)
+
+
+def test_pre_slide_golden_and_tta_vs_oracle():
+    from oracle import infer
+    from uemda_amd.utils.tools import pre_slide, tta_predict
+    g = load_golden("pre_slide")
+    out = pre_slide(fake_model, g["image"].cuda(), num_classes=3, tile_size=(32, 32))
+    torch.testing.assert_close(out.cpu(), g["out"], rtol=1e-6, atol=1e-6)
+    one = pre_slide(fake_model, g["image"][:, :, :32, :32].cuda(), num_classes=3, tile_size=(32, 32))
+    torch.testing.assert_close(one.cpu(), g["out_one_tile"], rtol=1e-6, atol=1e-6)
+
+    def asym(x):                                       # position dependent: exercises the de-augmentation order
+        h, w = x.shape[-2:]
+        ramp = torch.arange(h * w, dtype=torch.float32, device=x.device).view(1, 1, h, w) / (h * w)
+        return torch.cat([x[:, :2] * ramp, x[:, 2:] + ramp], 1)
+    img = g["image"][:1, :, :40, :40]
+    ref = infer.tta_predict(asym, img)
+    got = tta_predict(asym, img.cuda())
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+    ref = infer.pre_slide(asym, g["image"][:1, :, :64, :64], 3, (32, 32), tta=True)
+    got = pre_slide(asym, g["image"][:1, :, :64, :64].cuda(), 3, (32, 32), tta=True)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_confusion_matrix_and_metrics_exact():
+    from oracle import infer
+    from uemda_amd.utils.eval import ConfusionMeter
+    gen = torch.Generator().manual_seed(3)
+    prob = torch.rand(3, C, 50, 70, generator=gen)
+    prob[0, :, :5] = 0.5                               # ties -> first maximum
+    gt = torch.randint(-1, C, (3, 50, 70), generator=gen)
+    meter = ConfusionMeter(C, ignore_labels=[0])
+    pred = meter.update(prob.cuda(), gt.cuda())
+    assert torch.equal(pred.cpu(), prob.argmax(1))
+    cm = infer.confusion(prob, gt, C)
+    assert np.array_equal(meter.cm.cpu().numpy(), cm)
+    res, ref = meter.summary(), infer.metrics(cm, ignore_labels=[0])
+    np.testing.assert_allclose(res["iou"], np.round(ref["iou"], 5))
+    assert res["miou"] == pytest.approx(ref["miou"], abs=1e-5)
+
+
+def test_init_prototypes_and_pseudo_generation_roundtrip(tmp_path):
+    from oracle import gast, synth
+    from oracle.weights import det_state_dict
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.gast.pseudo_generation import gener_target_pseudo
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.utils.eval import evaluate
+    b = synth.make_batch(B=4, H=64, W=64, C=C, k=64, seed=9)
+    gen = torch.Generator().manual_seed(1)
+    feats = [torch.randn(2, 64, 4, 4, generator=gen) for _ in range(2)]
+    al = Aligner(None, 64, C, -1, 0.996)
+    sums, cnts = torch.zeros(C, 64), torch.zeros(C)
+    for i, f in enumerate(feats):                      # tools/init_prototypes.py:101-111
+        lab = b["label_s"][2 * i:2 * i + 2]
+        al.update_avg(f.cuda(), lab.cuda())
+        ds = gast.downscale_label(lab, C)
+        _, s, n = gast.local_prototypes(f, ds, torch.zeros(C, 64), C)
+        sums, cnts = sums + s, cnts + n
+    al.init_avg()
+    torch.testing.assert_close(al.prototypes.cpu(), sums / (cnts.unsqueeze(1) + 1e-7), rtol=1e-5, atol=1e-6)
+    # offline pseudo labels: <name>.pt holds the (C,H,W) fp32 probability map the target loader reads back
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    model = Deeplabv2(cfg)
+    model.load_state_dict(det_state_dict("resnet50", C, False, seed=2333))
+    model = model.cuda()
+    # 512x768: two overlapping 512-px windows (images smaller than the tile give 0/0 in the reference too)
+    imgs = [torch.randn(1, 3, 512, 768, generator=gen).cuda() for _ in range(2)]
+    hards = gener_target_pseudo(model, imgs, ["a.png", "b.png"], str(tmp_path), C, slide=True, size=(512, 768))
+    prob = torch.load(os.path.join(str(tmp_path), "a.png.pt"))
+    assert prob.shape == (C, 512, 768) and prob.dtype == torch.float32
+    assert torch.allclose(prob.sum(0), torch.ones(512, 768), atol=1e-4)
+    assert hards[0].shape == (1, 512, 768)
+    res, miou = evaluate(model, [(imgs[0], torch.randint(-1, C, (1, 512, 768)).cuda())], C, ignore_labels=[0])
+    assert 0.0 <= miou <= 1.0 and res["confusion"].sum() > 0

@@ -252,3 +252,18 @@ def test_full_model_ssl_step(tag):
     torch.testing.assert_close(model.p["encoder.resnet.bn1.running_mean"], g["post_bn1_running_mean"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(model.p["encoder.resnet.layer4.2.bn3.running_var"], g["post_l4_bn3_running_var"], rtol=1e-4, atol=1e-6)
     assert int(model.p["encoder.resnet.bn1.num_batches_tracked"]) == int(g["nbt"]) == 2
+
+
+def test_pre_slide_windowing_golden():
+    from oracle import infer
+    g = load_golden("pre_slide")
+
+    def fake_model(x):
+        return torch.stack([x[:, 0] * 0.5 + x[:, 1], x[:, 2] - x[:, 0], x.sum(1) * 0.25], dim=1)
+    out = infer.pre_slide(fake_model, g["image"], num_classes=3, tile_size=(32, 32))
+    torch.testing.assert_close(out, g["out"], rtol=1e-6, atol=1e-6)
+    one = infer.pre_slide(fake_model, g["image"][:, :, :32, :32], num_classes=3, tile_size=(32, 32))
+    torch.testing.assert_close(one, g["out_one_tile"], rtol=1e-6, atol=1e-6)
+    # TTA of a model that commutes with the dihedral group is the model itself
+    eq = infer.tta_predict(lambda x: x * 2.0, g["image"][:1])
+    torch.testing.assert_close(eq, g["image"][:1] * 2.0, rtol=1e-6, atol=1e-6)

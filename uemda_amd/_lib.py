@@ -80,6 +80,11 @@ SIGNATURES = {
     "uem_uvem_weight": [P, P, L, F, F, F, P],
     "uem_class_count": [P, L, I, L, P, P],
     "uem_class_weight_gather": [P, P, P, L, I, L, P],
+    "uem_window_accumulate": [P, P, P, I, I, I, I, I, I, I, I, I, I, P],
+    "uem_window_normalize": [P, P, I, I, I, I, P],
+    "uem_scale": [P, L, F, P],
+    "uem_argmax_confusion": [P, P, P, P, I, I, L, P],
+    "uem_proto_mean": [P, P, P, I, I, P],
     "uem_grad_sqnorm": [P, L, P, P, P],
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
 }

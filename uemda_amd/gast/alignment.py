@@ -168,6 +168,9 @@ class Aligner:
         ops.add_(self._data_cnt, cnts.view(-1, 1).contiguous())
 
     def init_avg(self):
-        # prototypes = sum / (cnt + eps): expressed with the EMA kernel is not possible (decay in (0,1));
-        # this runs once per stage, on (C, k) values, through the proto_ema kernel with counts forced >= 1
-        raise UemError("init_avg belongs to tools/init_prototypes.py (SURVEY section 8 f3, 'next'); not built yet")
+        """prototypes = accumulated class sums / (counts + eps)  (alignment.py:121-122; tools/init_prototypes.py)."""
+        self.prototypes = torch.empty_like(self._data_sum)
+        call("uem_proto_mean", ptr(self._data_sum), ptr(self._data_cnt.contiguous()), ptr(self.prototypes),
+             self.feat_channels, self.class_num, stream())
+        if self.logger is not None:
+            self.logger.info('finish init prototypes!')

@@ -32,3 +32,26 @@ def pseudo_selection(mask, cutoff_top=0.8, cutoff_low=0.6, return_type='ndarray'
         call("uem_plane_max", ptr(m), ptr(_plane_max), B, C, H * W, stream())
     ret = _select(m, _plane_max, cutoff_top, cutoff_low, ignore_label, check_range)
     return ret.cpu().numpy() if return_type == 'ndarray' else ret
+
+
+def gener_target_pseudo(model, images, names, save_pseudo_label_path, num_classes, slide=True, save_prob=True,
+                        size=None, cutoff_top=0.8, cutoff_low=0.6, ignore_label=-1):
+    """Offline pseudo-label generation (pseudo_generation.py:96-155): eval-mode sliding-window forward with the
+    8-way TTA, then `<fname>.pt` = torch.save of the (C,H,W) fp32 probability map (the wire format
+    `BaseData.__getitem__` loads, basedata.py:87).  `images` yields (1,3,H,W) CUDA tensors, `names` the file names.
+    Returns the hard labels selected from each map (what the reference only renders as colour PNGs)."""
+    import os
+    from ..utils.tools import pre_slide
+    os.makedirs(save_pseudo_label_path, exist_ok=True)
+    model.eval()
+    hards = []
+    with torch.no_grad():
+        for img, name in zip(images, names):
+            cls = pre_slide(model, img, num_classes=num_classes, tta=True) if slide else model(img)
+            if size is not None and tuple(size) != tuple(cls.shape[-2:]):
+                raise UemError("gener_target_pseudo: resizing to a different `size` is not implemented "
+                               "(the ISPRS / LoveDA tiles are generated at their native size)")
+            if save_prob:
+                torch.save(cls.squeeze(dim=0).cpu(), os.path.join(save_pseudo_label_path, name + '.pt'))
+            hards.append(pseudo_selection(cls, cutoff_top, cutoff_low, 'tensor', ignore_label))
+    return hards

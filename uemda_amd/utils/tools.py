@@ -57,3 +57,61 @@ def seed_torch(seed=2333):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+
+
+# ---- sliding-window / test-time-augmentation inference (reference tools.py:53-97,132-152) --------------------
+def pad_image(img, target_size):
+    """tools.py:53-58, verbatim semantics: F.pad(img, (0, 0, rows_missing, cols_missing)) -- i.e. the reference
+    pads only the HEIGHT (top by rows_missing, bottom by cols_missing); it is a no-op for every window pre_slide
+    cuts from an image at least as large as the tile.  Pure data movement."""
+    import torch.nn.functional as tnf
+    rows_missing, cols_missing = target_size[0] - img.shape[2], target_size[1] - img.shape[3]
+    if rows_missing == 0 and cols_missing == 0:
+        return img
+    return tnf.pad(img, (0, 0, rows_missing, cols_missing), 'constant', 0)
+
+
+def tta_predict(model, img):
+    """hflip x rot90{0,90,180,270}: 8 eval forwards, de-augmented and averaged (tools.py:132-152; ttach semantics:
+    augment = hflip then rot90(k), de-augment = rot90(-k) then hflip).  Like the reference, the mean is taken over
+    the concatenated batch dimension, so it is only meaningful for batch size 1."""
+    from .. import ops
+    if img.shape[0] != 1:
+        raise UemError("tta_predict: the reference averages over cat(xs, 0); use batch size 1")
+    acc = None
+    for flip in (False, True):
+        for k in range(4):
+            aug = img.flip(3) if flip else img
+            aug = torch.rot90(aug, k, (2, 3)).contiguous()
+            x = model(aug)
+            x = torch.rot90(x, -k, (2, 3))
+            x = (x.flip(3) if flip else x).contiguous()
+            acc = x if acc is None else ops.add_(acc, x)
+    ops.call("uem_scale", ops.ptr(acc), acc.numel(), 1.0 / 8.0, ops.stream())
+    return acc
+
+
+def pre_slide(model, image, num_classes=7, tile_size=(512, 512), tta=False):
+    """overlap-averaged sliding-window inference, tile 512 / stride 256 (tools.py:61-97)."""
+    from math import ceil
+    from .. import ops
+    ops.need_gpu(image)
+    B, _, H, W = image.shape
+    stride = ceil(tile_size[0] * (1 - 1 / 2))
+    tile_rows = int(ceil((H - tile_size[0]) / stride) + 1)
+    tile_cols = int(ceil((W - tile_size[1]) / stride) + 1)
+    full = torch.zeros((B, num_classes, H, W), device=image.device, dtype=torch.float32)
+    cnt = torch.zeros((B, 1, H, W), device=image.device, dtype=torch.float32)
+    for row in range(tile_rows):
+        for col in range(tile_cols):
+            x1, y1 = int(col * stride), int(row * stride)
+            x2, y2 = min(x1 + tile_size[1], W), min(y1 + tile_size[0], H)
+            x1, y1 = max(int(x2 - tile_size[1]), 0), max(int(y2 - tile_size[0]), 0)
+            img = image[:, :, y1:y2, x1:x2]
+            padded_img = pad_image(img, tile_size).contiguous()
+            padded = tta_predict(model, padded_img) if tta else model(padded_img)
+            padded = padded.contiguous()
+            ops.call("uem_window_accumulate", ops.ptr(full), ops.ptr(cnt), ops.ptr(padded), B, num_classes, H, W, y1, x1,
+                     y2 - y1, x2 - x1, padded.shape[2], padded.shape[3], ops.stream())
+    ops.call("uem_window_normalize", ops.ptr(full), ops.ptr(cnt), B, num_classes, H, W, ops.stream())
+    return full
