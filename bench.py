@@ -63,8 +63,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU source batch (= target batch)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", default="ssl", choices=["ssl", "src"])
+    ap.add_argument("--model", default="resnet50", choices=["resnet50", "resnet101"])
+    ap.add_argument("--head", default="aspp", choices=["aspp", "ppm"])
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force the CUDA device index (rehearsal on one GPU)")
+    ap.add_argument("--no-overlap", action="store_true", help="all-reduce the whole gradient arena after backward")
+    ap.add_argument("--dump-params", default="", help="write a parameter checksum after the run (DP rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -85,11 +89,11 @@ def main():
 
     C, B, S = 6, args.batch, args.size
     seed_torch(2333)
-    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True,
-               cascade=False, use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048,
-               num_classes=C, is_ins_norm=True)
+    cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
+               cascade=False, use_ppm=(args.head == "ppm"), ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
+               inchannels=2048, num_classes=C, is_ins_norm=True)
     model = Deeplabv2(cfg).cuda()                 # random init of the reference's architecture (no checkpoints)
-    wrapper = udp.DataParallel(model) if world > 1 else None
+    wrapper = udp.DataParallel(model, overlap=not args.no_overlap) if world > 1 else None
     # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
     pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + rank)
     rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]
@@ -156,7 +160,7 @@ def main():
             "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"train_ssl_uem step ({args.workload}): ResNet50-ASPP 6-class, per-GPU {B} source + "
+            "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, fp32 (f32 MFMA), "
                                    f"random init; tiles counted = source + target",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}"},
@@ -166,6 +170,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+    if args.dump_params:
+        arena, _, n = model.flat_parameters()
+        with open(f"{args.dump_params}.rank{rank}", "w") as f:
+            f.write(f"{float(arena[:n].double().sum()):.10e} {float(arena[:n].double().abs().sum()):.10e}\n")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -280,6 +280,11 @@ static int conv_check(const uem_conv_shape* s) {
     const int wo = (s->W + 2 * s->pad - s->dil * (s->KW - 1) - 1) / s->stride + 1;
     if (ho != s->Ho || wo != s->Wo) return uem_fail(UEM_ERR_INVALID, "conv: Ho/Wo (%d,%d) inconsistent with input (expected %d,%d)", s->Ho, s->Wo, ho, wo);
     if (s->x_ld < s->Cin || s->y_ld < s->Cout || (s->x_ld % 4) != 0) return uem_fail(UEM_ERR_INVALID, "conv: bad x_ld/y_ld");
+    // the loaders index with 32-bit element offsets
+    const double lim = 4294967296.0;
+    if ((double)s->N * s->H * s->W * s->x_ld >= lim || (double)s->N * s->Ho * s->Wo * s->y_ld >= lim ||
+        (double)s->Cout * s->KH * s->KW * s->Cin >= lim)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv: tensor has >= 2^32 elements (split the batch)");
     return UEM_OK;
 }
 

@@ -49,9 +49,16 @@ def allreduce_flat_(flat, async_op=False):
 
 
 class DataParallel:
-    """Thin wrapper: broadcast at construction, `reduce_gradients()` after backward."""
+    """Broadcast at construction, then per iteration `reduce_gradients()` after backward.
 
-    def __init__(self, model):
+    The gradient all-reduce is split into two buckets of the flat arena and the first one is started while
+    backward is still running: parameters sit in the arena in forward order, backward finishes them last-to-
+    first, so once `layer3[0]` has finished its backward for every forward of the step, the tail of the arena
+    (layer3 + layer4 + heads = 94 % of the R50-ASPP bytes) is final and goes out asynchronously (RCCL runs it on
+    its own stream, ordered after the kernels already queued); the head of the arena follows after backward.
+    """
+
+    def __init__(self, model, overlap=True):
         self.model = model
         self.world = world_size()
         arena, _, _ = model.flat_parameters()
@@ -59,9 +66,49 @@ class DataParallel:
         for b in model.buffers():
             if b.is_floating_point():
                 broadcast_flat(b)
+        self._split = None
+        self._pending = None
+        self._fwd_calls = 0
+        self._bwd_calls = 0
+        if overlap and self.world > 1:
+            self._install_overlap()
+
+    # ---- overlap machinery -------------------------------------------------------------------------------
+    def _install_overlap(self):
+        model = self.model
+        try:
+            trigger = model.encoder.resnet.layer3[0]
+            first = next(trigger.parameters())
+        except (AttributeError, StopIteration, IndexError):
+            return
+        arena, _, n = model.flat_parameters()
+        off = (first.data_ptr() - arena.data_ptr()) // arena.element_size()
+        if not (0 < off < n):
+            return
+        self._split = int(off) // 4 * 4
+        trigger._uem_after_backward = self._on_trigger_backward
+        model.register_forward_pre_hook(self._on_forward)
+
+    def _on_forward(self, module, args):
+        if module.training and torch.is_grad_enabled():
+            self._fwd_calls += 1
+
+    def _on_trigger_backward(self):
+        self._bwd_calls += 1
+        if self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
+            _, garena, n = self.model.flat_parameters()
+            self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def reduce_gradients(self):
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
-        allreduce_flat_(garena)
+        if self.world > 1:
+            if self._pending is not None:
+                dist.all_reduce(garena[:self._split], op=dist.ReduceOp.SUM)
+                self._pending.wait()
+            else:
+                dist.all_reduce(garena, op=dist.ReduceOp.SUM)
+        self._pending = None
+        self._fwd_calls = 0
+        self._bwd_calls = 0
         return 1.0 / self.world

@@ -152,6 +152,9 @@ class BottleneckFn(Function):
             ops.conv2d_dgrad(dzd, ops.weight_transpose(W(ds_conv.weight)), x.shape, stride=s, out=dx, accumulate=True)
         else:
             dx = ops.conv2d_dgrad(dz1, wt1, x.shape, out=dp, accumulate=True)     # identity grad + conv1 dgrad
+        cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
+        if cb is not None:
+            cb()
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
