@@ -100,7 +100,8 @@ int uem_affine_act(const float* x, const float* scale, const float* shift, const
  * pass 2: dx = scale*(dp - dbeta/M - xhat*dgamma/M);  dres (optional) = dp                         */
 int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                       const float* save_mean, const float* save_invstd, int M, int C, int relu,
-                      float* dgamma /* = */, float* dbeta /* = */, float* workspace, void* stream);
+                      float* dgamma /* = */, float* dbeta /* = */, float* grad_gamma /* +=, may be NULL */,
+                      float* grad_beta /* +=, may be NULL */, float* workspace, void* stream);
 int uem_bn_bwd_apply(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
@@ -149,7 +150,7 @@ int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_
                            int H, int W, int S, void* stream);
 /* fused three-view refinement (alignment.py:209-293) for modes all / s / p / l:
  *   soft_out = normalise( weight * soft ), and per-(b,c) max of soft_out into plane_max (uint bits of
- *   non-negative floats, caller zero-fills) for the selection pass.  sim / logits are (B,h,w,C).    */
+ *   non-negative floats; written, not accumulated) for the selection pass.  sim / logits are (B,h,w,C). */
 #define UEM_REFINE_ALL 0
 #define UEM_REFINE_S 1
 #define UEM_REFINE_P 2
@@ -157,7 +158,9 @@ int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_
 int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
                      const float* logits2 /* may be NULL */, const uint32_t* seg_keys,
                      const int64_t* ignore_id /* device */, float* soft_out, uint32_t* plane_max,
-                     int B, int C, int h, int w, int H, int W, int S, float temp, int mode, void* stream);
+                     float* workspace /* uem_label_refine_workspace_floats(B,C,H,W) */, int B, int C, int h, int w,
+                     int H, int W, int S, float temp, int mode, void* stream);
+int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W);
 /* per-(b,c) max over H*W of an NCHW map                                pseudo_generation.py:76     */
 int uem_plane_max(const float* mask, uint32_t* plane_max, int B, int C, int64_t HW, void* stream);
 /* hard[b][p] = the unique c with mask > max(cutoff_top*max_c, cutoff_low), else ignore

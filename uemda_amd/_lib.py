@@ -46,7 +46,7 @@ SIGNATURES = {
     "uem_bn_workspace_floats": [I, I],
     "uem_bn_eval_affine": [P, P, P, P, F, P, P, I, P],
     "uem_affine_act": [P, P, P, P, P, P, P, L, I, I, P],
-    "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P],
+    "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
     "uem_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, P, P, P],
     "uem_affine_act_bwd": [P, P, P, P, P, L, I, I, P, P, P],
     "uem_maxpool3x3s2_fwd": [P, P, P, I, I, I, I, P],
@@ -66,7 +66,8 @@ SIGNATURES = {
     "uem_index_max": [P, L, P, P],
     "uem_scatter": [P, P, P, P, I, I, I, I, I, P],
     "uem_segment_max_planar": [P, P, P, I, I, I, I, I, P],
-    "uem_label_refine": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "uem_label_refine": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "uem_label_refine_workspace_floats": [I, I, I, I],
     "uem_plane_max": [P, P, I, I, L, P],
     "uem_pseudo_select": [P, P, P, P, I, I, L, F, F, L, P],
     "uem_downscale_label": [P, P, I, I, I, I, I, L, F, P],
@@ -88,7 +89,8 @@ SIGNATURES = {
     "uem_grad_sqnorm": [P, L, P, P, P],
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
 }
-_RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64}
+_RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64,
+            "uem_label_refine_workspace_floats": c_int64}
 
 # compile-time constants mirrored from the header
 UEM_MAX_CLASSES = 16

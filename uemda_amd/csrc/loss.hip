@@ -83,6 +83,17 @@ __global__ __launch_bounds__(256) void loss_gather_kernel(
     const int ww = xhi - xlo + 1, wh = yhi - ylo + 1;
     const float* l1b = lg1 + (size_t)b * h * w * C;
     const float* l2b = lg2 ? lg2 + (size_t)b * h * w * C : nullptr;
+    // every pixel that touches this cell interpolates inside the 3x3 cell neighbourhood: stage it in LDS once
+    __shared__ float nb[2][3][3][CMAX];
+    for (int i = threadIdx.x; i < 2 * 9 * CMAX; i += 256) {
+        const int c = i % CMAX, q = (i / CMAX) % 9, hd = i / (9 * CMAX);
+        const int yy = cy - 1 + q / 3, xx = cx - 1 + q % 3;
+        const float* src = hd ? l2b : l1b;
+        float v = 0.f;
+        if (src != nullptr && c < C && yy >= 0 && yy < h && xx >= 0 && xx < w) v = src[((size_t)yy * w + xx) * C + c];
+        nb[hd][q / 3][q % 3][c] = v;
+    }
+    __syncthreads();
     float g1[CMAX], g2[CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) g1[c] = g2[c] = 0.f;
@@ -112,14 +123,21 @@ __global__ __launch_bounds__(256) void loss_gather_kernel(
         if (pixw) pw *= pixw[(size_t)b * plane + p];
         if (!lab_ok) pw = 0.f;                                    // ignore_index: zero loss and gradient
         float v[CMAX], ce;
-        up_logits<CMAX>(l1b, C, w, ly, lx, v);
+        const int ry0 = ly.i0 - cy + 1, ry1 = ly.i1 - cy + 1, rx0 = lx.i0 - cx + 1, rx1 = lx.i1 - cx + 1;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) v[c] = ly.l0 * (lx.l0 * nb[0][ry0][rx0][c] + lx.l1 * nb[0][ry0][rx1][c]) +
+                              ly.l1 * (lx.l0 * nb[0][ry1][rx0][c] + lx.l1 * nb[0][ry1][rx1][c]);
         softmax_ce<CMAX>(v, C, lab, ce);
         if (owner) loss1 += pw * ce;
         const float k1 = pw * wy * wx;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) g1[c] += k1 * (v[c] - (c == lab ? 1.f : 0.f));
         if (l2b) {
-            up_logits<CMAX>(l2b, C, w, ly, lx, v);
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) v[c] = ly.l0 * (lx.l0 * nb[1][ry0][rx0][c] + lx.l1 * nb[1][ry0][rx1][c]) +
+                                  ly.l1 * (lx.l0 * nb[1][ry1][rx0][c] + lx.l1 * nb[1][ry1][rx1][c]);
             softmax_ce<CMAX>(v, C, lab, ce);
             if (owner) loss2 += pw * ce;
 #pragma unroll

@@ -251,54 +251,83 @@ __device__ __forceinline__ void softmax_maxnorm(float (&v)[CMAX], int C, float i
     for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] / d;
 }
 
+// One block = 256 consecutive pixels of ONE image row, so the vertical lerp is block-uniform and the strip
+// only touches <= 256*(w-1)/(W-1) + 3 low-resolution cells: the two source rows of sim / logits1 / logits2 for
+// that cell range are staged in LDS once ([map][row][cell][CMAX]) and every per-pixel bilinear tap is an LDS
+// read instead of an L2 round trip (72 scattered loads per pixel before: 3.0 ms per B=32 step, 2 % of the HBM
+// roofline; the kernel is now bounded by its 56 B/pixel of soft-label / superpixel traffic).
 template <int CMAX>
-__device__ __forceinline__ void bilerp(const float* __restrict__ low, int C, int w, const Lerp& ly, const Lerp& lx,
-                                       float (&v)[CMAX]) {
-    // low: one image (h, w, C).  PyTorch order: ly.l0*(lx.l0*v00 + lx.l1*v01) + ly.l1*(lx.l0*v10 + lx.l1*v11)
-    const float* r0 = low + (size_t)ly.i0 * w * C;
-    const float* r1 = low + (size_t)ly.i1 * w * C;
+__device__ __forceinline__ void bilerp_lds(const float* __restrict__ r0, const float* __restrict__ r1, int C, int c0,
+                                           const Lerp& ly, const Lerp& lx, float (&v)[CMAX]) {
+    // same operation order as the global-memory form: ly.l0*(lx.l0*v00 + lx.l1*v01) + ly.l1*(lx.l0*v10 + lx.l1*v11)
+    const float* a0 = r0 + (lx.i0 - c0) * CMAX;
+    const float* a1 = r0 + (lx.i1 - c0) * CMAX;
+    const float* b0 = r1 + (lx.i0 - c0) * CMAX;
+    const float* b1 = r1 + (lx.i1 - c0) * CMAX;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-        if (c < C) {
-            float v00 = r0[lx.i0 * C + c], v01 = r0[lx.i1 * C + c];
-            float v10 = r1[lx.i0 * C + c], v11 = r1[lx.i1 * C + c];
-            v[c] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
-        }
-    }
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) v[c] = ly.l0 * (lx.l0 * a0[c] + lx.l1 * a1[c]) + ly.l1 * (lx.l0 * b0[c] + lx.l1 * b1[c]);
 }
 
 template <int CMAX>
 __global__ __launch_bounds__(256) void label_refine_kernel(
     const float* __restrict__ soft, const int64_t* __restrict__ sup, const float* __restrict__ sim,
     const float* __restrict__ lg1, const float* __restrict__ lg2, const uint32_t* __restrict__ seg,
-    const int64_t* __restrict__ ignore_id, float* __restrict__ out, uint32_t* __restrict__ plane_max, int C, int h,
-    int w, int H, int W, int S, float inv_temp, int mode) {
-    const int b = blockIdx.y;
+    const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C, int h,
+    int w, int H, int W, int S, float inv_temp, int mode, int ncell) {
+    extern __shared__ __attribute__((aligned(16))) float lowres[];       // [3 maps][2 rows][ncell][CMAX]
+    const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * 256;
     const size_t plane = (size_t)H * W;
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool active = p < plane;
+    const Lerp ly = lerp_setup(Y, h, H, true);
+    const int c0 = lerp_setup(X0, w, W, true).i0;                        // first cell of the strip
+    const int Xl = min(X0 + 255, W - 1);
+    const int c1 = lerp_setup(Xl, w, W, true).i1;                        // last cell of the strip
+    const int nc = c1 - c0 + 1;                                          // <= ncell by construction
+    {
+        const float* maps[3] = {sim, lg1, lg2};
+        const int per_map = 2 * ncell * CMAX;
+        for (int i = threadIdx.x; i < 3 * per_map; i += 256) {
+            const int m = i / per_map, r = i - m * per_map;
+            const int row = r / (ncell * CMAX), q = r - row * (ncell * CMAX);
+            const int cell = q / CMAX, c = q - cell * CMAX;
+            float v = 0.f;
+            if (maps[m] != nullptr && cell < nc && c < C)
+                v = maps[m][(((size_t)b * h + (row ? ly.i1 : ly.i0)) * w + (c0 + cell)) * C + c];
+            lowres[i] = v;
+        }
+    }
+    __syncthreads();
+    const float* s_sim0 = lowres;
+    const float* s_sim1 = lowres + ncell * CMAX;
+    const float* s_l10 = lowres + 2 * ncell * CMAX;
+    const float* s_l11 = lowres + 3 * ncell * CMAX;
+    const float* s_l20 = lowres + 4 * ncell * CMAX;
+    const float* s_l21 = lowres + 5 * ncell * CMAX;
+
+    const int X = X0 + threadIdx.x;
+    const bool active = X < W;
+    const size_t p = (size_t)Y * W + X;
     float o[CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) o[c] = 0.f;
     if (active) {
-        const int Y = (int)(p / W), X = (int)(p % W);
-        const Lerp ly = lerp_setup(Y, h, H, true), lx = lerp_setup(X, w, W, true);
+        const Lerp lx = lerp_setup(X, w, W, true);
         float wgt[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) wgt[c] = 0.f;
         if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_P) {          // prototype view
             float v[CMAX];
-            bilerp<CMAX>(sim + (size_t)b * h * w * C, C, w, ly, lx, v);
+            bilerp_lds<CMAX>(s_sim0, s_sim1, C, c0, ly, lx, v);
             softmax_maxnorm<CMAX>(v, C, 1.0f);
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) wgt[c] += v[c];
         }
         if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) {          // prediction view
             float v[CMAX];
-            bilerp<CMAX>(lg1 + (size_t)b * h * w * C, C, w, ly, lx, v);
+            bilerp_lds<CMAX>(s_l10, s_l11, C, c0, ly, lx, v);
             if (lg2 != nullptr) {
                 float u[CMAX];
-                bilerp<CMAX>(lg2 + (size_t)b * h * w * C, C, w, ly, lx, u);
+                bilerp_lds<CMAX>(s_l20, s_l21, C, c0, ly, lx, u);
                 // 0.5 * (softmax(x1/T) + softmax(x2/T)), then max-normalise
                 float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
@@ -341,35 +370,67 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] / d; out[((size_t)b * C + c) * plane + p] = o[c]; }
     }
-    // per-(b,c) running max for the selection pass (values are >= 0: uint order == float order)
+    // per-(b,c) maximum for the selection pass: block maximum -> blockmax[b][block][c]; a second tiny kernel
+    // reduces the blocks.  (One atomicMax per wave on the B*C result words serialised 0.8 M atomics on 192
+    // addresses and cost 3 ms: 95 % of this kernel.)
+    __shared__ float wmax[4][CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-        if (c < C) {
-            float m = wave_max(o[c]);
-            if ((threadIdx.x & 63) == 0) atomicMax(&plane_max[b * C + c], __float_as_uint(fmaxf(m, 0.f)));
-        }
+        const float m = wave_max(o[c]);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6][c] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < CMAX) {
+        const int c = threadIdx.x;
+        const float m = fmaxf(fmaxf(wmax[0][c], wmax[1][c]), fmaxf(wmax[2][c], wmax[3][c]));
+        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        blockmax[((size_t)b * gridDim.x * gridDim.y + blk) * CMAX + c] = fmaxf(m, 0.f);
     }
 }
+__global__ __launch_bounds__(256) void blockmax_reduce_kernel(const float* __restrict__ blockmax, uint32_t* __restrict__ plane_max,
+                                                              int nblk, int C, int cmax) {
+    // grid = (C, B): one block per result word
+    const int c = blockIdx.x, b = blockIdx.y;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) m = fmaxf(m, blockmax[((size_t)b * nblk + i) * cmax + c]);
+    __shared__ float red[4];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) plane_max[b * C + c] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
 
+extern "C" int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W) {
+    return (int64_t)B * uem_cdiv(W, 256) * H * (C <= 8 ? 8 : 16);
+}
 extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
                                 const float* logits2, const uint32_t* seg_keys, const int64_t* ignore_id,
-                                float* soft_out, uint32_t* plane_max, int B, int C, int h, int w, int H, int W,
-                                int S, float temp, int mode, void* stream) {
-    UEM_REQUIRE(soft && soft_out && plane_max, "label_refine: null pointer");
+                                float* soft_out, uint32_t* plane_max, float* workspace, int B, int C, int h, int w,
+                                int H, int W, int S, float temp, int mode, void* stream) {
+    UEM_REQUIRE(soft && soft_out && plane_max && workspace, "label_refine: null pointer");
     UEM_REQUIRE(mode >= 0 && mode <= 3, "label_refine: bad mode %d", mode);
-    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H > 0 && W > 0, "label_refine: bad shape");
+    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w && H <= 65535, "label_refine: bad shape");
     UEM_REQUIRE(temp > 0.f, "label_refine: temp must be > 0");
     if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_P) UEM_REQUIRE(sim, "label_refine: sim required");
     if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) UEM_REQUIRE(logits1, "label_refine: logits required");
     if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_S) UEM_REQUIRE(sup && seg_keys && ignore_id && S > 0, "label_refine: superpixel inputs required");
-    dim3 grid((unsigned)uem_cdiv((int64_t)H * W, 256), (unsigned)B);
+    // cells touched by a 256-pixel strip: floor(255*(w-1)/(W-1)) + 3 covers every alignment
+    const int ncell = (W > 1 ? (int)((255LL * (w - 1)) / (W - 1)) : 0) + 4;      // +1 slack for float rounding
+    const int cmax = C <= 8 ? 8 : 16;
+    const size_t lds = (size_t)6 * ncell * cmax * sizeof(float);
+    UEM_REQUIRE(lds <= 150 * 1024, "label_refine: low-resolution strip does not fit LDS");
+    dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)H, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 8)
-        label_refine_kernel<8><<<grid, 256, 0, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
-                                                     plane_max, C, h, w, H, W, S, 1.0f / temp, mode);
-    else
-        label_refine_kernel<16><<<grid, 256, 0, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
-                                                      plane_max, C, h, w, H, W, S, 1.0f / temp, mode);
+    if (C <= 8) {
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)label_refine_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        label_refine_kernel<8><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
+                                                       workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);
+    } else {
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)label_refine_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        label_refine_kernel<16><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
+                                                        workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);
+    }
+    blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(workspace, plane_max, (int)(grid.x * grid.y), C, cmax);
     return uem_check_launch("label_refine");
 }
 

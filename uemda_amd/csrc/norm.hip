@@ -267,17 +267,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ ws, int chunks, int C,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ acc_gamma, float* __restrict__ acc_beta) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float b = 0.f, g = 0.f;
     for (int j = lane; j < chunks; j += 64) { b += ws[(size_t)j * 2 * C + c]; g += ws[(size_t)j * 2 * C + C + c]; }
     b = wave_sum(b);
     g = wave_sum(g);
-    if (lane == 0) { dbeta[c] = b; dgamma[c] = g; }
+    if (lane == 0) {
+        dbeta[c] = b;
+        dgamma[c] = g;
+        // parameter-gradient accumulation (stream-ordered: the two graphs of a step run back to back)
+        if (acc_gamma) acc_gamma[c] += g;
+        if (acc_beta) acc_beta[c] += b;
+    }
 }
 extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                                  const float* save_mean, const float* save_invstd, int M, int C, int relu, float* dgamma,
-                                 float* dbeta, float* workspace, void* stream) {
+                                 float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
     UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce: null pointer");
     UEM_REQUIRE(M > 0 && col_shape_ok(C), "bn_bwd_reduce: unsupported shape M=%d C=%d", M, C);
     hipStream_t st = (hipStream_t)stream;
@@ -285,7 +292,7 @@ extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* y
     col_chunks(M, C, &chunks, &rpc);
     dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
     bn_bwd_partial_kernel<<<grid, 256, 0, st>>>(x, dy, ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
-    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta);
+    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta, grad_gamma, grad_beta);
     return uem_check_launch("bn_bwd_reduce");
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,

@@ -118,9 +118,10 @@ class Aligner:
             seg = torch.zeros((B, S, C), device=dev, dtype=torch.int32)
             call("uem_segment_max_planar", ptr(soft), ptr(sup), ptr(seg), B, C, H, W, S, stream())
         out = torch.empty_like(soft)
-        plane_max = torch.zeros((B, C), device=dev, dtype=torch.int32)
+        plane_max = torch.empty((B, C), device=dev, dtype=torch.int32)
+        ws = torch.empty(_lib.load().uem_label_refine_workspace_floats(B, C, H, W), device=dev, dtype=torch.float32)
         call("uem_label_refine", ptr(soft), ptr(sup), ptr(sim), ptr(lg1), ptr(lg2), ptr(seg), ptr(ign), ptr(out),
-             ptr(plane_max), B, C, h, w, H, W, S, float(temp), _MODES[mode], stream())
+             ptr(plane_max), ptr(ws), B, C, h, w, H, W, S, float(temp), _MODES[mode], stream())
         self._last_plane_max = plane_max
         return (out, plane_max) if return_plane_max else out
 

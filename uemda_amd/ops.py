@@ -234,12 +234,10 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None
         tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
         call("uem_bn_bwd_reduce", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
-             ptr(st.invstd), M, C, 1 if relu else 0, ptr(tmp[0]), ptr(tmp[1]), ptr(ws), stream())
+             ptr(st.invstd), M, C, 1 if relu else 0, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws),
+             stream())
         call("uem_bn_bwd_apply", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
              ptr(st.invstd), ptr(tmp[0]), ptr(tmp[1]), M, C, 1 if relu else 0, ptr(dx), ptr(dres), stream())
-        if gamma_grad is not None:
-            call("uem_add_inplace", ptr(gamma_grad), ptr(tmp[0]), C, stream())
-            call("uem_add_inplace", ptr(beta_grad), ptr(tmp[1]), C, stream())
     else:
         # frozen statistics (eval-mode BN inside a graph): dx = dp * scale; dgamma/dbeta via the reduce
         raise UemError("backward through eval-mode BatchNorm is not supported (reference never does it)")
