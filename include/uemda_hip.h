@@ -56,6 +56,11 @@ typedef struct {
  * which is expressed as KH=7, KW=1, Cin=32 over an NHWC4 image (see uem_stem_pack_*).             */
 int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
                    const float* in_shift, float* y, const uem_conv_shape* s, int flags, void* stream);
+/* same forward conv, and the epilogue also leaves the per-128-row-tile column sums of y and y*y in
+ * tile_stats[M/128][2][Cout] (fused BatchNorm statistics: saves the stand-alone pass over y).  Needs
+ * M % 128 == 0 and Cout % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise: use uem_bn_stats).                   */
+int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift, float* y,
+                         const uem_conv_shape* s, int flags, float* tile_stats, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
 /* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */
@@ -87,6 +92,10 @@ int uem_bn_stats(const float* x, int M, int C, int ld, const float* gamma, const
                  float* save_mean, float* save_invstd, float* scale, float* shift,
                  float* workspace /* >= uem_bn_workspace_floats(M, C) floats */, void* stream);
 int64_t uem_bn_workspace_floats(int M, int C); /* also covers uem_bn_bwd_reduce's workspace */
+/* the same outputs from uem_conv2d_fwd_stats' tile sums (tiles = M/128)                              */
+int uem_bn_stats_from_tiles(const float* tile_stats, int tiles, int M, int C, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                            float* save_invstd, float* scale, float* shift, void* stream);
 int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
 /* y = act(x*scale + shift (+ r)); r = res, or res*res_scale + res_shift (downsample branch BN) when

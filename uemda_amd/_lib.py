@@ -32,6 +32,7 @@ SIGNATURES = {
     "uem_version": [],
     "uem_last_error": [],
     "uem_conv2d_fwd": [P, P, P, P, P, P, POINTER(ConvShape), I, P],
+    "uem_conv2d_fwd_stats": [P, P, P, P, P, POINTER(ConvShape), I, P, P],
     "uem_conv2d_stem_fwd": [P, P, P, I, I, I, P],
     "uem_conv2d_wgrad": [P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_stem_wgrad": [P, P, P, I, I, I, P],
@@ -44,6 +45,7 @@ SIGNATURES = {
     "uem_aspp_gather_bwd": [P, P, I, I, I, I, I, I, POINTER(c_int), P],
     "uem_bn_stats": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P, P],
     "uem_bn_workspace_floats": [I, I],
+    "uem_bn_stats_from_tiles": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P],
     "uem_bn_eval_affine": [P, P, P, P, F, P, P, I, P],
     "uem_affine_act": [P, P, P, P, P, P, P, L, I, I, P],
     "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],

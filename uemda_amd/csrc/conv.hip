@@ -34,6 +34,7 @@ struct ConvP {
     int x_ld, y_ld;
     int accumulate;
     int relu;
+    float* tile_stats;     // optional [tiles_m][2][Cout]: per-128-row-tile column sums of y and y*y (fused BN statistics)
     // strided data-gradient only: one launch per output-parity class (py, px); rows enumerate the pixels
     // (sub*yy + py, sub*xx + px) and only the taps that can reach that class are walked.
     int sub, py, px, Hs, Ws;          // sub == 1: dense rows (every other use)
@@ -229,18 +230,58 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------
     const bool dense_rows = !(MODE == 1 && p.sub > 1);
-    if (dense_rows && !p.accumulate && m0 + BM <= p.M && n0 + BN <= p.Cout) {
-        // full tile: 16*MT*NT unconditional stores per lane, addresses by constant strides
+    if (dense_rows && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        // Full tile: the accumulators go through LDS (the operand stages are dead now) in two 64-row halves and
+        // leave as 16-byte stores, 32 lanes per 512-B row segment.  (64 dword stores per lane made the epilogue
+        // store-issue bound on the small-K layers.)  The staged half is also where the fused BatchNorm statistics
+        // (column sums of y and y*y over the tile) are taken: consecutive threads on consecutive banks.
+        constexpr int LDW = BN + 4;                     // staged row stride (floats), keeps 16-B alignment
+        constexpr int TPR = BN / 4;                     // threads per staged row
+        constexpr int RPP = 256 / TPR;                  // rows per store pass
+        float* const stg = smem;                        // 64 x LDW floats <= the A+B stages
+        const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv4 = *reinterpret_cast<const float4*>(p.bias + n0 + sc4);
+        float cs1 = 0.f, cs2 = 0.f;                     // column tid of the tile (threads < BN)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wn + j * 32 + fr;
-            const float bv = p.bias ? p.bias[n] : 0.f;
+        for (int hm = 0; hm < 2; ++hm) {
+            if (wm / 64 == hm) {
+                const int rbase = wm % 64;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                float* base = p.y + (size_t)(m0 + wm + i * 32 + 4 * fh) * p.y_ld + n;
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) base[(size_t)((r & 3) + 8 * (r >> 2)) * p.y_ld] = acc[i][j][r] + bv;
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
             }
+            __syncthreads();
+#pragma unroll
+            for (int rp = 0; rp < 64 / RPP; ++rp) {
+                const int row = srow + rp * RPP;
+                float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                float* dst = p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4;
+                if (p.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(dst);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(dst) = v;
+            }
+            if (p.tile_stats != nullptr && tid < BN) {
+#pragma unroll 8
+                for (int row = 0; row < 64; ++row) {
+                    const float v = stg[row * LDW + tid];
+                    cs1 += v;
+                    cs2 += v * v;
+                }
+            }
+            __syncthreads();
+        }
+        if (p.tile_stats != nullptr && tid < BN) {
+            float* ts = p.tile_stats + (size_t)(m0 / BM) * 2 * p.Cout + n0 + tid;
+            ts[0] = cs1;
+            ts[p.Cout] = cs2;
         }
         return;
     }
@@ -321,8 +362,25 @@ static int conv_launch(const ConvP& p, bool affine, hipStream_t st) {
     return uem_check_launch("conv2d");
 }
 
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* in_scale,
+                           const float* in_shift, float* y, const uem_conv_shape* s, int flags, float* tile_stats,
+                           void* stream);
+
 extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
                               const float* in_shift, float* y, const uem_conv_shape* s, int flags, void* stream) {
+    return conv2d_fwd_impl(x, w, bias, in_scale, in_shift, y, s, flags, nullptr, stream);
+}
+extern "C" int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift,
+                                    float* y, const uem_conv_shape* s, int flags, float* tile_stats, void* stream) {
+    UEM_REQUIRE(tile_stats && s, "conv2d_fwd_stats: null pointer");
+    if ((flags & (UEM_CONV_TRANSPOSED | UEM_CONV_ACCUMULATE)) || ((int64_t)s->N * s->Ho * s->Wo) % 128 != 0 || s->Cout % 64 != 0)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_fwd_stats: needs a forward conv with M %% 128 == 0 and Cout %% 64 == 0");
+    return conv2d_fwd_impl(x, w, nullptr, in_scale, in_shift, y, s, flags, tile_stats, stream);
+}
+
+static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* in_scale,
+                           const float* in_shift, float* y, const uem_conv_shape* s, int flags, float* tile_stats,
+                           void* stream) {
     UEM_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     int rc = conv_check(s);
     if (rc) return rc;
@@ -336,6 +394,7 @@ extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias,
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0;
     p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0;
+    p.tile_stats = tile_stats;
     if (!transposed) {
         UEM_REQUIRE(s->Cin % BK == 0, "conv2d_fwd: Cin=%d must be a multiple of 32", s->Cin);
         p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
@@ -383,7 +442,7 @@ extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, i
     p.N = N; p.H = H; p.W = W; p.Cin = 32;               // one tap row = 8 px x 4 ch
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
-    p.accumulate = 0; p.relu = 0;
+    p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0;
     p.M = N * p.Ho * p.Wo;
     return conv_launch<2>(p, false, (hipStream_t)stream);

@@ -147,6 +147,61 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
     }
 }
+// statistics from the conv epilogue's per-tile column sums: tile_stats[tile][0][c] = sum y, [tile][1][c] = sum y*y
+// over the tile's `rows` rows; tiles are merged with the same Chan combination as the stand-alone path
+__global__ __launch_bounds__(64) void bn_stats_tiles_finalize_kernel(const float* __restrict__ ts, int tiles, int rows, int M, int C,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float eps, float momentum, float* __restrict__ rmean,
+                                                                     float* __restrict__ rvar, float* __restrict__ smean,
+                                                                     float* __restrict__ sinv, float* __restrict__ scale,
+                                                                     float* __restrict__ shift) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float nb = (float)rows;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int j = lane; j < tiles; j += 64) {
+        const float s1 = ts[(size_t)j * 2 * C + c], s2 = ts[(size_t)j * 2 * C + C + c];
+        const float mb = s1 / nb;
+        const float qb = fmaxf(s2 - s1 * mb, 0.f);
+        if (n == 0.f) { n = nb; mean = mb; m2 = qb; }
+        else chan_merge(n, mean, m2, nb, mb, qb);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float nb2 = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+        const float nt = n + nb2;
+        if (nt > 0.f) {
+            const float delta = mb - mean;
+            const float mnew = (n * mean + nb2 * mb) / nt;
+            m2 = m2 + qb + delta * delta * (n * nb2 / nt);
+            mean = mnew;
+        }
+        n = nt;
+    }
+    if (lane != 0) return;
+    const float var = m2 / (float)M;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    if (smean) smean[c] = mean;
+    if (sinv) sinv[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - mean * sc;
+    if (rmean) {
+        const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+    }
+}
+extern "C" int uem_bn_stats_from_tiles(const float* tile_stats, int tiles, int M, int C, const float* gamma, const float* beta,
+                                       float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
+                                       float* save_invstd, float* scale, float* shift, void* stream) {
+    UEM_REQUIRE(tile_stats && scale && shift && tiles > 0 && M == tiles * 128 && C > 0, "bn_stats_from_tiles: bad arguments");
+    UEM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats_from_tiles: running stats must come in pairs");
+    bn_stats_tiles_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(tile_stats, tiles, 128, M, C, gamma, beta, eps, momentum,
+                                                                      running_mean, running_var, save_mean, save_invstd, scale, shift);
+    return uem_check_launch("bn_stats_from_tiles");
+}
+
 extern "C" int uem_bn_stats(const float* x, int M, int C, int ld, const float* gamma, const float* beta, float eps,
                             float momentum, float* running_mean, float* running_var, float* save_mean,
                             float* save_invstd, float* scale, float* shift, float* workspace, void* stream) {

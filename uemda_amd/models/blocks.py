@@ -95,16 +95,13 @@ class BottleneckFn(Function):
     def forward(ctx, x, blk, *params):
         W = ops.weight_ohwi
         s, d = blk.stride, blk.dilation
-        z1 = ops.conv2d(x, W(blk.conv1.weight))
-        st1 = _BN.stats(z1, blk.bn1)
-        z2 = ops.conv2d(z1, W(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
-        st2 = _BN.stats(z2, blk.bn2)
-        z3 = ops.conv2d(z2, W(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
-        st3 = _BN.stats(z3, blk.bn3)
+        z1, st1 = ops.conv2d_bn(x, W(blk.conv1.weight), blk.bn1)
+        z2, st2 = ops.conv2d_bn(z1, W(blk.conv2.weight), blk.bn2, stride=s, pad=d, dil=d, in_scale=st1.scale,
+                                in_shift=st1.shift, in_relu=True)
+        z3, st3 = ops.conv2d_bn(z2, W(blk.conv3.weight), blk.bn3, in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
         has_ds = blk.downsample is not None
         if has_ds:
-            zd = ops.conv2d(x, W(blk.downsample[0].weight), stride=s)
-            std = _BN.stats(zd, blk.downsample[1])
+            zd, std = ops.conv2d_bn(x, W(blk.downsample[0].weight), blk.downsample[1], stride=s)
             y = ops.affine_act(z3, st3, res=zd, res_st=std, relu=True)
         else:
             zd, std = None, None

@@ -112,6 +112,37 @@ def conv2d(x, w_ohwi, bias=None, stride=1, pad=0, dil=1, in_scale=None, in_shift
     return out
 
 
+def conv2d_bn(x, w_ohwi, bn, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False):
+    """conv followed by training-mode BatchNorm statistics.  When the GEMM tiles are full (M % 128 == 0,
+    Cout % 64 == 0) the statistics come out of the conv epilogue (no extra pass over y); otherwise, and in eval
+    mode, this is conv2d + bn_stats.  Returns (y, BNState)."""
+    training = bn.training or bn.running_mean is None
+    cout, kh, kw, cin = w_ohwi.shape
+    s = _shape(x, cout, kh, kw, stride, pad, dil)
+    M = s.N * s.Ho * s.Wo
+    if not training or M % 128 != 0 or cout % 64 != 0:
+        y = conv2d(x, w_ohwi, None, stride, pad, dil, in_scale, in_shift, in_relu)
+        return y, bn_stats(y, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training, bn.eps,
+                           bn.momentum if bn.momentum is not None else 0.1)
+    need_gpu(x, w_ohwi)
+    _f32c(x, "conv2d x"), _f32c(w_ohwi, "conv2d w")
+    y = torch.empty((s.N, s.Ho, s.Wo, cout), device=x.device, dtype=torch.float32)
+    tiles = M // 128
+    ts = torch.empty((tiles, 2, cout), device=x.device, dtype=torch.float32)
+    flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0)
+    flops = 2.0 * M * cout * kh * kw * cin
+    PROF.run("conv_fwd", flops, lambda: call("uem_conv2d_fwd_stats", ptr(x), ptr(w_ohwi), ptr(in_scale), ptr(in_shift),
+                                             ptr(y), ctypes.byref(s), flags, ptr(ts), stream()))
+    st = BNState()
+    st.training = True
+    buf = torch.empty((4, cout), device=x.device, dtype=torch.float32)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    call("uem_bn_stats_from_tiles", ptr(ts), tiles, M, cout, ptr(bn.weight.detach()), ptr(bn.bias.detach()), float(bn.eps),
+         float(bn.momentum if bn.momentum is not None else 0.1), ptr(bn.running_mean), ptr(bn.running_var),
+         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream())
+    return y, st
+
+
 def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=False, algo_cout=None):
     """dx (N,H,W,Cin) from dy (N,Ho,Wo,Cout); w_t = weight_transpose(w) of shape (Cin,KH,KW,Cout)."""
     need_gpu(dy, w_t)
