@@ -61,6 +61,12 @@ int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const floa
  * M % 128 == 0 and Cout % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise: use uem_bn_stats).                   */
 int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift, float* y,
                          const uem_conv_shape* s, int flags, float* tile_stats, void* stream);
+/* data gradient of a stride-1 conv (dx = dA of the producing layer) whose epilogue also computes the first pass
+ * of that layer's BatchNorm+ReLU backward: with bn_z = the layer's raw conv output (N,H,W,Cin) and bn_vec =
+ * (4,Cin) [scale, shift, mean, invstd], tile_partials[M/128][2][Cin] receives per-tile sums of dp = dA*[relu mask]
+ * and dp*xhat (replaces uem_bn_bwd_reduce's pass over z and dA).  s describes the FORWARD conv.          */
+int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* bn_z,
+                           const float* bn_vec, float* tile_partials, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
 /* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */
@@ -111,6 +117,8 @@ int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const
                       const float* save_mean, const float* save_invstd, int M, int C, int relu,
                       float* dgamma /* = */, float* dbeta /* = */, float* grad_gamma /* +=, may be NULL */,
                       float* grad_beta /* +=, may be NULL */, float* workspace, void* stream);
+int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* dgamma /* = */, float* dbeta /* = */,
+                          float* grad_gamma /* += or NULL */, float* grad_beta /* += or NULL */, void* stream);
 int uem_bn_bwd_apply(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "uem_last_error": [],
     "uem_conv2d_fwd": [P, P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_fwd_stats": [P, P, P, P, P, POINTER(ConvShape), I, P, P],
+    "uem_conv2d_dgrad_bnbwd": [P, P, P, POINTER(ConvShape), P, P, P, P],
     "uem_conv2d_stem_fwd": [P, P, P, I, I, I, P],
     "uem_conv2d_wgrad": [P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_stem_wgrad": [P, P, P, I, I, I, P],
@@ -49,6 +50,7 @@ SIGNATURES = {
     "uem_bn_eval_affine": [P, P, P, P, F, P, P, I, P],
     "uem_affine_act": [P, P, P, P, P, P, P, L, I, I, P],
     "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
+    "uem_bn_bwd_from_tiles": [P, I, I, P, P, P, P, P],
     "uem_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, P, P, P],
     "uem_affine_act_bwd": [P, P, P, P, P, L, I, I, P, P, P],
     "uem_maxpool3x3s2_fwd": [P, P, P, I, I, I, I, P],

@@ -35,6 +35,12 @@ struct ConvP {
     int accumulate;
     int relu;
     float* tile_stats;     // optional [tiles_m][2][Cout]: per-128-row-tile column sums of y and y*y (fused BN statistics)
+    // data-gradient only: fused first pass of the BatchNorm(+ReLU) backward of the layer this gradient feeds.
+    // y here is dA (grad wrt the post-ReLU activation); with z = that layer's raw conv output the epilogue also
+    // leaves per-tile column sums of dp = dA*[z*sc+sh > 0] and dp*xhat in tile_bnbwd[tiles_m][2][Cout].
+    const float* bn_z;
+    const float* bn_vec;   // (4, Cout): scale, shift, mean, invstd
+    float* tile_bnbwd;
     // strided data-gradient only: one launch per output-parity class (py, px); rows enumerate the pixels
     // (sub*yy + py, sub*xx + px) and only the taps that can reach that class are walked.
     int sub, py, px, Hs, Ws;          // sub == 1: dense rows (every other use)
@@ -243,6 +249,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) bv4 = *reinterpret_cast<const float4*>(p.bias + n0 + sc4);
         float cs1 = 0.f, cs2 = 0.f;                     // column tid of the tile (threads < BN)
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;   // fused BN-backward partials (MODE 1)
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm) {
             if (wm / 64 == hm) {
@@ -268,6 +275,24 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
                 }
                 *reinterpret_cast<float4*>(dst) = v;
             }
+            if (MODE == 1 && p.tile_bnbwd != nullptr) {
+                // each thread owns 4 columns x (64/RPP) rows of this half: accumulate dbeta / dgamma partials
+                const float4 sc = *reinterpret_cast<const float4*>(p.bn_vec + n0 + sc4);
+                const float4 sh = *reinterpret_cast<const float4*>(p.bn_vec + p.Cout + n0 + sc4);
+                const float4 mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.Cout + n0 + sc4);
+                const float4 is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.Cout + n0 + sc4);
+#pragma unroll
+                for (int rp = 0; rp < 64 / RPP; ++rp) {
+                    const int row = srow + rp * RPP;
+                    const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                    const float4 z = *reinterpret_cast<const float4*>(p.bn_z + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4);
+                    const float dx_ = (z.x * sc.x + sh.x > 0.f) ? d.x : 0.f, dy_ = (z.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+                    const float dz_ = (z.z * sc.z + sh.z > 0.f) ? d.z : 0.f, dw_ = (z.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+                    bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
+                    bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
+                    bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
+                }
+            }
             if (p.tile_stats != nullptr && tid < BN) {
 #pragma unroll 8
                 for (int row = 0; row < 64; ++row) {
@@ -282,6 +307,21 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
             float* ts = p.tile_stats + (size_t)(m0 / BM) * 2 * p.Cout + n0 + tid;
             ts[0] = cs1;
             ts[p.Cout] = cs2;
+        }
+        if (MODE == 1 && p.tile_bnbwd != nullptr) {
+            // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again)
+            float* red = stg;                           // [2][RPP][BN]
+            *reinterpret_cast<float4*>(&red[(0 * RPP + srow) * BN + sc4]) = bb;
+            *reinterpret_cast<float4*>(&red[(1 * RPP + srow) * BN + sc4]) = bg;
+            __syncthreads();
+            if (tid < BN) {
+                float b = 0.f, g = 0.f;
+#pragma unroll
+                for (int q = 0; q < RPP; ++q) { b += red[(0 * RPP + q) * BN + tid]; g += red[(1 * RPP + q) * BN + tid]; }
+                float* tb = p.tile_bnbwd + (size_t)(m0 / BM) * 2 * p.Cout + n0 + tid;
+                tb[0] = b;
+                tb[p.Cout] = g;
+            }
         }
         return;
     }
@@ -362,25 +402,34 @@ static int conv_launch(const ConvP& p, bool affine, hipStream_t st) {
     return uem_check_launch("conv2d");
 }
 
+struct BnBwdFuse { const float* z; const float* vec; float* tiles; };
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* in_scale,
                            const float* in_shift, float* y, const uem_conv_shape* s, int flags, float* tile_stats,
-                           void* stream);
+                           const BnBwdFuse* bnbwd, void* stream);
 
 extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
                               const float* in_shift, float* y, const uem_conv_shape* s, int flags, void* stream) {
-    return conv2d_fwd_impl(x, w, bias, in_scale, in_shift, y, s, flags, nullptr, stream);
+    return conv2d_fwd_impl(x, w, bias, in_scale, in_shift, y, s, flags, nullptr, nullptr, stream);
+}
+extern "C" int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* bn_z,
+                                      const float* bn_vec, float* tile_partials, void* stream) {
+    UEM_REQUIRE(bn_z && bn_vec && tile_partials && s, "conv2d_dgrad_bnbwd: null pointer");
+    if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_bnbwd: needs stride 1, M %% 128 == 0, Cin %% 64 == 0");
+    BnBwdFuse f{bn_z, bn_vec, tile_partials};
+    return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED, nullptr, &f, stream);
 }
 extern "C" int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift,
                                     float* y, const uem_conv_shape* s, int flags, float* tile_stats, void* stream) {
     UEM_REQUIRE(tile_stats && s, "conv2d_fwd_stats: null pointer");
     if ((flags & (UEM_CONV_TRANSPOSED | UEM_CONV_ACCUMULATE)) || ((int64_t)s->N * s->Ho * s->Wo) % 128 != 0 || s->Cout % 64 != 0)
         return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_fwd_stats: needs a forward conv with M %% 128 == 0 and Cout %% 64 == 0");
-    return conv2d_fwd_impl(x, w, nullptr, in_scale, in_shift, y, s, flags, tile_stats, stream);
+    return conv2d_fwd_impl(x, w, nullptr, in_scale, in_shift, y, s, flags, tile_stats, nullptr, stream);
 }
 
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* in_scale,
                            const float* in_shift, float* y, const uem_conv_shape* s, int flags, float* tile_stats,
-                           void* stream) {
+                           const BnBwdFuse* bnbwd, void* stream) {
     UEM_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     int rc = conv_check(s);
     if (rc) return rc;
@@ -395,6 +444,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0;
     p.tile_stats = tile_stats;
+    p.bn_z = bnbwd ? bnbwd->z : nullptr; p.bn_vec = bnbwd ? bnbwd->vec : nullptr; p.tile_bnbwd = bnbwd ? bnbwd->tiles : nullptr;
     if (!transposed) {
         UEM_REQUIRE(s->Cin % BK == 0, "conv2d_fwd: Cin=%d must be a multiple of 32", s->Cin);
         p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
@@ -442,7 +492,7 @@ extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, i
     p.N = N; p.H = H; p.W = W; p.Cin = 32;               // one tap row = 8 px x 4 ch
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
-    p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr;
+    p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0;
     p.M = N * p.Ho * p.Wo;
     return conv_launch<2>(p, false, (hipStream_t)stream);

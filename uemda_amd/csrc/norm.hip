@@ -337,6 +337,28 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
         if (acc_beta) acc_beta[c] += b;
     }
 }
+// dgamma / dbeta from the data-gradient epilogue's per-tile partials: tiles[tile][0][c] = sum dp, [tile][1][c] = sum dp*xhat
+__global__ __launch_bounds__(64) void bn_bwd_tiles_finalize_kernel(const float* __restrict__ tp, int tiles, int C,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   float* __restrict__ acc_gamma, float* __restrict__ acc_beta) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float b = 0.f, g = 0.f;
+    for (int j = lane; j < tiles; j += 64) { b += tp[(size_t)j * 2 * C + c]; g += tp[(size_t)j * 2 * C + C + c]; }
+    b = wave_sum(b);
+    g = wave_sum(g);
+    if (lane == 0) {
+        dbeta[c] = b;
+        dgamma[c] = g;
+        if (acc_gamma) acc_gamma[c] += g;
+        if (acc_beta) acc_beta[c] += b;
+    }
+}
+extern "C" int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* dgamma, float* dbeta, float* grad_gamma,
+                                     float* grad_beta, void* stream) {
+    UEM_REQUIRE(tile_partials && dgamma && dbeta && tiles > 0 && C > 0, "bn_bwd_from_tiles: bad arguments");
+    bn_bwd_tiles_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(tile_partials, tiles, C, dgamma, dbeta, grad_gamma, grad_beta);
+    return uem_check_launch("bn_bwd_from_tiles");
+}
 extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                                  const float* save_mean, const float* save_invstd, int M, int C, int relu, float* dgamma,
                                  float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {

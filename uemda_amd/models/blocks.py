@@ -131,13 +131,13 @@ class BottleneckFn(Function):
         dp = torch.empty_like(dy)
         dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), ymask=y, relu=True, dres=dp)
         ops.conv2d_wgrad(z2, dz3, G(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
-        da2 = ops.conv2d_dgrad(dz3, ops.weight_transpose(W(blk.conv3.weight)), z2.shape)
+        dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose(W(blk.conv3.weight)), z2, st2, gb(blk.bn2.weight),
+                                           gb(blk.bn2.bias))
         del dz3
-        dz2 = ops.bn_backward(z2, da2, st2, gb(blk.bn2.weight), gb(blk.bn2.bias), None, True, dx=da2)
         ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
-        da1 = ops.conv2d_dgrad(dz2, ops.weight_transpose(W(blk.conv2.weight)), z1.shape, stride=s, pad=d, dil=d)
-        del dz2, da2
-        dz1 = ops.bn_backward(z1, da1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), None, True, dx=da1)
+        dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose(W(blk.conv2.weight)), z1, st1, gb(blk.bn1.weight),
+                                           gb(blk.bn1.bias), stride=s, pad=d, dil=d)
+        del dz2
         ops.conv2d_wgrad(x, dz1, G(blk.conv1.weight))
         wt1 = ops.weight_transpose(W(blk.conv1.weight))
         if ctx.has_ds:

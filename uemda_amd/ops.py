@@ -10,8 +10,13 @@ import torch
 from . import _lib
 from ._lib import CONV_ACCUMULATE, CONV_IN_AFFINE, CONV_IN_RELU, CONV_TRANSPOSED, ConvShape, UemError, call
 
+import os
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# epilogue fusions (on by default; the switches exist for A/B measurements)
+FUSE_BN_STATS = os.environ.get("UEM_FUSE_BN_STATS", "1") != "0"
+FUSE_BN_BACKWARD = os.environ.get("UEM_FUSE_BN_BACKWARD", "1") != "0"
 
 
 def stream():
@@ -120,7 +125,7 @@ def conv2d_bn(x, w_ohwi, bn, stride=1, pad=0, dil=1, in_scale=None, in_shift=Non
     cout, kh, kw, cin = w_ohwi.shape
     s = _shape(x, cout, kh, kw, stride, pad, dil)
     M = s.N * s.Ho * s.Wo
-    if not training or M % 128 != 0 or cout % 64 != 0:
+    if not training or M % 128 != 0 or cout % 64 != 0 or not FUSE_BN_STATS:
         y = conv2d(x, w_ohwi, None, stride, pad, dil, in_scale, in_shift, in_relu)
         return y, bn_stats(y, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training, bn.eps,
                            bn.momentum if bn.momentum is not None else 0.1)
@@ -161,6 +166,39 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_fwd", ptr(dy), ptr(w_t), None, None, None, ptr(out),
                                                ctypes.byref(s), flags, stream()))
     return out
+
+
+def conv2d_dgrad_bn_backward(dy, w_t, z, st, gamma_grad, beta_grad, stride=1, pad=0, dil=1):
+    """dA = dgrad(dy) for the conv that consumed relu(bn(z)), then the BatchNorm+ReLU backward of that bn:
+    returns dz (in dA's buffer).  When the tiles are full and the conv has stride 1, the reduction pass of the
+    BN backward (sum dp, sum dp*xhat) runs inside the data-gradient epilogue."""
+    cin, kh, kw, cout = w_t.shape
+    n, h, w, _ = z.shape
+    M = n * h * w
+    if stride != 1 or M % 128 != 0 or cin % 64 != 0 or not st.training or not FUSE_BN_BACKWARD:
+        da = conv2d_dgrad(dy, w_t, z.shape, stride=stride, pad=pad, dil=dil)
+        return bn_backward(z, da, st, gamma_grad, beta_grad, None, True, dx=da)
+    need_gpu(dy, w_t, z)
+    _f32c(dy, "dgrad dy"), _f32c(w_t, "dgrad w_t"), _f32c(z, "dgrad z")
+    s = ConvShape()
+    s.N, s.H, s.W, s.Cin = n, h, w, cin
+    s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], cout
+    s.KH, s.KW, s.stride, s.pad, s.dil = kh, kw, stride, pad, dil
+    s.x_ld, s.y_ld = cin, cout
+    da = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
+    tiles = M // 128
+    tp = torch.empty((tiles, 2, cin), device=dy.device, dtype=torch.float32)
+    vec = st.scale._base if st.scale._base is not None else None
+    if vec is None or vec.shape != (4, cin):
+        raise UemError("conv2d_dgrad_bn_backward: BNState vectors must live in one (4, C) buffer")
+    flops = 2.0 * n * dy.shape[1] * dy.shape[2] * cout * kh * kw * cin
+    PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_dgrad_bnbwd", ptr(dy), ptr(w_t), ptr(da), ctypes.byref(s), ptr(z),
+                                               ptr(vec), ptr(tp), stream()))
+    tmp = torch.empty((2, cin), device=dy.device, dtype=torch.float32)
+    call("uem_bn_bwd_from_tiles", ptr(tp), tiles, cin, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
+    call("uem_bn_bwd_apply", ptr(z), ptr(da), None, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         ptr(tmp[0]), ptr(tmp[1]), M, cin, 1, ptr(da), None, stream())
+    return da
 
 
 def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
