@@ -240,6 +240,22 @@ int uem_argmax_confusion(const float* prob, const int64_t* gt, int64_t* pred, in
 /* prototypes = sums / (counts + 1e-7)   (Aligner.init_avg, alignment.py:121-122)                       */
 int uem_proto_mean(const float* sums, const float* counts, float* protos, int k, int C, void* stream);
 
+/* ---- stage-2 alignment losses, forward + backward fused ----------------------------------------
+ * PrototypeContrastiveLoss (uemda/loss.py:10-47): rows with label == ignore are dropped; feat (n,k) and the
+ * prototypes (C,k) are L2-normalised (eps 1e-12), logits = feat.Proto^T / temperature, loss = mean CE.
+ * dfeat (n,k) receives d loss / d feat (zero rows for ignored labels).                                     */
+int uem_pcl_loss(const float* protos, const float* feat, const int64_t* labels, float* loss_out /* [1] */, float* dfeat,
+                 float* workspace /* uem_pcl_workspace_floats(k, C) */, int n, int k, int C, float temperature,
+                 int64_t ignore_label, void* stream);
+int64_t uem_pcl_workspace_floats(int k, int C);
+/* CoralLoss (uemda/gast/coral.py:15-47).  gram_* = X^T X (d x d, from uem_conv2d_wgrad with x = dy = the (n,d)
+ * features), mean_* = column means.  Outputs the loss and the two pre-scaled symmetric matrices of the backward:
+ * d source = (source - mean_s) . g_s,  d target = (target - mean_t) . g_t  (1x1 uem_conv2d_fwd with the affine
+ * prologue scale = 1, shift = -mean).                                                                       */
+int uem_coral_finish(const float* gram_s, const float* gram_t, const float* mean_s, const float* mean_t, int ns, int nt,
+                     int d, float* g_s, float* g_t, float* loss_out, float* partial /* >= 1024 floats */, void* stream);
+int uem_negate(const float* a, float* b, int n, void* stream);
+
 /* ---- optimizer: clip_grad_norm_(max_norm, L2) + SGD(momentum, weight_decay) over a flat arena ----------
  * train_ssl_uem.py:169-170,228-232.  sqnorm: partial sums (>= UEM_NORM_BLOCKS floats) -> norm_out[0].  */
 #define UEM_NORM_BLOCKS 1024

@@ -210,6 +210,27 @@ def loss_calc_uvem(preds, hard, soft, m=0.2, t=0.7, gamma=4.0, ignore_label=-1, 
     return total / len(preds)
 
 
+def pcl_loss(protos, feat, labels, temperature=8.0, ignore_label=-1):
+    """PrototypeContrastiveLoss.forward (uemda/loss.py:18-47)."""
+    if feat.dim() != 2:
+        feat = feat.permute(0, 2, 3, 1).reshape(-1, feat.size(1))
+    labels = labels.reshape(-1)
+    mask = labels != ignore_label
+    f = F.normalize(feat[mask], p=2, dim=1)
+    p = F.normalize(protos, p=2, dim=1)
+    return F.cross_entropy(f @ p.t() / temperature, labels[mask])
+
+
+def coral_loss(source, target):
+    """CoralLoss.forward (uemda/gast/coral.py:27-47)."""
+    d = source.shape[1]
+    xm = source.mean(0, keepdim=True) - source
+    xc = xm.t() @ xm / (source.shape[0] - 1)
+    xmt = target.mean(0, keepdim=True) - target
+    xct = xmt.t() @ xmt / (target.shape[0] - 1)
+    return ((xc - xct) ** 2).sum() / (4 * d * d)
+
+
 class ClassBalance:
     """balance.py:15-78 restated (EMA of class frequency -> per-pixel weight)."""
 

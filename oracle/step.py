@@ -81,3 +81,36 @@ def src_step(model, opt, batch, lr, hp=HYPER, dropout=False):
     gnorm = opt.clip_grad_norm(hp["max_norm"])
     opt.step(lr)
     return dict(loss_source=loss.detach(), grad_norm=gnorm, pred_s1=ps1.detach(), pred_s2=ps2.detach())
+
+
+def align_step(model, opt, prototypes, batch, lr, hp=HYPER, n_classes=6, align_domain=True, pcl_temp=8.0):
+    """One stage-2 iteration: reference tools/train_align_uem.py:139-183."""
+    import torch.nn.functional as F
+    model.train()
+    ps1, ps2, feat_s = model(batch["images_s"])
+    with torch.no_grad():
+        new_protos, label_s_down = gast.update_prototype(feat_s.detach(), batch["label_s"], prototypes, n_classes,
+                                                         hp["proto_decay"], hp["ignore_label"])
+    pt1, pt2, feat_t = model(batch["images_t"])
+    with torch.no_grad():
+        size = batch["images_t"].shape[-2:]
+        x1 = F.interpolate(pt1, size, mode="bilinear", align_corners=True)
+        x2 = F.interpolate(pt2, size, mode="bilinear", align_corners=True)
+        soft = (x1.softmax(1) + x2.softmax(1)) * 0.5
+        soft = gast.label_refine(batch["label_t_sup"], feat_t.detach(), [pt1.detach(), pt2.detach()], soft, new_protos,
+                                 True, hp["refine_mode"], hp["refine_temp"])
+        hard = gast.pseudo_selection(soft, hp["cutoff_top"], hp["cutoff_low"], hp["ignore_label"])
+        label_t = gast.downscale_label(hard, n_classes, 16, hp["ignore_label"], 0.75)
+    loss_seg = gast.loss_calc([ps1, ps2], batch["label_s"], hp["ignore_label"])
+    k = feat_s.shape[1]
+    loss_domain = gast.coral_loss(feat_s.permute(0, 2, 3, 1).reshape(-1, k), feat_t.permute(0, 2, 3, 1).reshape(-1, k)) \
+        if align_domain else 0.0
+    loss_align = 0.5 * (gast.pcl_loss(new_protos, feat_s, label_s_down, pcl_temp, hp["ignore_label"]) +
+                        gast.pcl_loss(new_protos, feat_t, label_t, pcl_temp, hp["ignore_label"]))
+    loss = loss_seg + loss_domain + loss_align
+    opt.zero_grad()
+    loss.backward()
+    gnorm = opt.clip_grad_norm(hp["max_norm"])
+    opt.step(lr)
+    return dict(loss_seg=loss_seg.detach(), loss_domain=torch.as_tensor(loss_domain).detach(), loss_align=loss_align.detach(),
+                prototypes=new_protos, label_t_hard=hard, grad_norm=gnorm, pred_s1=ps1.detach(), pred_t1=pt1.detach())

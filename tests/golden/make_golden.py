@@ -290,6 +290,22 @@ def main():
     save("pre_slide", image=img, out=ref.tools.pre_slide(fake_model, img, num_classes=3, tile_size=(32, 32), tta=False),
          out_one_tile=ref.tools.pre_slide(fake_model, img[:, :, :32, :32], num_classes=3, tile_size=(32, 32), tta=False))
 
+    # stage-2 alignment losses
+    import importlib
+    loss_mod, coral_mod = importlib.import_module("uemda.loss"), importlib.import_module("uemda.gast.coral")
+    ga = torch.Generator().manual_seed(77)
+    featp = (torch.randn(2, 128, 6, 5, generator=ga) * 1.5 + 0.3).requires_grad_(True)
+    protosp = torch.randn(6, 128, generator=ga)
+    labelsp = torch.randint(-1, 6, (2, 1, 6, 5), generator=ga)
+    lp = loss_mod.PrototypeContrastiveLoss(temperature=8.0, ignore_label=-1)(protosp, featp, labelsp)
+    (lp * 3.0).backward()
+    srcp = (torch.randn(300, 128, generator=ga) + 0.5).requires_grad_(True)
+    tgtp = (torch.randn(280, 128, generator=ga) * 1.3 - 0.2).requires_grad_(True)
+    lcp = coral_mod.CoralLoss()(srcp, tgtp)
+    lcp.backward()
+    save("align_losses", feat=featp, protos=protosp, labels=labelsp, pcl=lp, pcl_gfeat_x3=featp.grad, src=srcp, tgt=tgtp,
+         coral=lcp, coral_gsrc=srcp.grad, coral_gtgt=tgtp.grad)
+
     # ---------------- G-layers ------------------------------------------------------------------
     print("G-layers")
     from oracle.weights import _rng, fill_like

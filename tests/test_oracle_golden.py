@@ -267,3 +267,18 @@ def test_pre_slide_windowing_golden():
     # TTA of a model that commutes with the dihedral group is the model itself
     eq = infer.tta_predict(lambda x: x * 2.0, g["image"][:1])
     torch.testing.assert_close(eq, g["image"][:1] * 2.0, rtol=1e-6, atol=1e-6)
+
+
+def test_stage2_alignment_losses_golden():
+    g = load_golden("align_losses")
+    f = g["feat"].clone().requires_grad_(True)
+    l = gast.pcl_loss(g["protos"], f, g["labels"], 8.0, -1)
+    (l * 3.0).backward()
+    torch.testing.assert_close(l.detach(), g["pcl"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(f.grad, g["pcl_gfeat_x3"], rtol=1e-5, atol=1e-8)
+    s, t = g["src"].clone().requires_grad_(True), g["tgt"].clone().requires_grad_(True)
+    lc = gast.coral_loss(s, t)
+    lc.backward()
+    torch.testing.assert_close(lc.detach(), g["coral"], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(s.grad, g["coral_gsrc"], rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(t.grad, g["coral_gtgt"], rtol=1e-4, atol=1e-9)

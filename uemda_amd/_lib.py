@@ -90,11 +90,15 @@ SIGNATURES = {
     "uem_scale": [P, L, F, P],
     "uem_argmax_confusion": [P, P, P, P, I, I, L, P],
     "uem_proto_mean": [P, P, P, I, I, P],
+    "uem_pcl_loss": [P, P, P, P, P, P, I, I, I, F, L, P],
+    "uem_pcl_workspace_floats": [I, I],
+    "uem_coral_finish": [P, P, P, P, I, I, I, P, P, P, P, P],
+    "uem_negate": [P, P, I, P],
     "uem_grad_sqnorm": [P, L, P, P, P],
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
 }
 _RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64,
-            "uem_label_refine_workspace_floats": c_int64}
+            "uem_label_refine_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64}
 
 # compile-time constants mirrored from the header
 UEM_MAX_CLASSES = 16

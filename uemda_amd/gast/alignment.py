@@ -55,6 +55,17 @@ class Aligner:
         self._data_sum = torch.zeros([class_num, feat_channels], device=self.device)
         self._data_cnt = torch.zeros([class_num, 1], device=self.device)
 
+    # ---- domain alignment (stage 1/2, --align-domain) -------------------------------------------------------
+    def align_domain(self, feat_s, feat_t):
+        """CORAL loss between source and target feature maps (alignment.py:79-84)."""
+        from ..loss import ops_as_rows
+        from .coral import CoralLoss
+        assert feat_s.shape == feat_t.shape, 'tensor "feat_s" has the same shape as tensor "feat_t"'
+        assert len(feat_s.shape) == 4, 'tensor "feat_s" and "feat_t" must have 4 dimensions'
+        if not hasattr(self, "coral"):
+            self.coral = CoralLoss()
+        return self.coral(ops_as_rows(feat_s, self.feat_channels), ops_as_rows(feat_t, self.feat_channels))
+
     # ---- distances ------------------------------------------------------------------------------------
     def _pearson_dist(self, feat1, feat2):
         """(n, k) x (m, k) -> (n, m) Pearson distance in [0, 1]  (alignment.py:424-451)."""

@@ -56,3 +56,41 @@ def src_step(model, optimizer, state, batch, lr, dp=None):
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
     return dict(loss_source=loss.detach(), pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
                 grad_norm=optimizer.last_grad_norm)
+
+
+def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None, align_domain=True, pcl_temp=8.0):
+    """One stage-2 (prototype-contrastive alignment) iteration: reference tools/train_align_uem.py:139-183."""
+    import torch
+    from . import ops
+    from .gast.pseudo_generation import pseudo_selection
+    from .loss import PrototypeContrastiveLoss
+    hp = state.hp
+    if not hasattr(state, "loss_fn_pcl"):
+        state.loss_fn_pcl = PrototypeContrastiveLoss(temperature=pcl_temp, ignore_label=hp["ignore_label"])
+    model.train()
+    optimizer.param_groups[0]["lr"] = lr
+    pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # :147
+    label_s_down = aligner.update_prototype(feat_s, batch["label_s"])           # :150
+    pred_t1, pred_t2, feat_t = model(batch["images_t"])                         # :156
+    # on-the-fly soft labels (:158-160): (softmax(up(x1)) + softmax(up(x2))) / 2, the eval-output kernel
+    x1, x2 = ops.as_nhwc(pred_t1.detach()).contiguous(), ops.as_nhwc(pred_t2.detach()).contiguous()
+    n, h, w, c = x1.shape
+    H, W = batch["images_t"].shape[-2:]
+    soft0 = torch.empty((n, c, H, W), device=x1.device, dtype=torch.float32)
+    ops.call("uem_upsample_softmax_avg", ops.ptr(x1), ops.ptr(x2), ops.ptr(soft0), n, c, h, w, H, W, ops.stream())
+    soft, hard = aligner.refine_and_select(batch["label_t_sup"], feat_t, [pred_t1, pred_t2], soft0, mode=hp["refine_mode"],
+                                           temp=hp["refine_temp"], cutoff_top=hp["cutoff_top"], cutoff_low=hp["cutoff_low"],
+                                           sup_ignore_id=sup_ignore_id)          # :161-165
+    label_t = aligner.downscale_gt(hard)                                        # :170
+    loss_seg = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)     # :174
+    loss_domain = aligner.align_domain(feat_s, feat_t) if align_domain else 0   # :175
+    loss_align = (state.loss_fn_pcl(aligner.prototypes, feat_s, label_s_down) +
+                  state.loss_fn_pcl(aligner.prototypes, feat_t, label_t)) * 0.5  # :176-177
+    loss = loss_seg + loss_domain + loss_align
+    optimizer.zero_grad()
+    loss.backward()
+    prescale = dp.reduce_gradients() if dp is not None else 1.0
+    optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
+    return dict(loss_seg=loss_seg.detach(), loss_domain=loss_domain.detach() if torch.is_tensor(loss_domain) else loss_domain,
+                loss_align=loss_align.detach(), label_t_hard=hard, pred_s1=pred_s1.detach(), pred_t1=pred_t1.detach(),
+                grad_norm=optimizer.last_grad_norm)
