@@ -1,0 +1,91 @@
+"""Size-independent properties at BASELINE.json's full sizes (B=32, 512x512, C=6): the oracle cannot run these
+in seconds on the CPU, so the checks are invariants of the domain (normalisation, threshold semantics,
+idempotence, linearity, forward determinism)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+C, B, S = 6, 32, 512
+
+
+@pytest.fixture(scope="module")
+def big_batch():
+    from oracle import synth
+    pool = synth.make_batch(B=4, H=S, W=S, C=C, k=2048, seed=31)
+    return {k: (v.cuda().repeat((B // 4,) + (1,) * (v.dim() - 1)).contiguous() if k != "prototypes" else v.cuda())
+            for k, v in pool.items()}
+
+
+def test_mining_invariants_at_b32(big_batch):
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    b = big_batch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rep = lambda t: t.repeat(B // 4, 1, 1, 1).contiguous().permute(0, 3, 1, 2)     # 8 copies of 4 distinct tiles
+    feat = rep(torch.randn(4, 32, 32, 2048, device="cuda", generator=g))
+    p1 = rep(2 * torch.randn(4, 32, 32, C, device="cuda", generator=g))
+    p2 = rep(2 * torch.randn(4, 32, 32, C, device="cuda", generator=g))
+    al = Aligner(None, 2048, C, -1, 0.996)
+    al.prototypes = b["prototypes"].clone()
+    soft, hard = al.refine_and_select(b["label_t_sup"], feat, [p1, p2], b["label_t_soft"], sup_ignore_id=1024)
+    assert torch.isfinite(soft).all() and (soft >= 0).all()
+    assert ((soft.sum(1) - 1).abs() < 1e-5).all()                              # _logits_norm
+    assert torch.equal(hard, pseudo_selection(soft, return_type="tensor"))     # shared maxima == standalone selection
+    thr = torch.maximum(soft.flatten(2).max(-1)[0] * 0.8, torch.tensor(0.6, device="cuda")).view(B, C, 1, 1)
+    above = soft > thr
+    assert torch.equal(hard >= 0, above.sum(1) == 1)                           # labelled <=> exactly one class above
+    picked = torch.gather(above, 1, hard.clamp(min=0).unsqueeze(1)).squeeze(1)
+    assert picked[hard >= 0].all()                                             # ... and it is the labelled class
+    # the batch is 8 copies of 4 tiles: per-image thresholds => identical labels for identical tiles
+    assert torch.equal(hard[:4], hard[4:8]) and torch.equal(hard[:4], hard[28:32])
+    # refining with refine=False is the identity; the explicit ignore id equals the batch-global max path
+    soft2 = al.label_refine(b["label_t_sup"], feat, [p1, p2], b["label_t_soft"])
+    assert torch.equal(soft2, soft)
+
+
+def test_conv_linearity_and_bn_invariants_at_b32():
+    from uemda_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x1 = torch.randn(B, 64, 64, 128, device="cuda", generator=g)
+    x2 = torch.randn(B, 64, 64, 128, device="cuda", generator=g)
+    w = torch.randn(128, 3, 3, 128, device="cuda", generator=g) * 0.03
+    y = ops.conv2d(2.5 * x1 + x2, w, pad=1)
+    y12 = 2.5 * ops.conv2d(x1, w, pad=1) + ops.conv2d(x2, w, pad=1)
+    assert (y - y12).abs().max() <= 1e-4 * y.abs().max()
+    # fused epilogue statistics == stand-alone statistics kernel
+    bn = torch.nn.BatchNorm2d(128).cuda()
+    bn.train()
+    rm0 = bn.running_mean.clone()
+    z, st = ops.conv2d_bn(x1, w, bn, pad=1)
+    bn.running_mean.copy_(rm0)
+    st2 = ops.bn_stats(z, bn.weight.detach(), bn.bias.detach(), None, None, True)
+    torch.testing.assert_close(st.mean, st2.mean, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(st.invstd, st2.invstd, rtol=1e-4, atol=1e-6)
+    a = ops.affine_act(z, st, relu=False)
+    m = a.reshape(-1, 128).mean(0)
+    v = a.reshape(-1, 128).var(0, unbiased=False)
+    assert m.abs().max() < 1e-4 and (v - 1).abs().max() < 1e-3                 # normalised output: mean 0, var 1
+
+
+def test_forward_is_deterministic_and_step_is_finite_at_b32(big_batch):
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    torch.manual_seed(0)
+    model = Deeplabv2(cfg).cuda()
+    model.eval()
+    with torch.no_grad():
+        a = model(big_batch["images_t"][:8])
+        b = model(big_batch["images_t"][:8])
+    assert torch.equal(a, b)                                                   # no atomics on the forward path
+    assert ((a.sum(1) - 1).abs() < 1e-5).all()
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    al.prototypes = big_batch["prototypes"].clone()
+    opt = FusedSGD(model, 1e-2, 0.9, 5e-4)
+    out = ssl_step(model, al, opt, StepState(C), big_batch, 1e-3, sup_ignore_id=1024)
+    assert torch.isfinite(out["loss_source"]) and torch.isfinite(out["loss_target"]) and torch.isfinite(out["grad_norm"]).all()
+    arena, garena, n = model.flat_parameters()
+    assert torch.isfinite(arena[:n]).all() and torch.isfinite(garena[:n]).all()
