@@ -161,8 +161,12 @@ def main():
                         families={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                           ms_per_step=round(v["ms"] / prof_steps, 2)) for k, v in prof.items()},
                         measured="HIP events around every conv launch of the last timed step")
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            metric = "512x512 tiles/sec (fwd+bwd+pseudo-label) ResNet50-ASPP bs=32, 1/2/4/8 GPU"
         line = {
-            "metric": "512x512 tiles/sec (fwd+bwd+pseudo-label) ResNet50-ASPP bs=32",
+            "metric": metric,
             "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

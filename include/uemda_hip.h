@@ -48,6 +48,9 @@ typedef struct {
 #define UEM_CONV_IN_AFFINE 1   /* operand prologue: x' = x*in_scale[c] + in_shift[c]  (fused BN apply) */
 #define UEM_CONV_IN_RELU 2     /* operand prologue: x' = max(x', 0)                                  */
 #define UEM_CONV_ACCUMULATE 4  /* epilogue: y += result (ASPP branch sum, Encoder.py:83)               */
+#define UEM_CONV_PREC_BF16X3 16 /* opt-in: operands split x = hi + lo (bf16), hi*hi + hi*lo + lo*hi on the bf16 MFMA,
+                                  fp32 accumulate: ~2^-16 relative error per product (exact fp32 MFMA is the default) */
+#define UEM_CONV_PREC_BF16 32   /* opt-in: plain bf16 operands (hi*hi only), fp32 accumulate                        */
 #define UEM_CONV_TRANSPOSED 8  /* gather of the data-gradient of a strided conv: shape describes the
                                   FORWARD conv, x is dY (N,Ho,Wo,Cout), y is dX (N,H,W,Cin), w is
                                   W'[Cin][KH][KW][Cout] (uem_weight_transpose of the forward weights) */
@@ -64,9 +67,10 @@ int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, 
 /* data gradient of a stride-1 conv (dx = dA of the producing layer) whose epilogue also computes the first pass
  * of that layer's BatchNorm+ReLU backward: with bn_z = the layer's raw conv output (N,H,W,Cin) and bn_vec =
  * (4,Cin) [scale, shift, mean, invstd], tile_partials[M/128][2][Cin] receives per-tile sums of dp = dA*[relu mask]
- * and dp*xhat (replaces uem_bn_bwd_reduce's pass over z and dA).  s describes the FORWARD conv.          */
+ * and dp*xhat (replaces uem_bn_bwd_reduce's pass over z and dA).  s describes the FORWARD conv; flags may carry
+ * a UEM_CONV_PREC_* bit only.                                                                            */
 int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* bn_z,
-                           const float* bn_vec, float* tile_partials, void* stream);
+                           const float* bn_vec, float* tile_partials, int flags, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
 /* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */

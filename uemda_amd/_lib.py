@@ -33,7 +33,7 @@ SIGNATURES = {
     "uem_last_error": [],
     "uem_conv2d_fwd": [P, P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_fwd_stats": [P, P, P, P, P, POINTER(ConvShape), I, P, P],
-    "uem_conv2d_dgrad_bnbwd": [P, P, P, POINTER(ConvShape), P, P, P, P],
+    "uem_conv2d_dgrad_bnbwd": [P, P, P, POINTER(ConvShape), P, P, P, c_int, P],
     "uem_conv2d_stem_fwd": [P, P, P, I, I, I, P],
     "uem_conv2d_wgrad": [P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_stem_wgrad": [P, P, P, I, I, I, P],
@@ -105,6 +105,7 @@ UEM_MAX_CLASSES = 16
 UEM_PROTO_SPLIT = 256
 UEM_NORM_BLOCKS = 1024
 CONV_IN_AFFINE, CONV_IN_RELU, CONV_ACCUMULATE, CONV_TRANSPOSED = 1, 2, 4, 8
+CONV_PREC_BF16X3, CONV_PREC_BF16 = 16, 32
 
 
 class UemError(RuntimeError):

@@ -57,11 +57,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // MODE: 0 = forward gather, 1 = transposed gather (data gradient), 2 = stem (NHWC4, 8 px x 4 ch per tap row)
 // NBUF: 1 = one LDS stage (two barriers per k-step, 3 blocks/CU); 2 = two LDS stages (one barrier per k-step,
 //       74 KB => 2 blocks/CU, so power-of-two grids fill the 512 block slots in whole rounds)
-template <int BN, int WM, int WN, int MODE, bool AFFINE, int NBUF>
+// PREC: 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 = 3xbf16 split: x = hi + lo (two bf16), the product keeps
+//       hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-16 relative per product, 5.3x
+//       fewer matrix-pipe cycles); 2 = plain bf16 operands (hi*hi only).  Opt-in (UEM_CONV_PREC_* flags).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define LDS_LDH 40   // bf16 elements per LDS row in the split modes: 32 + 8 pad => 80-B stride, conflict-free b128 reads
+
+template <int BN, int WM, int WN, int MODE, bool AFFINE, int NBUF, int PREC>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const ConvP p) {
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     constexpr int BROWS = BN / 32;                      // B-tile rows per thread
-    constexpr int A_SZ = BM * LDS_LD, B_SZ = BN * LDS_LD;
+    // stage sizes in floats; split modes hold a hi and a lo bf16 image of each tile (same bytes + padding)
+    constexpr int A_SZ = PREC == 0 ? BM * LDS_LD : BM * LDS_LDH, B_SZ = PREC == 0 ? BN * LDS_LD : BN * LDS_LDH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const As0 = smem;                            // [NBUF][BM][LDS_LD]
     float* const Bs0 = smem + NBUF * A_SZ;              // [NBUF][BN][LDS_LD]
@@ -172,6 +180,24 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
             psc = *reinterpret_cast<const float4*>(&Ssc[pci0 + lc4]);
             psh = *reinterpret_cast<const float4*>(&Ssc[p.Cin + pci0 + lc4]);
         }
+        auto put = [&](float* stage, int row, float4 v) {
+            if constexpr (PREC == 0) {
+                *reinterpret_cast<float4*>(&stage[row * LDS_LD + lc4]) = v;
+            } else {
+                // hi image in the first half of the stage, lo image in the second half ([rows][LDS_LDH] bf16 each)
+                __bf16* hi = reinterpret_cast<__bf16*>(stage);
+                bf16x4 h;
+                h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+                *reinterpret_cast<bf16x4*>(&hi[row * LDS_LDH + lc4]) = h;
+                if constexpr (PREC == 1) {
+                    __bf16* lo = hi + (stage == As ? BM : BN) * LDS_LDH;
+                    bf16x4 l;
+                    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+                    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+                    *reinterpret_cast<bf16x4*>(&lo[row * LDS_LDH + lc4]) = l;
+                }
+            }
+        };
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = ra[j];
@@ -179,10 +205,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
                 v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y; v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
-            *reinterpret_cast<float4*>(&As[(lrow + 32 * j) * LDS_LD + lc4]) = v;
+            put(As, lrow + 32 * j, v);
         }
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * j) * LDS_LD + lc4]) = rb[j];
+        for (int j = 0; j < BROWS; ++j) put(Bs, lrow + 32 * j, rb[j]);
     };
 
     f32x16 acc[MT][NT];
@@ -206,20 +232,58 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
         const float* const As = As0 + cur * A_SZ;
         const float* const Bs = Bs0 + cur * B_SZ;
         if (kt + 1 < KT) load_tiles(kt + 1);            // in flight during the MFMA phase
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float4 a[MT], b[NT];
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                float4 a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
+                for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
-            // k outer, accumulators inner: consecutive MFMAs never depend on each other
+                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * LDS_LD + ks * 8 + fh * 4]);
+                // k outer, accumulators inner: consecutive MFMAs never depend on each other
 #define MFMA_STEP(C)                                                                                      \
     _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].C, b[j].C, acc[i][j], 0, 0, 0);
-            MFMA_STEP(x) MFMA_STEP(y) MFMA_STEP(z) MFMA_STEP(w)
+                MFMA_STEP(x) MFMA_STEP(y) MFMA_STEP(z) MFMA_STEP(w)
 #undef MFMA_STEP
+            }
+        } else {
+            // bf16 operand fragment of v_mfma_f32_32x32x16_bf16: lane (r = l&31, h = l>>5) holds row r, k = 8h..8h+7
+            const __bf16* Ah = reinterpret_cast<const __bf16*>(As);
+            const __bf16* Al = Ah + BM * LDS_LDH;
+            const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs);
+            const __bf16* Bl = Bh + BN * LDS_LDH;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int o = (wm + i * 32 + fr) * LDS_LDH + ks * 16 + fh * 8;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[o]);
+                    if constexpr (PREC == 1) al[i] = *reinterpret_cast<const bf16x8*>(&Al[o]);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int o = (wn + j * 32 + fr) * LDS_LDH + ks * 16 + fh * 8;
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[o]);
+                    if constexpr (PREC == 1) bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[o]);
+                }
+                if constexpr (PREC == 1) {              // small cross terms first, then the leading term
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (NBUF == 2) {
             // the other stage was last read in iteration kt-1, which every wave left through the barrier below
@@ -369,35 +433,46 @@ static int conv_check(const uem_conv_shape* s) {
     return UEM_OK;
 }
 
-template <int BN_, int WM_, int WN_, int MODE, int NBUF>
+template <int BN_, int WM_, int WN_, int MODE, int NBUF, int PREC>
 static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
-    size_t lds = (size_t)NBUF * (BM + BN_) * LDS_LD * sizeof(float);
+    const size_t a_sz = PREC == 0 ? (size_t)BM * LDS_LD : (size_t)BM * LDS_LDH;
+    const size_t b_sz = PREC == 0 ? (size_t)BN_ * LDS_LD : (size_t)BN_ * LDS_LDH;
+    size_t lds = (size_t)NBUF * (a_sz + b_sz) * sizeof(float);
     if (affine) lds += (size_t)2 * p.Cin * sizeof(float);
     if (affine) {
-        auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, true, NBUF>;
+        auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, true, NBUF, PREC>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         k<<<grid, 256, lds, st>>>(p);
     } else {
-        auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, false, NBUF>;
+        auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, false, NBUF, PREC>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         k<<<grid, 256, lds, st>>>(p);
     }
 }
 
 template <int MODE>
-static int conv_launch(const ConvP& p, bool affine, hipStream_t st) {
+static int conv_launch(const ConvP& p, bool affine, hipStream_t st, int prec = 0) {
     static const int nbuf = getenv("UEM_CONV_NBUF") ? atoi(getenv("UEM_CONV_NBUF")) : 1;
+    static const int smallk_bn64 = getenv("UEM_CONV_SMALLK_BN64") ? atoi(getenv("UEM_CONV_SMALLK_BN64")) : 0;
     const int tiles_m = (int)uem_cdiv(p.M, BM);
-    if (p.Cout % 128 == 0) {
+    const bool prefer64 = smallk_bn64 > 0 && p.ntaps * p.Cin <= smallk_bn64 && p.Cout % 64 == 0;
+    if (p.Cout % 128 == 0 && !prefer64) {
         const int grid = tiles_m * (p.Cout / 128);
-        if (nbuf == 2) conv_go<128, 2, 2, MODE, 2>(p, affine, grid, st);
-        else conv_go<128, 2, 2, MODE, 1>(p, affine, grid, st);
+        if (prec == 1) conv_go<128, 2, 2, MODE, 1, 1>(p, affine, grid, st);
+        else if (prec == 2) conv_go<128, 2, 2, MODE, 1, 2>(p, affine, grid, st);
+        else if (nbuf == 2) conv_go<128, 2, 2, MODE, 2, 0>(p, affine, grid, st);
+        else conv_go<128, 2, 2, MODE, 1, 0>(p, affine, grid, st);
     } else if (p.Cout % 64 == 0) {
         const int grid = tiles_m * (p.Cout / 64);
-        if (nbuf == 2) conv_go<64, 2, 2, MODE, 2>(p, affine, grid, st);
-        else conv_go<64, 2, 2, MODE, 1>(p, affine, grid, st);
+        if (prec == 1) conv_go<64, 2, 2, MODE, 1, 1>(p, affine, grid, st);
+        else if (prec == 2) conv_go<64, 2, 2, MODE, 1, 2>(p, affine, grid, st);
+        else if (nbuf == 2) conv_go<64, 2, 2, MODE, 2, 0>(p, affine, grid, st);
+        else conv_go<64, 2, 2, MODE, 1, 0>(p, affine, grid, st);
     } else {
-        conv_go<32, 4, 1, MODE, 1>(p, affine, tiles_m * (int)uem_cdiv(p.Cout, 32), st);
+        const int grid = tiles_m * (int)uem_cdiv(p.Cout, 32);
+        if (prec == 1) conv_go<32, 4, 1, MODE, 1, 1>(p, affine, grid, st);
+        else if (prec == 2) conv_go<32, 4, 1, MODE, 1, 2>(p, affine, grid, st);
+        else conv_go<32, 4, 1, MODE, 1, 0>(p, affine, grid, st);
     }
     return uem_check_launch("conv2d");
 }
@@ -412,12 +487,13 @@ extern "C" int uem_conv2d_fwd(const float* x, const float* w, const float* bias,
     return conv2d_fwd_impl(x, w, bias, in_scale, in_shift, y, s, flags, nullptr, nullptr, stream);
 }
 extern "C" int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* bn_z,
-                                      const float* bn_vec, float* tile_partials, void* stream) {
+                                      const float* bn_vec, float* tile_partials, int flags, void* stream) {
     UEM_REQUIRE(bn_z && bn_vec && tile_partials && s, "conv2d_dgrad_bnbwd: null pointer");
     if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin)
         return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_bnbwd: needs stride 1, M %% 128 == 0, Cin %% 64 == 0");
     BnBwdFuse f{bn_z, bn_vec, tile_partials};
-    return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED, nullptr, &f, stream);
+    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_dgrad_bnbwd: only precision flags are accepted");
+    return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED | flags, nullptr, &f, stream);
 }
 extern "C" int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift,
                                     float* y, const uem_conv_shape* s, int flags, float* tile_stats, void* stream) {
@@ -435,6 +511,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     if (rc) return rc;
     const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
     const bool transposed = (flags & UEM_CONV_TRANSPOSED) != 0;
+    const int prec = (flags & UEM_CONV_PREC_BF16X3) ? 1 : ((flags & UEM_CONV_PREC_BF16) ? 2 : 0);
     UEM_REQUIRE(!affine || (in_scale && in_shift), "conv2d_fwd: affine prologue needs scale/shift");
     UEM_REQUIRE(!(affine && transposed), "conv2d_fwd: prologue not supported on the transposed gather");
     ConvP p;
@@ -450,7 +527,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
         p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
         p.x_ld = s->x_ld; p.y_ld = s->y_ld;
         p.M = s->N * s->Ho * s->Wo;
-        return conv_launch<0>(p, affine, (hipStream_t)stream);
+        return conv_launch<0>(p, affine, (hipStream_t)stream, prec);
     }
     // data gradient: rows = input pixels (N,H,W), reduction over (tap, Cout), gather from dY (N,Ho,Wo,Cout).
     // dX[y,x] += dY[(y+pad-ky*d)/s, (x+pad-kx*d)/s] * W[ky,kx] only where the division is exact, so the
@@ -478,7 +555,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
                 }
             }
             p.M = s->N * p.Hs * p.Ws;
-            rc = conv_launch<1>(p, false, (hipStream_t)stream);
+            rc = conv_launch<1>(p, false, (hipStream_t)stream, prec);
             if (rc) return rc;
         }
     }
