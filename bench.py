@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 F32_MATRIX_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the peak of the opt-in "bf16" operand mode)
 GFLOP_PER_TILE = {("resnet50", "aspp", 512): (66.66, 198.8)}       # BASELINE.md section 3 (fwd, fwd+bwd)
 
 
@@ -72,6 +73,10 @@ def main():
     ap.add_argument("--dump-params", default="", help="write a parameter checksum after the run (DP rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--conv-prec", default="fp32", choices=["fp32", "mixed", "bf16x3", "bf16"],
+                    help="matrix-core operand precision of the convolutions (fp32 = exact f32 MFMA, the parity default)")
+    ap.add_argument("--no-other-precisions", action="store_true",
+                    help="skip the short extra legs that time the same step in the two opt-in precisions (N=1 only)")
     args = ap.parse_args()
 
     from uemda_amd import dp as udp, ops
@@ -88,6 +93,7 @@ def main():
     from uemda_amd.step import HYPER, StepState, src_step, ssl_step
     from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
 
+    ops.set_conv_precision(args.conv_prec)
     C, B, S = 6, args.batch, args.size
     seed_torch(2333)
     cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
@@ -143,6 +149,29 @@ def main():
     tiles_per_step = (2 * B if args.workload == "ssl" else B) * world
     value = tiles_per_step * args.steps / elapsed
 
+    others = None
+    if world == 1 and not args.no_other_precisions:
+        # the same step in the other matrix-core precisions (2 untimed + 3 timed steps each); `value` above is untouched
+        others = {}
+        for prec in ("fp32", "mixed", "bf16x3", "bf16"):
+            if prec == args.conv_prec:
+                continue
+            ops.set_conv_precision(prec)
+            for i in range(2):
+                one_step(args.warmup + args.steps + i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(3):
+                one_step(args.warmup + args.steps + 2 + i)
+            barrier()
+            dt = (time.perf_counter() - t1) / 3
+            others[prec] = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=3)
+        ops.set_conv_precision(args.conv_prec)
+
+    peak = BF16_MATRIX_PEAK_TFLOPS if args.conv_prec == "bf16" else F32_MATRIX_PEAK_TFLOPS
+    prec_text = {"fp32": "fp32 (f32 MFMA)", "bf16x3": "fp32 storage, 3xbf16 split MFMA with fp32 accumulate",
+                 "mixed": "fp32 (f32 MFMA) forward, 3xbf16 split MFMA data/weight gradients",
+                 "bf16": "fp32 storage, bf16 MFMA operands with fp32 accumulate"}[args.conv_prec]
     if rank == 0:
         roof = None
         prof = ops.PROF.summary()
@@ -153,8 +182,8 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get(fam)
-            roof = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=F32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / F32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic,
+            roof = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=traffic,
                         launches_per_step=agg["launches"] // prof_steps,
                         avg_launch_ms=round(agg["ms"] / agg["launches"], 4),
                         algorithmic_gflop_per_launch=round(agg["flops"] / agg["launches"] / 1e9, 3),
@@ -169,14 +198,17 @@ def main():
             "metric": metric,
             "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "mixed": "f32 fwd / 3xbf16 split bwd", "bf16x3": "f32 (3xbf16 split)", "bf16": "bf16"}[args.conv_prec],
+            "data": "synthetic",
             "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
-                                   f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, fp32 (f32 MFMA), "
+                                   f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text}, "
                                    f"random init; tiles counted = source + target",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}"},
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }
+        if others:
+            line["other_precisions"] = others
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -17,7 +17,7 @@ def rel(a, b):
 def main():
     torch.manual_seed(0)
     for cin, cout, k, s, d, h in [(64, 64, 3, 1, 1, 32), (256, 128, 1, 1, 1, 32), (512, 512, 3, 1, 2, 16), (2048, 512, 1, 1, 1, 16),
-                                  (128, 128, 3, 2, 1, 32), (2048, 32, 3, 1, 6, 16)]:
+                                  (128, 128, 3, 2, 1, 32), (2048, 32, 3, 1, 6, 16), (64, 256, 1, 1, 1, 32), (256, 64, 1, 1, 1, 32)]:
         pad = d * (k - 1) // 2
         x = torch.randn(4, h, h, cin, device="cuda")
         w = torch.randn(cout, k, k, cin, device="cuda") * (2.0 / (cin * k * k)) ** 0.5
@@ -29,12 +29,16 @@ def main():
         wt = ops.weight_transpose(w)
         refd = torch.nn.grad.conv2d_input((4, cin, h, h), w.permute(0, 3, 1, 2).double(), dy.permute(0, 3, 1, 2).double(), s, pad, d)
         refd = refd.permute(0, 2, 3, 1)
+        refw = torch.nn.grad.conv2d_weight(xa.permute(0, 3, 1, 2).double(), (cout, cin, k, k), dy.permute(0, 3, 1, 2).double(), s, pad, d)
+        refw = refw.permute(0, 2, 3, 1)
         line = f"Cin={cin:4d} Cout={cout:4d} k={k} s={s} d={d}:"
         for prec in ("fp32", "bf16x3", "bf16"):
             ops.set_conv_precision(prec)
             y = ops.conv2d(x, w, stride=s, pad=pad, dil=d, in_scale=sc, in_shift=sh, in_relu=True)
             dx = ops.conv2d_dgrad(dy, wt, x.shape, stride=s, pad=pad, dil=d)
-            line += f"  {prec}: fwd {rel(y, ref):.2e} dgrad {rel(dx, refd):.2e}"
+            dw = torch.zeros_like(w)
+            ops.conv2d_wgrad(x, dy, dw, stride=s, pad=pad, dil=d, in_scale=sc, in_shift=sh, in_relu=True)
+            line += f"  {prec}: fwd {rel(y, ref):.2e} dgrad {rel(dx, refd):.2e} wgrad {rel(dw, refw):.2e}"
         ops.set_conv_precision("fp32")
         print(line)
 

@@ -59,6 +59,35 @@ def test_conv_forward_dgrad_wgrad(case):
     torch.testing.assert_close(nchw(y2), 2 * y_ref.detach() - bias.view(1, -1, 1, 1), rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 6e-3)])
+@pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[5], CONV_CASES[6], CONV_CASES[8]])
+def test_conv_reduced_operand_modes(case, prec, tol):
+    """Opt-in matrix-core precisions: relative-L2 error of forward / data gradient / weight gradient against fp64."""
+    from uemda_amd import ops
+    N, H, W, Cin, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(N, Cin, H, W, generator=g).double().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).double().requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, stride=s, padding=p, dilation=d)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy.double())
+    xf, wf = x.detach().float(), w.detach().float()
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    ops.set_conv_precision(prec)
+    try:
+        y = ops.conv2d(nhwc(xf), ohwi(wf), None, stride=s, pad=p, dil=d)
+        dx = ops.conv2d_dgrad(nhwc(gy), ops.weight_transpose(ohwi(wf)), (N, H, W, Cin), stride=s, pad=p, dil=d)
+        dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+        ops.conv2d_wgrad(nhwc(xf), nhwc(gy), dw, stride=s, pad=p, dil=d)
+    finally:
+        ops.set_conv_precision("fp32")
+    assert rel(nchw(y), y_ref.detach()) < tol
+    assert rel(nchw(dx), x.grad) < tol
+    assert rel(dw.permute(0, 3, 1, 2), w.grad) < tol
+
+
 def test_conv_operand_prologue_affine_relu():
     from uemda_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -252,7 +281,20 @@ def _model(use_ppm=False):
     return m.cuda()
 
 
-def test_full_model_aspp_ssl_step_matches_reference_golden():
+@pytest.fixture
+def conv_precision(request):
+    from uemda_amd import ops
+    ops.set_conv_precision(request.param)
+    yield request.param
+    ops.set_conv_precision("fp32")
+
+
+# "bf16x3" (opt-in split-bf16 matrix-core mode): ~4e-6 per conv instead of ~3e-7, which this randomly initialised
+# network amplifies to 1.7e-3 on the logits -- over north_star's 1e-3, which is why exact fp32 is the default.  The mode
+# is held to a 5e-3 logit bar and the same pseudo-label agreement (scripts/precision_fullmodel_report.py).
+# "mixed" (fp32 forward, bf16x3 gradients) is held to every assertion of the fp32 default.
+@pytest.mark.parametrize("conv_precision", ["fp32", "mixed", "bf16x3"], indirect=True)
+def test_full_model_aspp_ssl_step_matches_reference_golden(conv_precision):
     from oracle import synth
     from oracle.weights import checksum, subsample
     from uemda_amd.gast.alignment import Aligner
@@ -273,7 +315,13 @@ def test_full_model_aspp_ssl_step_matches_reference_golden():
     for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
         ref = g[k]
         err = (out[k].cpu() - ref).abs().max() / ref.abs().max()
-        assert err < 1e-3, (k, float(err))
+        assert err < (5e-3 if conv_precision == "bf16x3" else 1e-3), (k, float(err))
+    if conv_precision == "bf16x3":
+        assert (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item() >= 0.9995
+        torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=5e-3, atol=1e-4)
+        return
     torch.testing.assert_close(out["feat_t"].cpu().reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(out["label_t_soft"][:, :, ::4, ::4].cpu(), g["soft_sample"], rtol=1e-3, atol=1e-5)
     agree = (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item()

@@ -592,13 +592,37 @@ struct WgradP {
     int rows_per_split;
 };
 
-template <int TM, int TN, int WM, int WN, int WK, int MODE, bool AFFINE>
+// PREC as in conv_fwd_kernel.  The reduction runs over pixels, so both MFMA operands are needed k-major while
+// global memory (and the LDS image filled from it by coalesced channel-contiguous loads) is channel-major: the
+// bf16 modes keep a [pixel][channel] bf16 image and read it with ds_read_b64_tr_b16, the hardware transposing
+// read (per 16 lanes: a 4-pixel x 16-channel block, delivered channel-per-lane).  Row stride T*2 + 64 bytes puts
+// the 4 pixel rows of a 32-lane read into the 4 bank quarters (conflict-free); the 8-byte stores of one pixel
+// row are contiguous.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* img, int ld, int k0, int ch0, int lane) {
+    // operand fragment of v_mfma_f32_32x32x16_bf16 for the 32 channels at ch0 and the 8 pixels k0 .. k0+7
+    const int q = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
+    const unsigned char* a = img + (k0 + q) * ld + 2 * (ch0 + 16 * g16 + 4 * pp);
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * ld));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int TM, int TN, int WM, int WN, int WK, int MODE, bool AFFINE, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     constexpr int MT = TM / WM / 32, NT = TN / WN / 32;
     constexpr int DTPR = TM / 4, DRPP = 256 / DTPR, DPASS = (BK + DRPP - 1) / DRPP;   // dY loader
     constexpr int XTPR = TN / 4, XRPP = 256 / XTPR, XPASS = (BK + XRPP - 1) / XRPP;   // X loader
-    __shared__ __attribute__((aligned(16))) float Ds[BK * TM];
-    __shared__ __attribute__((aligned(16))) float Xs[BK * TN];
+    constexpr int NIMG = PREC == 1 ? 2 : 1;                                            // hi (+ lo) images
+    constexpr int LDD = TM * 2 + (TM >= 64 ? 64 : 0), LDX = TN * 2 + (TN >= 64 ? 64 : 0);   // bf16 image row bytes
+    constexpr int D_BYTES = PREC == 0 ? BK * TM * 4 : NIMG * BK * LDD;
+    constexpr int X_BYTES = PREC == 0 ? BK * TN * 4 : NIMG * BK * LDX;
+    static_assert(PREC == 0 || (BK / WK) % 16 == 0, "bf16 modes need 16 pixel rows per wave and step");
+    __shared__ __attribute__((aligned(16))) unsigned char Dsm[D_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char Xsm[X_BYTES];
+    float* Ds = reinterpret_cast<float*>(Dsm);
+    float* Xs = reinterpret_cast<float*>(Xsm);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci_tiles = (p.Cin + TN - 1) / TN;
@@ -671,11 +695,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
             while (xoy[j] >= p.Ho) { xoy[j] -= p.Ho; ++xn[j]; }
         }
     };
+    auto put_bf16 = [&](unsigned char* img, int ld, int r, int c4, float4 v) {
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(img + r * ld + 2 * c4) = h;
+        if constexpr (PREC == 1) {
+            bf16x4 l;
+            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+            l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+            *reinterpret_cast<bf16x4*>(img + BK * ld + r * ld + 2 * c4) = l;
+        }
+    };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int j = 0; j < DPASS; ++j) {
             const int r = drow + j * DRPP;
-            if (r < BK) *reinterpret_cast<float4*>(&Ds[r * TM + dc4]) = rd[j];
+            if (r < BK) {
+                if constexpr (PREC == 0) *reinterpret_cast<float4*>(&Ds[r * TM + dc4]) = rd[j];
+                else put_bf16(Dsm, LDD, r, dc4, rd[j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < XPASS; ++j) {
@@ -685,7 +723,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
-            if (r < BK) *reinterpret_cast<float4*>(&Xs[r * TN + xc4]) = v;
+            if (r < BK) {
+                if constexpr (PREC == 0) *reinterpret_cast<float4*>(&Xs[r * TN + xc4]) = v;
+                else put_bf16(Xsm, LDX, r, xc4, v);
+            }
         }
     };
 
@@ -708,18 +749,50 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         __syncthreads();
         for (int mb = mbeg; mb < mend; mb += BK) {
             if (mb + BK < mend) load_tiles(mb + BK);
+            if constexpr (PREC == 0) {
 #pragma unroll
-            for (int kp = 0; kp < KPW / 2; ++kp) {
-                const int k = wk * KPW + kp * 2 + fh;
-                float a[MT], b[NT];
+                for (int kp = 0; kp < KPW / 2; ++kp) {
+                    const int k = wk * KPW + kp * 2 + fh;
+                    float a[MT], b[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = Ds[k * TM + wm + i * 32 + fr];
+                    for (int i = 0; i < MT; ++i) a[i] = Ds[k * TM + wm + i * 32 + fr];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = Xs[k * TN + wn + j * 32 + fr];
+                    for (int j = 0; j < NT; ++j) b[j] = Xs[k * TN + wn + j * 32 + fr];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KPW / 16; ++ks) {
+                    const int k0 = wk * KPW + ks * 16 + 8 * fh;
+                    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        ah[i] = lds_tr_frag(Dsm, LDD, k0, wm + i * 32, lane);
+                        if constexpr (PREC == 1) al[i] = lds_tr_frag(Dsm + BK * LDD, LDD, k0, wm + i * 32, lane);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        bh[j] = lds_tr_frag(Xsm, LDX, k0, wn + j * 32, lane);
+                        if constexpr (PREC == 1) bl[j] = lds_tr_frag(Xsm + BK * LDX, LDX, k0, wn + j * 32, lane);
+                    }
+                    if constexpr (PREC == 1) {
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
             }
             __syncthreads();
             if (mb + BK < mend) {
@@ -755,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         }
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int MODE>
+template <int TM, int TN, int WM, int WN, int WK, int MODE, int PREC = 0>
 static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     WgradP p = p0;
     const int tiles = (int)(uem_cdiv(p.Cout, TM) * p.KH * p.KW * uem_cdiv(p.Cin, TN));
@@ -780,8 +853,8 @@ static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     splits = (int)uem_cdiv(p.M, rps);
     p.rows_per_split = rps;
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
-    if (affine) conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, true><<<grid, 256, 0, st>>>(p);
-    else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false><<<grid, 256, 0, st>>>(p);
+    if (affine) conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, true, PREC><<<grid, 256, 0, st>>>(p);
+    else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false, PREC><<<grid, 256, 0, st>>>(p);
 }
 
 extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift, float* dw,
@@ -798,10 +871,20 @@ extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in
     p.Cout = s->Cout; p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.x_ld = s->x_ld; p.dy_ld = s->y_ld; p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0; p.rows_per_split = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (s->Cout % 128 == 0 && s->Cin % 128 == 0) wgrad_go<128, 128, 2, 2, 1, 0>(p, affine, st);
-    else if (s->Cout % 64 == 0 && s->Cin % 64 == 0) wgrad_go<64, 64, 2, 2, 1, 0>(p, affine, st);
-    else if (s->Cin % 128 == 0) wgrad_go<32, 128, 1, 4, 1, 0>(p, affine, st);
-    else wgrad_go<32, 32, 1, 1, 4, 0>(p, affine, st);
+    const int prec = (flags & UEM_CONV_PREC_BF16X3) ? 1 : ((flags & UEM_CONV_PREC_BF16) ? 2 : 0);
+    if (s->Cout % 128 == 0 && s->Cin % 128 == 0) {
+        if (prec == 1) wgrad_go<128, 128, 2, 2, 1, 0, 1>(p, affine, st);
+        else if (prec == 2) wgrad_go<128, 128, 2, 2, 1, 0, 2>(p, affine, st);
+        else wgrad_go<128, 128, 2, 2, 1, 0>(p, affine, st);
+    } else if (s->Cout % 64 == 0 && s->Cin % 64 == 0) {
+        if (prec == 1) wgrad_go<64, 64, 2, 2, 1, 0, 1>(p, affine, st);
+        else if (prec == 2) wgrad_go<64, 64, 2, 2, 1, 0, 2>(p, affine, st);
+        else wgrad_go<64, 64, 2, 2, 1, 0>(p, affine, st);
+    } else if (s->Cin % 128 == 0) {
+        if (prec == 1) wgrad_go<32, 128, 1, 4, 1, 0, 1>(p, affine, st);
+        else if (prec == 2) wgrad_go<32, 128, 1, 4, 1, 0, 2>(p, affine, st);
+        else wgrad_go<32, 128, 1, 4, 1, 0>(p, affine, st);
+    } else wgrad_go<32, 32, 1, 1, 4, 0>(p, affine, st);      // tiny filters: always exact fp32
     return uem_check_launch("conv2d_wgrad");
 }
 

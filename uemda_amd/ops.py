@@ -20,15 +20,18 @@ FUSE_BN_BACKWARD = os.environ.get("UEM_FUSE_BN_BACKWARD", "1") != "0"
 # matrix-core precision of the forward / data-gradient convolutions.  "fp32" (default) is the exact fp32 MFMA and is
 # what every parity statement is made for; "bf16x3" (split hi/lo operands, three bf16 MFMAs, fp32 accumulate) and
 # "bf16" are opt-in experiments: set_conv_precision() or UEM_CONV_PREC.
-_PREC_FLAGS = {"fp32": 0, "bf16x3": _lib.CONV_PREC_BF16X3, "bf16": _lib.CONV_PREC_BF16}
-CONV_PREC = _PREC_FLAGS[os.environ.get("UEM_CONV_PREC", "fp32")]
+# "mixed" = exact fp32 forward (logits, BN statistics and pseudo-labels unchanged) + bf16x3 data/weight gradients
+# (4e-6 per conv, far below the 1-2 % ReLU-mask noise floor of fp32 gradients).
+_PREC_FLAGS = {"fp32": (0, 0), "bf16x3": (_lib.CONV_PREC_BF16X3,) * 2, "bf16": (_lib.CONV_PREC_BF16,) * 2,
+               "mixed": (0, _lib.CONV_PREC_BF16X3)}
+CONV_PREC, CONV_PREC_BWD = _PREC_FLAGS[os.environ.get("UEM_CONV_PREC", "fp32")]
 
 
 def set_conv_precision(name):
-    global CONV_PREC
+    global CONV_PREC, CONV_PREC_BWD
     if name not in _PREC_FLAGS:
         raise UemError(f"conv precision must be one of {sorted(_PREC_FLAGS)}, got {name!r}")
-    CONV_PREC = _PREC_FLAGS[name]
+    CONV_PREC, CONV_PREC_BWD = _PREC_FLAGS[name]
 
 
 def stream():
@@ -173,7 +176,7 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     s.x_ld, s.y_ld = cin, cout
     if out is None:
         out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
-    flags = CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0) | CONV_PREC
+    flags = CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0) | CONV_PREC_BWD
     flops = 2.0 * n * dy.shape[1] * dy.shape[2] * (algo_cout or cout) * kh * kw * cin
     PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_fwd", ptr(dy), ptr(w_t), None, None, None, ptr(out),
                                                ctypes.byref(s), flags, stream()))
@@ -205,7 +208,7 @@ def conv2d_dgrad_bn_backward(dy, w_t, z, st, gamma_grad, beta_grad, stride=1, pa
         raise UemError("conv2d_dgrad_bn_backward: BNState vectors must live in one (4, C) buffer")
     flops = 2.0 * n * dy.shape[1] * dy.shape[2] * cout * kh * kw * cin
     PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_dgrad_bnbwd", ptr(dy), ptr(w_t), ptr(da), ctypes.byref(s), ptr(z),
-                                               ptr(vec), ptr(tp), CONV_PREC, stream()))
+                                               ptr(vec), ptr(tp), CONV_PREC_BWD, stream()))
     tmp = torch.empty((2, cin), device=dy.device, dtype=torch.float32)
     call("uem_bn_bwd_from_tiles", ptr(tp), tiles, cin, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
     call("uem_bn_bwd_apply", ptr(z), ptr(da), None, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
@@ -222,7 +225,7 @@ def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift
     s = _shape(x, cout, kh, kw, stride, pad, dil)
     if (s.Ho, s.Wo) != (dy.shape[1], dy.shape[2]):
         raise UemError("conv2d_wgrad: dy spatial size mismatch")
-    flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0) | CONV_PREC
+    flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0) | CONV_PREC_BWD
     flops = 2.0 * s.N * s.Ho * s.Wo * (algo_cout or cout) * kh * kw * cin
     PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad", ptr(x), ptr(dy), ptr(in_scale), ptr(in_shift),
                                                ptr(dw_ohwi), ctypes.byref(s), flags, stream()))
