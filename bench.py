@@ -117,9 +117,17 @@ def main():
         pre = int(stop_steps / 20)
         return lr_warmup(HYPER["lr"], i, pre) if i < pre else lr_poly(HYPER["lr"], i, stop_steps * 1.5, 0.9)
 
-    def one_step(i):
+    marks = []                                    # (phase name, HIP event) of the last timed step
+
+    def mark(name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((name, ev))
+
+    def one_step(i, marked=False):
         if args.workload == "ssl":
-            return ssl_step(model, aligner, opt, state, batch, lr_at(i + 1), dp=wrapper, sup_ignore_id=sup_ignore)
+            return ssl_step(model, aligner, opt, state, batch, lr_at(i + 1), dp=wrapper, sup_ignore_id=sup_ignore,
+                            mark=mark if marked else None)
         return src_step(model, opt, state, batch, lr_at(i + 1), dp=wrapper)
 
     def barrier():
@@ -137,7 +145,7 @@ def main():
         # per-launch HIP events (the `roofline` leg) are recorded during the LAST timed step only: 660 event
         # records per step put ~10 ms of command-processor bubbles into a 160 ms step when left on throughout
         ops.PROF.enabled = (not args.no_kernel_events) and i == args.steps - 1
-        out = one_step(args.warmup + i)
+        out = one_step(args.warmup + i, marked=(i == args.steps - 1))
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
@@ -207,6 +215,14 @@ def main():
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }
+        if marks:
+            # per-phase wall time of the last timed step (HIP events on the compute stream) and, for the HBM-bound
+            # phases, algorithmic bytes (SURVEY 8d per-tile figures x tiles) over that time
+            ph = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
+            mb = {"label_refine_select": 25.2 * B, "prototype_update": 10.5 * B, "losses_forward": (8.4 + 2.1) * B,
+                  "clip_sgd": 5 * 4 * model.flat_parameters()[2] / 1e6}
+            line["phases_ms"] = ph
+            line["phases_hbm_GBps"] = {k: round(v / 1e3 / (ph[k] * 1e-3), 1) for k, v in mb.items() if ph.get(k, 0) > 0}
         if others:
             line["other_precisions"] = others
         if world == 1 and not args.no_cpu_baseline:

@@ -203,20 +203,20 @@ int uem_proto_ema(const float* sums, const float* counts, float* protos, int k, 
 /* ---- losses: bilinear(align_corners=True) upsample + CE / UVEM, forward AND backward in one pass -------
  * logits are low-res (B,h,w,C); the full-resolution logits are never materialised.
  * CE (tools.py:240-254 + balance.py:88-101): loss = mean over ALL pixels of CE(ignore);
- *   dlogits (B,h,w,C) receives d(loss*loss_scale)/dlogits (gather form: written, not accumulated,
- *   deterministic).  partial: >= 4*uem_loss_blocks(B,h,w) + 4 floats of workspace.                */
+ *   dlogits (B,h,w,C) receives d(loss*loss_scale)/dlogits (written, not accumulated).
+ *   workspace: >= uem_loss_workspace_floats(B,C,h,w) floats.                                      */
 int uem_ce_upsampled(const float* logits1, const float* logits2 /* NULL: one head */, const int64_t* label,
                      const float* pixel_weight /* NULL */, float* loss_out /* [1] = mean over heads */,
-                     float* dlogits1, float* dlogits2, float* partial, int B, int C, int h, int w, int H, int W,
+                     float* dlogits1, float* dlogits2, float* workspace, int B, int C, int h, int w, int H, int W,
                      int64_t ignore_label, float loss_scale, void* stream);
 /* UVEM (balance.py:356-423,437-451): u = entropy(soft); gate u>t; weight w(u); CE on `hard`;
  *   loss = sum(w*ce) / (#{u<=t & hard!=ignore} + 1e-7).  One call handles BOTH heads (logits2 may
  *   be NULL): loss_out[0] = mean over heads; dlogits1/2 get the gradient of loss*loss_scale.      */
 int uem_uvem_upsampled(const float* logits1, const float* logits2, const int64_t* hard, const float* soft,
                        const float* pixel_weight /* NULL */, float* loss_out, float* dlogits1,
-                       float* dlogits2, float* partial, int B, int C, int h, int w, int H, int W,
+                       float* dlogits2, float* workspace, int B, int C, int h, int w, int H, int W,
                        float m, float t, float gamma, int64_t ignore_label, float loss_scale, void* stream);
-int uem_loss_blocks(int B, int h, int w); /* = B*h*w: one gather block per low-res cell */
+int64_t uem_loss_workspace_floats(int B, int C, int h, int w); /* per-band gradient images + loss partials */
 /* a[i] *= *scalar (and b[i] when b != NULL); scalar lives on the device (no host sync)             */
 int uem_scale_by_scalar(float* a, float* b, int64_t n, const float* scalar, void* stream);
 /* eval-mode output: (softmax(up(x1)) + softmax(up(x2)))/2 -> NCHW prob        Encoder.py:153-155   */

@@ -79,7 +79,7 @@ SIGNATURES = {
     "uem_proto_ema": [P, P, P, I, I, F, P],
     "uem_ce_upsampled": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, F, P],
     "uem_uvem_upsampled": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, L, F, P],
-    "uem_loss_blocks": [I, I, I],
+    "uem_loss_workspace_floats": [I, I, I, I],
     "uem_scale_by_scalar": [P, P, L, P, P],
     "uem_upsample_softmax_avg": [P, P, P, I, I, I, I, I, I, P],
     "uem_uvem_weight": [P, P, L, F, F, F, P],
@@ -98,7 +98,8 @@ SIGNATURES = {
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
 }
 _RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64,
-            "uem_label_refine_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64}
+            "uem_label_refine_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64,
+            "uem_loss_workspace_floats": c_int64}
 
 # compile-time constants mirrored from the header
 UEM_MAX_CLASSES = 16

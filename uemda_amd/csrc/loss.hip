@@ -1,8 +1,7 @@
 // Fused "bilinear upsample (align_corners=True) + per-pixel loss" kernels, forward AND backward in
-// one pass, in GATHER form: one block per low-resolution logit cell walks the <=34x34 window of
-// full-resolution pixels whose interpolation touches that cell, recomputes their softmax, and
-// reduces the cell's gradient in registers/LDS -- no atomics, deterministic, and the (B,C,H,W)
-// upsampled logits are never materialised.
+// one pass: one block per band of full-resolution rows that interpolate between the same two
+// low-resolution logit rows; every pixel is evaluated once, the gradient of the band's two logit rows
+// is reduced in registers + LDS, and the (B,C,H,W) upsampled logits are never materialised.
 // Reference: uemda/utils/tools.py:240-254 (loss_calc), uemda/gast/balance.py:81-101 (CrossEntropy),
 //            uemda/gast/balance.py:356-423,437-451 (UVEMLoss, loss_calc_uvem).
 #include "common.h"
@@ -57,116 +56,173 @@ __device__ __forceinline__ float uvem_weight_dev(float u, float m, float t, floa
     return (u >= t) ? 0.f : wgt;
 }
 
-// window of destination indices whose lerp can touch source cell `i`
-__device__ __forceinline__ void cell_window(int i, int in_size, int out_size, int& lo, int& hi) {
-    if (in_size <= 1 || out_size <= 1) { lo = 0; hi = out_size - 1; return; }
-    const float inv = (float)(out_size - 1) / (float)(in_size - 1);
-    lo = (int)floorf((float)(i - 1) * inv) - 1;
-    hi = (int)ceilf((float)(i + 1) * inv) + 1;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > out_size - 1 ? out_size - 1 : hi;
-}
-
-// MODE 0: CE (mean over all pixels), MODE 1: UVEM.  NH = number of heads handled (1 or 2).
+// MODE 0: CE (mean over all pixels), MODE 1: UVEM.
+// One block per (image, low-resolution row `cy`): it owns the BAND of full-resolution rows whose upper
+// interpolation row is cy (~(H-1)/(h-1) rows), so every pixel is evaluated exactly once, reading label / soft-label
+// rows coalesced.  A thread walks one pixel column down the band; its pixels all interpolate between the same four
+// logit cells (rows cy, cy+1 x columns i0x, i1x), so the gradient is summed in registers over the column (y weights
+// applied per pixel), then added with the two x weights into a per-wave LDS image of the band's two logit rows
+// (LDS atomics; per-wave images summed in fixed order).  Band cy's second row and band cy+1's first row are the
+// same logit row: the bands' images go to the workspace and loss_band_combine_kernel adds the pair.
+#define LOSS_THREADS 256
+#define LOSS_WAVES (LOSS_THREADS / 64)
 template <int CMAX, int MODE>
-__global__ __launch_bounds__(256) void loss_gather_kernel(
+__global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
     const float* __restrict__ lg1, const float* __restrict__ lg2, const int64_t* __restrict__ label,
-    const float* __restrict__ soft, const float* __restrict__ pixw, float* __restrict__ dl1, float* __restrict__ dl2,
-    float* __restrict__ partial, int C, int h, int w, int H, int W, float um, float ut, float inv_gamma,
-    int64_t ignore, float coef) {
-    const int cell = blockIdx.x;
-    const int cx = cell % w, cy = (cell / w) % h, b = cell / (w * h);
+    const float* __restrict__ soft, const float* __restrict__ pixw, float* __restrict__ band_grad,
+    float* __restrict__ partial, int C, int h, int w, int H, int W, float um, float ut, float inv_gamma, int64_t ignore) {
+    extern __shared__ __attribute__((aligned(16))) float loss_sm[];
+    float* low = loss_sm;                              // [2 heads][2 rows][w][CMAX]
+    float* acc = loss_sm + 4 * w * CMAX;               // [LOSS_WAVES][2 rows][w][2 heads][CMAX]
+    const int cy = blockIdx.x % h, b = blockIdx.x / h;
+    const int cy1 = cy + (cy < h - 1 ? 1 : 0);
     const size_t plane = (size_t)H * W;
-    int ylo, yhi, xlo, xhi;
-    cell_window(cy, h, H, ylo, yhi);
-    cell_window(cx, w, W, xlo, xhi);
-    const int ww = xhi - xlo + 1, wh = yhi - ylo + 1;
-    const float* l1b = lg1 + (size_t)b * h * w * C;
-    const float* l2b = lg2 ? lg2 + (size_t)b * h * w * C : nullptr;
-    // every pixel that touches this cell interpolates inside the 3x3 cell neighbourhood: stage it in LDS once
-    __shared__ float nb[2][3][3][CMAX];
-    for (int i = threadIdx.x; i < 2 * 9 * CMAX; i += 256) {
-        const int c = i % CMAX, q = (i / CMAX) % 9, hd = i / (9 * CMAX);
-        const int yy = cy - 1 + q / 3, xx = cx - 1 + q % 3;
-        const float* src = hd ? l2b : l1b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * w * CMAX; i += LOSS_THREADS) {
+        const int c = i % CMAX, x = (i / CMAX) % w, r = (i / (CMAX * w)) & 1, hd = i / (2 * CMAX * w);
+        const float* src = hd ? lg2 : lg1;
         float v = 0.f;
-        if (src != nullptr && c < C && yy >= 0 && yy < h && xx >= 0 && xx < w) v = src[((size_t)yy * w + xx) * C + c];
-        nb[hd][q / 3][q % 3][c] = v;
+        if (src != nullptr && c < C) v = src[(((size_t)b * h + (r ? cy1 : cy)) * w + x) * C + c];
+        low[i] = v;
     }
+    for (int i = tid; i < LOSS_WAVES * 4 * w * CMAX; i += LOSS_THREADS) acc[i] = 0.f;
     __syncthreads();
-    float g1[CMAX], g2[CMAX];
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) g1[c] = g2[c] = 0.f;
+    // candidate rows of the band (a superset; rows whose i0 differs are skipped)
+    int ya = 0, yb = H - 1;
+    if (h > 1 && H > 1) {
+        const float inv = (float)(H - 1) / (float)(h - 1);
+        ya = (int)floorf((float)cy * inv) - 1;
+        yb = (int)ceilf((float)(cy + 1) * inv) + 1;
+        ya = ya < 0 ? 0 : ya;
+        yb = yb > H - 1 ? H - 1 : yb;
+    }
+    // exact row range of the band inside the candidate window
+    while (ya <= yb && lerp_setup(ya, h, H, true).i0 != cy) ++ya;
+    while (yb >= ya && lerp_setup(yb, h, H, true).i0 != cy) --yb;
+    float* wacc = acc + (size_t)wave * 4 * w * CMAX;
     float loss1 = 0.f, loss2 = 0.f, valid = 0.f;
-    for (int i = threadIdx.x; i < ww * wh; i += 256) {
-        const int Y = ylo + i / ww, X = xlo + i % ww;
-        const Lerp ly = lerp_setup(Y, h, H, true), lx = lerp_setup(X, w, W, true);
-        const float wy = (ly.i0 == cy ? ly.l0 : 0.f) + (ly.i1 == cy ? ly.l1 : 0.f);
-        const float wx = (lx.i0 == cx ? lx.l0 : 0.f) + (lx.i1 == cx ? lx.l1 : 0.f);
-        const bool touches = (ly.i0 == cy || ly.i1 == cy) && (lx.i0 == cx || lx.i1 == cx);
-        if (!touches) continue;
-        const bool owner = (ly.i0 == cy) && (lx.i0 == cx);       // forward value counted once
-        const size_t p = (size_t)Y * W + X;
-        const int64_t lab64 = label[(size_t)b * plane + p];
-        const bool lab_ok = (lab64 != ignore) && lab64 >= 0 && lab64 < C;
-        const int lab = lab_ok ? (int)lab64 : -1;
-        float pw = 1.0f;      // per-pixel coefficient on (softmax - onehot)
-        if (MODE == 1) {
-            float u = 0.f;
+    struct Px { int64_t lab; float q[CMAX]; float pw; };
+    for (int X = tid; X < W; X += LOSS_THREADS) {
+        const Lerp lx = lerp_setup(X, w, W, true);
+        const float* L00 = low + (size_t)lx.i0 * CMAX;                 // head 0, row 0
+        const float* L01 = low + (size_t)lx.i1 * CMAX;
+        // x-interpolated logits of the band's two rows (constant down the column): top/bot [head][class]
+        float top[2][CMAX], bot[2][CMAX];
+        float a0[2][CMAX], a1[2][CMAX];                                // [band row][class] for head 0 / head 1
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < C) { float q = soft[((size_t)b * C + c) * plane + p]; u += -q * logf(q); }
-            const bool gate = !(u > ut);                          // ce[u > t] = 0
-            pw = gate ? uvem_weight_dev(u, um, ut, inv_gamma) : 0.f;
-            if (owner && (u <= ut) && lab64 != ignore) valid += 1.f;
+        for (int c = 0; c < CMAX; ++c) {
+            a0[0][c] = a0[1][c] = a1[0][c] = a1[1][c] = 0.f;
+            top[0][c] = lx.l0 * L00[c] + lx.l1 * L01[c];
+            bot[0][c] = lx.l0 * L00[w * CMAX + c] + lx.l1 * L01[w * CMAX + c];
+            top[1][c] = lx.l0 * L00[2 * w * CMAX + c] + lx.l1 * L01[2 * w * CMAX + c];
+            bot[1][c] = lx.l0 * L00[3 * w * CMAX + c] + lx.l1 * L01[3 * w * CMAX + c];
         }
-        if (pixw) pw *= pixw[(size_t)b * plane + p];
-        if (!lab_ok) pw = 0.f;                                    // ignore_index: zero loss and gradient
-        float v[CMAX], ce;
-        const int ry0 = ly.i0 - cy + 1, ry1 = ly.i1 - cy + 1, rx0 = lx.i0 - cx + 1, rx1 = lx.i1 - cx + 1;
+        auto fetch = [&](int Y, Px& px) {
+            const size_t p = (size_t)b * plane + (size_t)Y * W + X;
+            px.lab = label[p];
+            if (MODE == 1) {
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-            if (c < C) v[c] = ly.l0 * (lx.l0 * nb[0][ry0][rx0][c] + lx.l1 * nb[0][ry0][rx1][c]) +
-                              ly.l1 * (lx.l0 * nb[0][ry1][rx0][c] + lx.l1 * nb[0][ry1][rx1][c]);
-        softmax_ce<CMAX>(v, C, lab, ce);
-        if (owner) loss1 += pw * ce;
-        const float k1 = pw * wy * wx;
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) px.q[c] = soft[((size_t)b * C + c) * plane + (size_t)Y * W + X];
+            }
+            px.pw = pixw ? pixw[p] : 1.0f;
+        };
+        Px cur, nxt;
+        if (ya <= yb) fetch(ya, cur);
+        for (int Y = ya; Y <= yb; ++Y) {
+            if (Y < yb) fetch(Y + 1, nxt);                            // next row's loads fly during this row's math
+            const Lerp ly = lerp_setup(Y, h, H, true);
+            const int64_t lab64 = cur.lab;
+            const bool lab_ok = (lab64 != ignore) && lab64 >= 0 && lab64 < C;
+            const int lab = lab_ok ? (int)lab64 : -1;
+            float pw = 1.0f;      // per-pixel coefficient on (softmax - onehot)
+            if (MODE == 1) {
+                float u = 0.f;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) g1[c] += k1 * (v[c] - (c == lab ? 1.f : 0.f));
-        if (l2b) {
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) { const float q = cur.q[c]; u += -q * logf(q); }
+                const bool gate = !(u > ut);                          // ce[u > t] = 0
+                pw = gate ? uvem_weight_dev(u, um, ut, inv_gamma) : 0.f;
+                if ((u <= ut) && lab64 != ignore) valid += 1.f;
+            }
+            pw *= cur.pw;
+            if (!lab_ok) pw = 0.f;                                    // ignore_index: zero loss and gradient
+            float v[CMAX], ce;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c)
-                if (c < C) v[c] = ly.l0 * (lx.l0 * nb[1][ry0][rx0][c] + lx.l1 * nb[1][ry0][rx1][c]) +
-                                  ly.l1 * (lx.l0 * nb[1][ry1][rx0][c] + lx.l1 * nb[1][ry1][rx1][c]);
+                if (c < C) v[c] = ly.l0 * top[0][c] + ly.l1 * bot[0][c];
             softmax_ce<CMAX>(v, C, lab, ce);
-            if (owner) loss2 += pw * ce;
+            loss1 += pw * ce;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) if (c < C) g2[c] += k1 * (v[c] - (c == lab ? 1.f : 0.f));
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) { const float g = pw * (v[c] - (c == lab ? 1.f : 0.f)); a0[0][c] += ly.l0 * g; a0[1][c] += ly.l1 * g; }
+            if (lg2) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) v[c] = ly.l0 * top[1][c] + ly.l1 * bot[1][c];
+                softmax_ce<CMAX>(v, C, lab, ce);
+                loss2 += pw * ce;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) { const float g = pw * (v[c] - (c == lab ? 1.f : 0.f)); a1[0][c] += ly.l0 * g; a1[1][c] += ly.l1 * g; }
+            }
+            cur = nxt;
         }
-    }
-    // block reduction: wave shuffles, then 4 waves through LDS
-    __shared__ float red[4][2 * CMAX + 3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
-        float a = wave_sum(g1[c]), d = wave_sum(g2[c]);
-        if (lane == 0) { red[wave][c] = a; red[wave][CMAX + c] = d; }
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c >= C) continue;
+                float* q0 = wacc + ((size_t)(r * w + lx.i0) * 2) * CMAX + c;
+                float* q1 = wacc + ((size_t)(r * w + lx.i1) * 2) * CMAX + c;
+                atomicAdd(q0, lx.l0 * a0[r][c]);
+                atomicAdd(q1, lx.l1 * a0[r][c]);
+                if (lg2) {
+                    atomicAdd(q0 + CMAX, lx.l0 * a1[r][c]);
+                    atomicAdd(q1 + CMAX, lx.l1 * a1[r][c]);
+                }
+            }
     }
+    __shared__ float red[LOSS_WAVES][3];
     {
-        float a = wave_sum(loss1), d = wave_sum(loss2), e = wave_sum(valid);
-        if (lane == 0) { red[wave][2 * CMAX] = a; red[wave][2 * CMAX + 1] = d; red[wave][2 * CMAX + 2] = e; }
+        const float a = wave_sum(loss1), d = wave_sum(loss2), e = wave_sum(valid);
+        if (lane == 0) { red[wave][0] = a; red[wave][1] = d; red[wave][2] = e; }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * CMAX + 3) {
-        const int j = threadIdx.x;
-        const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-        if (j < CMAX) { if (j < C) dl1[(size_t)cell * C + j] = s * coef; }
-        else if (j < 2 * CMAX) { if (dl2 && (j - CMAX) < C) dl2[(size_t)cell * C + (j - CMAX)] = s * coef; }
-        else partial[(size_t)cell * 4 + (j - 2 * CMAX)] = s;
+    float* out = band_grad + (size_t)blockIdx.x * 4 * w * CMAX;       // [2 rows][w][2 heads][CMAX]
+    for (int i = tid; i < 4 * w * CMAX; i += LOSS_THREADS) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < LOSS_WAVES; ++k) t += acc[(size_t)k * 4 * w * CMAX + i];      // fixed order
+        out[i] = t;
+    }
+    if (tid < 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < LOSS_WAVES; ++k) t += red[k][tid];
+        partial[(size_t)blockIdx.x * 4 + tid] = t;
     }
 }
 
-// single block: ordered (deterministic) reduction of the per-cell partials
+// dlogits[b][r][x][c] = coef * (*scale) * (band r's first row + band r-1's second row [+ the last band's own second row])
+template <int CMAX>
+__global__ void loss_band_combine_kernel(const float* __restrict__ band_grad, float* __restrict__ dl1, float* __restrict__ dl2,
+                                         int B, int C, int h, int w, float coef, const float* __restrict__ scale) {
+    const int64_t n = (int64_t)B * h * w * C;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C), x = (int)((i / C) % w), r = (int)((i / ((int64_t)C * w)) % h), b = (int)(i / ((int64_t)C * w * h));
+    const float f = scale ? coef * scale[0] : coef;
+    const size_t band = (size_t)4 * w * CMAX;
+    const float* g = band_grad + ((size_t)b * h + r) * band;
+    const size_t o0 = ((size_t)(0 * w + x) * 2) * CMAX + c, o1 = ((size_t)(1 * w + x) * 2) * CMAX + c;
+    float s1 = g[o0], s2 = g[o0 + CMAX];
+    if (r > 0) { s1 += (g - band)[o1]; s2 += (g - band)[o1 + CMAX]; }
+    if (r == h - 1) { s1 += g[o1]; s2 += g[o1 + CMAX]; }            // the last band's rows cy and cy+1 coincide
+    dl1[i] = s1 * f;
+    if (dl2) dl2[i] = s2 * f;
+}
+
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int cells, int mode,
                                                             int nheads, float ce_denominator, float* __restrict__ loss_out,
                                                             float* __restrict__ inv_valid) {
@@ -203,58 +259,71 @@ __global__ void scale_by_device_scalar_kernel(float* __restrict__ a, float* __re
     }
 }
 
-extern "C" int uem_loss_blocks(int B, int h, int w) { return B * h * w; }
+static inline int loss_cmax(int C) { return C <= 4 ? 4 : (C <= 6 ? 6 : (C <= 8 ? 8 : 16)); }
+extern "C" int64_t uem_loss_workspace_floats(int B, int C, int h, int w) {
+    const int cmax = loss_cmax(C);
+    return (int64_t)B * h * 4 * w * cmax + (int64_t)B * h * 4 + 4;
+}
 extern "C" int uem_scale_by_scalar(float* a, float* b, int64_t n, const float* scalar, void* stream) {
     UEM_REQUIRE(a && scalar && n > 0, "scale_by_scalar: bad arguments");
     scale_by_device_scalar_kernel<<<(int)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, scalar);
     return uem_check_launch("scale_by_scalar");
 }
 
+template <int CMAX, int MODE>
+static void loss_launch(const float* l1, const float* l2, const int64_t* label, const float* soft, const float* pixw,
+                        float* loss_out, float* d1, float* d2, float* ws, int B, int C, int h, int w, int H, int W, float m,
+                        float t, float inv_gamma, int64_t ignore, float coef, float ce_denominator, hipStream_t st) {
+    const int bands = B * h, nheads = l2 ? 2 : 1;
+    float* band_grad = ws;
+    float* partial = ws + (size_t)bands * 4 * w * CMAX;
+    float* inv_valid = partial + (size_t)bands * 4;
+    const size_t lds = (size_t)(4 + 4 * LOSS_WAVES) * w * CMAX * sizeof(float);
+    auto k = loss_band_kernel<CMAX, MODE>;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
+    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, bands, MODE, nheads, ce_denominator, loss_out, MODE ? inv_valid : nullptr);
+    const int64_t n = (int64_t)B * h * w * C;
+    loss_band_combine_kernel<CMAX><<<(int)uem_cdiv(n, 256), 256, 0, st>>>(band_grad, d1, d2, B, C, h, w, coef,
+                                                                          MODE ? inv_valid : nullptr);
+}
+
 extern "C" int uem_ce_upsampled(const float* logits1, const float* logits2, const int64_t* label,
                                 const float* pixel_weight, float* loss_out, float* dlogits1, float* dlogits2,
-                                float* partial, int B, int C, int h, int w, int H, int W, int64_t ignore_label,
+                                float* workspace, int B, int C, int h, int w, int H, int W, int64_t ignore_label,
                                 float loss_scale, void* stream) {
-    UEM_REQUIRE(logits1 && label && loss_out && dlogits1 && partial, "ce_upsampled: null pointer");
+    UEM_REQUIRE(logits1 && label && loss_out && dlogits1 && workspace, "ce_upsampled: null pointer");
     UEM_REQUIRE(!logits2 || dlogits2, "ce_upsampled: dlogits2 required with logits2");
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w, "ce_upsampled: bad shape");
+    UEM_REQUIRE((size_t)(4 + 4 * LOSS_WAVES) * w * 16 * sizeof(float) <= 160 * 1024, "ce_upsampled: low-resolution width %d too large", w);
     hipStream_t st = (hipStream_t)stream;
-    const int cells = B * h * w;
     const int nheads = logits2 ? 2 : 1;
     // mean over ALL pixels, ignored ones included in the denominator (balance.py:97-101)
     const float denom = (float)B * (float)H * (float)W;
     const float coef = loss_scale / denom / (float)nheads;
-    if (C <= 8)
-        loss_gather_kernel<8, 0><<<cells, 256, 0, st>>>(logits1, logits2, label, nullptr, pixel_weight, dlogits1, dlogits2,
-                                                        partial, C, h, w, H, W, 0.f, 0.f, 0.f, ignore_label, coef);
-    else
-        loss_gather_kernel<16, 0><<<cells, 256, 0, st>>>(logits1, logits2, label, nullptr, pixel_weight, dlogits1, dlogits2,
-                                                         partial, C, h, w, H, W, 0.f, 0.f, 0.f, ignore_label, coef);
-    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, cells, 0, nheads, denom, loss_out, nullptr);
+#define CE_GO(CM) loss_launch<CM, 0>(logits1, logits2, label, nullptr, pixel_weight, loss_out, dlogits1, dlogits2, workspace, B, C, \
+                                     h, w, H, W, 0.f, 0.f, 0.f, ignore_label, coef, denom, st)
+    switch (loss_cmax(C)) { case 4: CE_GO(4); break; case 6: CE_GO(6); break; case 8: CE_GO(8); break; default: CE_GO(16); }
+#undef CE_GO
     return uem_check_launch("ce_upsampled");
 }
 
 extern "C" int uem_uvem_upsampled(const float* logits1, const float* logits2, const int64_t* hard, const float* soft,
                                   const float* pixel_weight, float* loss_out, float* dlogits1, float* dlogits2,
-                                  float* partial, int B, int C, int h, int w, int H, int W, float m, float t, float gamma,
+                                  float* workspace, int B, int C, int h, int w, int H, int W, float m, float t, float gamma,
                                   int64_t ignore_label, float loss_scale, void* stream) {
-    UEM_REQUIRE(logits1 && hard && soft && loss_out && dlogits1 && partial, "uvem_upsampled: null pointer");
+    UEM_REQUIRE(logits1 && hard && soft && loss_out && dlogits1 && workspace, "uvem_upsampled: null pointer");
     UEM_REQUIRE(!logits2 || dlogits2, "uvem_upsampled: dlogits2 required with logits2");
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w, "uvem_upsampled: bad shape");
     UEM_REQUIRE(gamma > 0.f && t > 0.f, "uvem_upsampled: bad hyper-parameters");
+    UEM_REQUIRE((size_t)(4 + 4 * LOSS_WAVES) * w * 16 * sizeof(float) <= 160 * 1024, "uvem_upsampled: low-resolution width %d too large", w);
     hipStream_t st = (hipStream_t)stream;
-    const int cells = B * h * w;
     const int nheads = logits2 ? 2 : 1;
-    const float coef = loss_scale / (float)nheads;       // 1/(valid+eps) applied after the count is known
-    if (C <= 8)
-        loss_gather_kernel<8, 1><<<cells, 256, 0, st>>>(logits1, logits2, hard, soft, pixel_weight, dlogits1, dlogits2,
-                                                        partial, C, h, w, H, W, m, t, 1.0f / gamma, ignore_label, coef);
-    else
-        loss_gather_kernel<16, 1><<<cells, 256, 0, st>>>(logits1, logits2, hard, soft, pixel_weight, dlogits1, dlogits2,
-                                                         partial, C, h, w, H, W, m, t, 1.0f / gamma, ignore_label, coef);
-    float* inv_valid = partial + (size_t)cells * 4;      // one extra float behind the partials
-    loss_finalize_kernel<<<1, 256, 0, st>>>(partial, cells, 1, nheads, 1.f, loss_out, inv_valid);
-    const int64_t n = (int64_t)cells * C;
-    scale_by_device_scalar_kernel<<<(int)uem_cdiv(n, 256), 256, 0, st>>>(dlogits1, logits2 ? dlogits2 : nullptr, n, inv_valid);
+    const float coef = loss_scale / (float)nheads;       // 1/(valid+eps) is applied by the combine pass, once the count is known
+#define UV_GO(CM) loss_launch<CM, 1>(logits1, logits2, hard, soft, pixel_weight, loss_out, dlogits1, dlogits2, workspace, B, C, h, w, \
+                                     H, W, m, t, 1.0f / gamma, ignore_label, coef, 1.f, st)
+    switch (loss_cmax(C)) { case 4: UV_GO(4); break; case 6: UV_GO(6); break; case 8: UV_GO(8); break; default: UV_GO(16); }
+#undef UV_GO
     return uem_check_launch("uvem_upsampled");
 }
 

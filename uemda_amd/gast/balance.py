@@ -10,12 +10,12 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from .. import ops
+from .. import _lib, ops
 from ..ops import UemError, call, ptr, stream
 
 
-def _loss_ws(B, h, w, dev):
-    return torch.empty(4 * B * h * w + 4, device=dev, dtype=torch.float32)
+def _loss_ws(B, C, h, w, dev):
+    return torch.empty(_lib.load().uem_loss_workspace_floats(B, C, h, w), device=dev, dtype=torch.float32)
 
 
 class _FusedLossFn(Function):
@@ -34,7 +34,7 @@ class _FusedLossFn(Function):
         loss = torch.empty((1,), device=dev, dtype=torch.float32)
         d1 = torch.empty_like(l1)
         d2 = torch.empty_like(l2) if l2 is not None else None
-        ws = _loss_ws(B, h, w, dev)
+        ws = _loss_ws(B, C, h, w, dev)
         pw = pixel_weight.contiguous() if pixel_weight is not None else None
         if mode == "ce":
             call("uem_ce_upsampled", ptr(l1), ptr(l2), ptr(label), ptr(pw), ptr(loss), ptr(d1), ptr(d2), ptr(ws),

@@ -21,23 +21,34 @@ class StepState:
                                   ignore_label=hp["ignore_label"])
 
 
-def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None):
+def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None, mark=None):
+    """`mark(name)`, if given, is called at the phase boundaries (bench.py records a HIP event there)."""
     hp = state.hp
+    mark = mark or (lambda name: None)
     model.train()
     optimizer.param_groups[0]["lr"] = lr
+    mark("start")
     pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # :205
+    mark("forward_source")
     pred_t1, pred_t2, feat_t = model(batch["images_t"])                         # :207
+    mark("forward_target")
     soft, hard = aligner.refine_and_select(batch["label_t_sup"], feat_t, [pred_t1, pred_t2], batch["label_t_soft"],
                                            mode=hp["refine_mode"], temp=hp["refine_temp"], cutoff_top=hp["cutoff_top"],
                                            cutoff_low=hp["cutoff_low"], sup_ignore_id=sup_ignore_id)   # :209-214
+    mark("label_refine_select")
     label_ds = aligner.update_prototype(feat_s, batch["label_s"])               # :216
+    mark("prototype_update")
     loss_source = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :219
     loss_target = loss_calc_uvem([pred_t1, pred_t2], hard, soft, loss_fn=state.loss_fn_t, multi=True)    # :221
     loss = loss_source + loss_target
+    mark("losses_forward")
     optimizer.zero_grad()
     loss.backward()
+    mark("backward")
     prescale = dp.reduce_gradients() if dp is not None else 1.0
+    mark("grad_allreduce_wait")
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)             # :230-232 (clip 32 + SGD)
+    mark("clip_sgd")
     return dict(loss_source=loss_source.detach(), loss_target=loss_target.detach(), label_t_soft=soft,
                 label_t_hard=hard, label_s_ds=label_ds, pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
                 pred_t1=pred_t1.detach(), pred_t2=pred_t2.detach(), feat_s=feat_s.detach(), feat_t=feat_t.detach(),
