@@ -437,7 +437,8 @@ template <int BN_, int WM_, int WN_, int MODE, int NBUF, int PREC>
 static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
     const size_t a_sz = PREC == 0 ? (size_t)BM * LDS_LD : (size_t)BM * LDS_LDH;
     const size_t b_sz = PREC == 0 ? (size_t)BN_ * LDS_LD : (size_t)BN_ * LDS_LDH;
-    size_t lds = (size_t)NBUF * (a_sz + b_sz) * sizeof(float);
+    static const int lds_pad = getenv("UEM_CONV_LDS_PAD") ? atoi(getenv("UEM_CONV_LDS_PAD")) : 0;   // occupancy experiments
+    size_t lds = (size_t)NBUF * (a_sz + b_sz) * sizeof(float) + (size_t)lds_pad;
     if (affine) lds += (size_t)2 * p.Cin * sizeof(float);
     if (affine) {
         auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, true, NBUF, PREC>;
@@ -832,19 +833,24 @@ template <int TM, int TN, int WM, int WN, int WK, int MODE, int PREC = 0>
 static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     WgradP p = p0;
     const int tiles = (int)(uem_cdiv(p.Cout, TM) * p.KH * p.KW * uem_cdiv(p.Cin, TN));
-    // split-K sizing: ~2048 blocks fill the chip, but every split adds one fp32-atomic pass over the whole
-    // filter bank (chip-wide atomic rate 1.3 TB/s).  With few output tiles that pass dominates (measured: 60 %
-    // of the kernel at 16 tiles x 128 splits), so there the split count is capped at M/1536 (atomics ~10 % of
-    // the MFMA time) but never below what yields 512 blocks.
+    // split-K sizing.  The grid is sized to whole ROUNDS of the chip's resident-block slots (256 CUs x blocks per CU
+    // at this tile's register footprint): equal-work blocks run in lock step, so 2048 blocks on 768 slots take 3
+    // rounds at 89 % fill while 2304 take the same 3 rounds with 12 % less work each (+8 % on the 3x3 layers).
+    // Every split adds one fp32-atomic pass over the whole filter bank (chip-wide atomic rate 1.3 TB/s); with few
+    // output tiles that pass dominates (measured: 60 % of the kernel at 16 tiles x 128 splits), so there the number
+    // of rounds is limited to what keeps >= ~1024 pixel rows per split.
     static const int forced = getenv("UEM_WGRAD_SPLITS") ? atoi(getenv("UEM_WGRAD_SPLITS")) : 0;
+    static const int forced_rounds = getenv("UEM_WGRAD_ROUNDS") ? atoi(getenv("UEM_WGRAD_ROUNDS")) : 0;
+    constexpr int BLOCKS_PER_CU = TM * TN >= 128 * 128 ? 3 : (TM * TN >= 32 * 128 ? 4 : 6);
+    const int slots = 256 * BLOCKS_PER_CU;
     const int max_splits = (int)uem_cdiv(p.M, 4 * BK);
-    int splits = (int)uem_cdiv(2048, tiles);
+    int rounds = 3;
     if (tiles <= 32) {
-        int cap = p.M / 1536;
-        const int floor_splits = (int)uem_cdiv(512, tiles);
-        if (cap < floor_splits) cap = floor_splits;
-        if (splits > cap) splits = cap;
+        rounds = (int)((int64_t)p.M * tiles / 1024 / slots);
+        rounds = rounds < 1 ? 1 : (rounds > 3 ? 3 : rounds);
     }
+    if (forced_rounds > 0) rounds = forced_rounds;
+    int splits = slots * rounds / tiles;
     if (forced > 0) splits = forced;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
