@@ -51,6 +51,10 @@ def test_conv_forward_dgrad_wgrad(case):
     torch.testing.assert_close(nchw(y), y_ref.detach(), rtol=1e-4, atol=1e-4)
     dx = ops.conv2d_dgrad(nhwc(gy), ops.weight_transpose(ohwi(w.detach())), (N, H, W, Cin), stride=s, pad=p, dil=d)
     torch.testing.assert_close(nchw(dx), x.grad, rtol=1e-4, atol=1e-4)
+    # accumulate epilogue of the data gradient (residual sum; strided convs skip the parity classes no tap reaches)
+    dx2 = ops.conv2d_dgrad(nhwc(gy), ops.weight_transpose(ohwi(w.detach())), (N, H, W, Cin), stride=s, pad=p, dil=d,
+                           out=dx.clone(), accumulate=True)
+    torch.testing.assert_close(nchw(dx2), 2 * x.grad, rtol=1e-4, atol=2e-4)
     dw = torch.zeros(Cout, k, k, Cin, device="cuda")
     ops.conv2d_wgrad(nhwc(x.detach()), nhwc(gy), dw, stride=s, pad=p, dil=d)
     torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), w.grad, rtol=1e-4, atol=2e-4 * gy.numel() ** 0.5 / 16)

@@ -555,6 +555,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
                     ++p.ntaps;
                 }
             }
+            if (p.ntaps == 0 && p.accumulate) continue;       // class reached by no tap: adds zero (1x1 stride 2: 3 of 4)
             p.M = s->N * p.Hs * p.Ws;
             rc = conv_launch<1>(p, false, (hipStream_t)stream, prec);
             if (rc) return rc;
