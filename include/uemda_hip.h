@@ -109,21 +109,25 @@ int uem_bn_stats_from_tiles(const float* tile_stats, int tiles, int M, int C, co
 int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
 /* y = act(x*scale + shift (+ r)); r = res, or res*res_scale + res_shift (downsample branch BN) when
- * res_scale != NULL; act = relu if relu != 0.  In place allowed (y == x).                         */
+ * res_scale != NULL; act = relu if relu != 0.  In place allowed (y == x).  relu_bits (optional, C % 32 == 0,
+ * M*C/32 words): bit (e & 31) of word e >> 5 = [y_e > 0], e = row*C + c -- the 1/32-size ReLU mask the backward
+ * passes read with relu = UEM_RELU_BITS instead of re-reading y.                                  */
 int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
                    const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
-                   void* stream);
-/* backward of y = relu?(bn(x) (+res)):  given dy (grad wrt y).  relu mask: (ymask > 0) when ymask (the
- * materialised y) is given, else (x*scale+shift > 0) recomputed (operand-prologue layers).
+                   uint32_t* relu_bits, void* stream);
+#define UEM_RELU_BITS 2
+/* backward of y = relu?(bn(x) (+res)):  given dy (grad wrt y).  relu mask: relu == 1: (ymask > 0) when ymask (the
+ * materialised y, float) is given, else (x*scale+shift > 0) recomputed (operand-prologue layers); relu ==
+ * UEM_RELU_BITS: ymask is uem_affine_act's relu_bits.
  * pass 1: dgamma[c] = sum dp*xhat, dbeta[c] = sum dp   (dp = dy masked by relu)
  * pass 2: dx = scale*(dp - dbeta/M - xhat*dgamma/M);  dres (optional) = dp                         */
-int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+int uem_bn_bwd_reduce(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                       const float* save_mean, const float* save_invstd, int M, int C, int relu,
                       float* dgamma /* = */, float* dbeta /* = */, float* grad_gamma /* +=, may be NULL */,
                       float* grad_beta /* +=, may be NULL */, float* workspace, void* stream);
 int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* dgamma /* = */, float* dbeta /* = */,
                           float* grad_gamma /* += or NULL */, float* grad_beta /* += or NULL */, void* stream);
-int uem_bn_bwd_apply(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
 /* eval-mode / frozen-stat backward: dx = dp * scale                                              */

@@ -86,6 +86,8 @@ def test_forward_is_deterministic_and_step_is_finite_at_b32(big_batch):
     al.prototypes = big_batch["prototypes"].clone()
     opt = FusedSGD(model, 1e-2, 0.9, 5e-4)
     out = ssl_step(model, al, opt, StepState(C), big_batch, 1e-3, sup_ignore_id=1024)
-    assert torch.isfinite(out["loss_source"]) and torch.isfinite(out["loss_target"]) and torch.isfinite(out["grad_norm"]).all()
     arena, garena, n = model.flat_parameters()
+    bad = [name for name, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    assert not bad, f"non-finite gradients in {bad[:8]} ({len(bad)} tensors)"
+    assert torch.isfinite(out["loss_source"]) and torch.isfinite(out["loss_target"]) and torch.isfinite(out["grad_norm"]).all()
     assert torch.isfinite(arena[:n]).all() and torch.isfinite(garena[:n]).all()

@@ -147,9 +147,14 @@ def test_batchnorm_stats_apply_backward(Cn, M):
     gg, gb = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
     pre = F.batch_norm(x.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5)
     away = pre.abs() > 1e-4            # a pre-activation within rounding of the ReLU kink may flip its mask
-    for ymask in (None, y):                               # recomputed mask and materialised mask agree
+    y2, bits = ops.affine_act(xd, st, relu=True, want_bits=True)          # packed sign bits (C % 32 == 0 here)
+    assert torch.equal(y2, y)
+    expect = (y.reshape(-1, 32) > 0).to(torch.int64) << torch.arange(32, device="cuda")
+    assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, expect.sum(1))
+    for ymask in (None, y, bits):                         # recomputed, materialised and bit-packed masks agree
         gg.zero_(), gb.zero_()
-        dx = ops.bn_backward(xd, gy.cuda(), st, gg, gb, ymask=ymask, relu=True)
+        kw = dict(ymask_bits=bits) if ymask is bits else dict(ymask=ymask)
+        dx = ops.bn_backward(xd, gy.cuda(), st, gg, gb, relu=True, **kw)
         torch.testing.assert_close(dx.cpu()[away], x.grad[away], rtol=1e-3, atol=1e-4)
         assert away.float().mean() > 0.999
         torch.testing.assert_close(gg.cpu(), gamma.grad, rtol=5e-3, atol=1e-3)   # a flipped mask moves one channel's sum

@@ -240,8 +240,12 @@ extern "C" int uem_bn_eval_affine(const float* gamma, const float* beta, const f
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const float* __restrict__ res,
                                                          const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                         float* __restrict__ y, int64_t nvec, int C, int relu) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+                                                         float* __restrict__ y, int64_t nvec, int C, int relu,
+                                                         uint32_t* __restrict__ bits) {
+    // `bits` (optional; needs nvec % 8 == 0): one bit per element, bit (e & 31) of word e >> 5 = [y_e > 0].  The
+    // backward passes read these 1/32-size words instead of the materialised output.
+    const int64_t nloop = bits ? (nvec + 7) / 8 * 8 : nvec;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nloop; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
         float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
@@ -258,23 +262,41 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = v;
+        if (bits) {
+            // 8 consecutive lanes hold the 32 elements of one word (i is lane-aligned: grid stride is a multiple of 256)
+            uint32_t m = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            m <<= 4 * (threadIdx.x & 7);
+            m |= __shfl_xor(m, 1);
+            m |= __shfl_xor(m, 2);
+            m |= __shfl_xor(m, 4);
+            if ((threadIdx.x & 7) == 0) bits[i >> 3] = m;
+        }
     }
 }
 extern "C" int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
                               const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
-                              void* stream) {
+                              uint32_t* relu_bits, void* stream) {
     UEM_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && (C % 4) == 0, "affine_act: bad arguments");
+    UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act: relu_bits needs C %% 32 == 0 (C=%d)", C);
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act: bad residual affine");
     const int64_t nvec = M * C / 4;
-    affine_act_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu);
+    affine_act_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     return uem_check_launch("affine_act");
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm backward (training stats).  dp = dy * [relu mask];  xhat = (x - mean) * invstd
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 relu_mask4(float4 dy, float4 x, float4 sc, float4 sh, const float* ymask, size_t off) {
+// relu: 1 = mask from the materialised output `ymask` (float) or, without it, from x*scale+shift recomputed;
+//       2 (UEM_RELU_BITS) = `ymask` points at the packed sign bits written by uem_affine_act
+__device__ __forceinline__ float4 relu_mask4(float4 dy, float4 x, float4 sc, float4 sh, const float* ymask, size_t off,
+                                             int relu = 1) {
     float4 pre;
+    if (relu == 2) {
+        const uint32_t m = reinterpret_cast<const uint32_t*>(ymask)[off >> 5] >> (off & 31);
+        dy.x = (m & 1u) ? dy.x : 0.f; dy.y = (m & 2u) ? dy.y : 0.f; dy.z = (m & 4u) ? dy.z : 0.f; dy.w = (m & 8u) ? dy.w : 0.f;
+        return dy;
+    }
     if (ymask) pre = *reinterpret_cast<const float4*>(ymask + off);       // materialised relu output
     else { pre.x = x.x * sc.x + sh.x; pre.y = x.y * sc.y + sh.y; pre.z = x.z * sc.z + sh.z; pre.w = x.w * sc.w + sh.w; }
     dy.x = pre.x > 0.f ? dy.x : 0.f; dy.y = pre.y > 0.f ? dy.y : 0.f;
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const size_t off = (size_t)r * C + cm.c0;
         const float4 xv = *reinterpret_cast<const float4*>(x + off);
         float4 d = *reinterpret_cast<const float4*>(dy + off);
-        if (relu) d = relu_mask4(d, xv, sc, sh, res, off);
+        if (relu) d = relu_mask4(d, xv, sc, sh, res, off, relu);
         sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
         sg.x += d.x * ((xv.x - mu.x) * is.x); sg.y += d.y * ((xv.y - mu.y) * is.y);
         sg.z += d.z * ((xv.z - mu.z) * is.z); sg.w += d.w * ((xv.w - mu.w) * is.w);
@@ -359,16 +381,17 @@ extern "C" int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int 
     bn_bwd_tiles_finalize_kernel<<<C, 64, 0, (hipStream_t)stream>>>(tile_partials, tiles, C, dgamma, dbeta, grad_gamma, grad_beta);
     return uem_check_launch("bn_bwd_from_tiles");
 }
-extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                                  const float* save_mean, const float* save_invstd, int M, int C, int relu, float* dgamma,
                                  float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
     UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce: null pointer");
     UEM_REQUIRE(M > 0 && col_shape_ok(C), "bn_bwd_reduce: unsupported shape M=%d C=%d", M, C);
+    UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "bn_bwd_reduce: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     hipStream_t st = (hipStream_t)stream;
     int chunks, rpc;
     col_chunks(M, C, &chunks, &rpc);
     dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
-    bn_bwd_partial_kernel<<<grid, 256, 0, st>>>(x, dy, ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
+    bn_bwd_partial_kernel<<<grid, 256, 0, st>>>(x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
     bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta, grad_gamma, grad_beta);
     return uem_check_launch("bn_bwd_reduce");
 }
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float4 xv = *reinterpret_cast<const float4*>(x + off);
         float4 d = *reinterpret_cast<const float4*>(dy + off);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-        if (relu) d = relu_mask4(d, xv, sc, *reinterpret_cast<const float4*>(shift + c), res, off);
+        if (relu) d = relu_mask4(d, xv, sc, *reinterpret_cast<const float4*>(shift + c), res, off, relu);
         if (dres) *reinterpret_cast<float4*>(dres + off) = d;
         const float4 mu = *reinterpret_cast<const float4*>(smean + c);
         const float4 is = *reinterpret_cast<const float4*>(sinv + c);
@@ -398,14 +421,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         *reinterpret_cast<float4*>(dx + off) = o;
     }
 }
-extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
+extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                                 const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
                                 int M, int C, int relu, float* dx, float* dres, void* stream) {
     UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && dx, "bn_bwd_apply: null pointer");
     UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad shape");
+    UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "bn_bwd_apply: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = (int64_t)M * C / 4;
     bn_bwd_apply_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
-        x, dy, ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
+        x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
     return uem_check_launch("bn_bwd_apply");
 }
 __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,

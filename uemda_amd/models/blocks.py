@@ -100,19 +100,22 @@ class BottleneckFn(Function):
                                 in_shift=st1.shift, in_relu=True)
         z3, st3 = ops.conv2d_bn(z2, W(blk.conv3.weight), blk.bn3, in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
         has_ds = blk.downsample is not None
+        need_bwd = any(ctx.needs_input_grad) and ops.RELU_BITS
         if has_ds:
             zd, std = ops.conv2d_bn(x, W(blk.downsample[0].weight), blk.downsample[1], stride=s)
-            y = ops.affine_act(z3, st3, res=zd, res_st=std, relu=True)
+            y = ops.affine_act(z3, st3, res=zd, res_st=std, relu=True, want_bits=need_bwd)
         else:
             zd, std = None, None
-            y = ops.affine_act(z3, st3, res=x, relu=True)
+            y = ops.affine_act(z3, st3, res=x, relu=True, want_bits=need_bwd)
+        y, ybits = y if need_bwd else (y, None)
         if blk.bn1.training:
             blk._nbt_add()
         if any(ctx.needs_input_grad):
             ctx.blk = blk
             ctx.has_ds = has_ds
             ctx.training = st1.training
-            saved = [x, y, z1, z2, z3, _st_tensor(st1), _st_tensor(st2), _st_tensor(st3)]
+            # the ReLU mask of the block output travels as packed bits (1/32 of y): y itself is not read in backward
+            saved = [x, ybits if ybits is not None else y, z1, z2, z3, _st_tensor(st1), _st_tensor(st2), _st_tensor(st3)]
             if has_ds:
                 saved += [zd, _st_tensor(std)]
             ctx.save_for_backward(*saved)
@@ -122,14 +125,15 @@ class BottleneckFn(Function):
     def backward(ctx, dy):
         blk = ctx.blk
         sv = ctx.saved_tensors
-        x, y, z1, z2, z3 = sv[:5]
+        x, ybits, z1, z2, z3 = sv[:5]
         st1, st2, st3 = (_st_from(b, ctx.training) for b in sv[5:8])
         s, d = blk.stride, blk.dilation
         W, G, gb = ops.weight_ohwi, grad_ohwi, grad_buffer
         dy = dy.contiguous()
         # BN3 + residual + ReLU: mask from the materialised output y; dp = grad of the pre-ReLU sum
         dp = torch.empty_like(dy)
-        dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), ymask=y, relu=True, dres=dp)
+        kw = dict(ymask_bits=ybits) if ybits.dtype == torch.int32 else dict(ymask=ybits)
+        dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=True, dres=dp, **kw)
         ops.conv2d_wgrad(z2, dz3, G(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
         dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose(W(blk.conv3.weight)), z2, st2, gb(blk.bn2.weight),
                                            gb(blk.bn2.bias))

@@ -17,6 +17,7 @@ BN_MOMENTUM = 0.1
 # epilogue fusions (on by default; the switches exist for A/B measurements)
 FUSE_BN_STATS = os.environ.get("UEM_FUSE_BN_STATS", "1") != "0"
 FUSE_BN_BACKWARD = os.environ.get("UEM_FUSE_BN_BACKWARD", "1") != "0"
+RELU_BITS = os.environ.get("UEM_RELU_BITS", "1") != "0"      # block-output ReLU mask saved as packed bits
 # matrix-core precision of the forward / data-gradient convolutions.  "fp32" (default) is the exact fp32 MFMA and is
 # what every parity statement is made for; "bf16x3" (split hi/lo operands, three bf16 MFMAs, fp32 accumulate) and
 # "bf16" are opt-in experiments: set_conv_precision() or UEM_CONV_PREC.
@@ -300,28 +301,33 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=BN_EPS, mo
     return st
 
 
-def affine_act(x, st, res=None, res_st=None, relu=True, out=None):
+def affine_act(x, st, res=None, res_st=None, relu=True, out=None, want_bits=False):
+    """y = relu?(x*scale + shift (+ res [*res_scale + res_shift])).  want_bits: also return the packed sign bits of y
+    (int32 words, 1/32 of y) that bn_backward(ymask_bits=...) reads instead of y."""
     C = x.shape[-1]
     out = torch.empty_like(x) if out is None else out
+    bits = torch.empty(x.numel() // 32, device=x.device, dtype=torch.int32) if want_bits else None
     call("uem_affine_act", ptr(x), ptr(st.scale), ptr(st.shift), ptr(res),
          ptr(res_st.scale) if res_st is not None else None, ptr(res_st.shift) if res_st is not None else None,
-         ptr(out), x.numel() // C, C, 1 if relu else 0, stream())
-    return out
+         ptr(out), x.numel() // C, C, 1 if relu else 0, ptr(bits), stream())
+    return (out, bits) if want_bits else out
 
 
-def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None, dres=None):
+def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None, dres=None, ymask_bits=None):
     """BatchNorm(+ReLU) backward.  Accumulates into gamma_grad/beta_grad; returns dx (may alias dy)."""
     C = x.shape[-1]
     M = x.numel() // C
     dx = torch.empty_like(x) if dx is None else dx
+    if ymask_bits is not None:
+        ymask, relu = ymask_bits, 2          # UEM_RELU_BITS
     if st.training:
         tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
         ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
         call("uem_bn_bwd_reduce", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
-             ptr(st.invstd), M, C, 1 if relu else 0, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws),
+             ptr(st.invstd), M, C, int(relu), ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws),
              stream())
         call("uem_bn_bwd_apply", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
-             ptr(st.invstd), ptr(tmp[0]), ptr(tmp[1]), M, C, 1 if relu else 0, ptr(dx), ptr(dres), stream())
+             ptr(st.invstd), ptr(tmp[0]), ptr(tmp[1]), M, C, int(relu), ptr(dx), ptr(dres), stream())
     else:
         # frozen statistics (eval-mode BN inside a graph): dx = dp * scale; dgamma/dbeta via the reduce
         raise UemError("backward through eval-mode BatchNorm is not supported (reference never does it)")
