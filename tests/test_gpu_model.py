@@ -428,3 +428,33 @@ def test_cpu_tensors_fail_loudly():
     from uemda_amd.gast.pseudo_generation import pseudo_selection
     with pytest.raises(UemError):
         pseudo_selection(torch.rand(1, C, 8, 8), return_type="tensor")
+
+
+def test_ragged_batch_and_tile_size_ssl_step_vs_oracle():
+    """Odd batch (3), non-square 144x208 tiles (9x13 feature map: no GEMM dimension is a multiple of the 128-row
+    tile, the fused BatchNorm epilogues fall back to the stand-alone passes): one SSL step against the oracle."""
+    from oracle import synth
+    from oracle.model import OracleDeeplabv2
+    from oracle.step import HYPER as OH, SGDState, ssl_step as oracle_ssl
+    from oracle.weights import det_state_dict
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    sd = det_state_dict("resnet50", C, False, seed=2333)
+    bc = synth.make_batch(B=3, H=144, W=208, C=C, k=2048, seed=77)
+    om = OracleDeeplabv2(sd, "resnet50", C, False)
+    ref = oracle_ssl(om, SGDState(om.parameters(), 0.9, 5e-4), bc["prototypes"], bc, 2e-3, OH)
+    model = _model(False)
+    b = {k: v.cuda() for k, v in bc.items()}
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    al.prototypes = b["prototypes"].clone()
+    out = ssl_step(model, al, FusedSGD(model, 1e-2, 0.9, 5e-4), StepState(C), b, 2e-3)
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        err = (out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()
+        assert err < 1e-3, (k, float(err))
+    assert (out["label_t_hard"].cpu() == ref["label_t_hard"]).float().mean() >= 0.9995
+    torch.testing.assert_close(out["label_t_soft"].cpu(), ref["label_t_soft"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_source"].cpu(), ref["loss_source"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_target"].cpu(), ref["loss_target"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(al.prototypes.cpu(), ref["prototypes"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), ref["grad_norm"].reshape(()), rtol=2e-2, atol=1e-4)
