@@ -440,6 +440,11 @@ static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
     static const int lds_pad = getenv("UEM_CONV_LDS_PAD") ? atoi(getenv("UEM_CONV_LDS_PAD")) : 0;   // occupancy experiments
     size_t lds = (size_t)NBUF * (a_sz + b_sz) * sizeof(float) + (size_t)lds_pad;
     if (affine) lds += (size_t)2 * p.Cin * sizeof(float);
+    // 769..1024 blocks of the 128x128 tile are 4 per CU: at 3 resident blocks they run as 3 + 1 (the last one alone,
+    // nothing hiding its load/store phases), at 2 resident blocks as 2 + 2.  Unused LDS caps the residency at 2
+    // (layer2 shapes +4..15 %, layer4 shapes +-2 %).
+    static const int occ2 = getenv("UEM_CONV_OCC2") ? atoi(getenv("UEM_CONV_OCC2")) : 1;
+    if (occ2 && BN_ == 128 && PREC == 0 && NBUF == 1 && grid > 768 && grid <= 1024 && lds < 56 * 1024) lds = 56 * 1024;
     if (affine) {
         auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, true, NBUF, PREC>;
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
