@@ -60,13 +60,13 @@ typedef struct {
 int uem_conv2d_fwd(const float* x, const float* w, const float* bias, const float* in_scale,
                    const float* in_shift, float* y, const uem_conv_shape* s, int flags, void* stream);
 /* same forward conv, and the epilogue also leaves the per-128-row-tile column sums of y and y*y in
- * tile_stats[M/128][2][Cout] (fused BatchNorm statistics: saves the stand-alone pass over y).  Needs
+ * tile_stats[2][Cout][M/128] (fused BatchNorm statistics: saves the stand-alone pass over y).  Needs
  * M % 128 == 0 and Cout % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise: use uem_bn_stats).                   */
 int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift, float* y,
                          const uem_conv_shape* s, int flags, float* tile_stats, void* stream);
 /* data gradient of a stride-1 conv (dx = dA of the producing layer) whose epilogue also computes the first pass
  * of that layer's BatchNorm+ReLU backward: with bn_z = the layer's raw conv output (N,H,W,Cin) and bn_vec =
- * (4,Cin) [scale, shift, mean, invstd], tile_partials[M/128][2][Cin] receives per-tile sums of dp = dA*[relu mask]
+ * (4,Cin) [scale, shift, mean, invstd], tile_partials[2][Cin][M/128] receives per-tile sums of dp = dA*[relu mask]
  * and dp*xhat (replaces uem_bn_bwd_reduce's pass over z and dA).  s describes the FORWARD conv; flags may carry
  * a UEM_CONV_PREC_* bit only.                                                                            */
 int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* bn_z,

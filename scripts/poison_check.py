@@ -16,13 +16,16 @@ from uemda_amd.optim import FusedSGD
 from uemda_amd.step import HYPER, StepState, ssl_step
 
 
+PATTERN = float("nan")
+
+
 def poison(gib):
     blocks = []
-    for size_mb in (2048, 512, 128, 32, 8, 2):
-        n = max(1, int(gib * 1024 / 6 / size_mb))
+    for size_mb in (4096, 2048, 512, 128, 32, 8, 2):
+        n = max(1, int(gib * 1024 / 7 / size_mb))
         for _ in range(n):
-            blocks.append(torch.full((size_mb * 1024 * 256,), float("nan"), device="cuda"))
-    small = [torch.full((k,), float("nan"), device="cuda") for k in (16, 64, 256, 1024, 4096, 65536) for _ in range(64)]
+            blocks.append(torch.full((size_mb * 1024 * 256,), PATTERN, device="cuda"))
+    small = [torch.full((k,), PATTERN, device="cuda") for k in (16, 64, 256, 1024, 4096, 65536) for _ in range(64)]
     del blocks, small                       # back to the caching allocator, contents intact
 
 
@@ -33,7 +36,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--poison-gib", type=float, default=60.0)
     ap.add_argument("--head", default="aspp")
+    ap.add_argument("--pattern", type=float, default=float("nan"),
+                    help="fill value: NaN is swallowed by fmaxf-style ReLUs, a huge finite value (1e30) is not")
     args = ap.parse_args()
+    global PATTERN
+    PATTERN = args.pattern
     C, B, S = 6, args.batch, args.size
     torch.manual_seed(0)
     cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,

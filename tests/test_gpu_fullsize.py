@@ -85,9 +85,30 @@ def test_forward_is_deterministic_and_step_is_finite_at_b32(big_batch):
     al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
     al.prototypes = big_batch["prototypes"].clone()
     opt = FusedSGD(model, 1e-2, 0.9, 5e-4)
-    out = ssl_step(model, al, opt, StepState(C), big_batch, 1e-3, sup_ignore_id=1024)
-    arena, garena, n = model.flat_parameters()
+    # first the step's pieces by hand, so that a non-finite value is caught where it appears (the fused clip+SGD
+    # would spread one NaN over every gradient through the clip coefficient)
+    from uemda_amd.gast.balance import loss_calc_uvem
+    from uemda_amd.utils.tools import loss_calc
+    state = StepState(C)
+    model.train()
+    ps1, ps2, fs = model(big_batch["images_s"])
+    pt1, pt2, ft = model(big_batch["images_t"])
+    soft, hard = al.refine_and_select(big_batch["label_t_sup"], ft, [pt1, pt2], big_batch["label_t_soft"], mode="all", temp=2.0,
+                                      cutoff_top=0.8, cutoff_low=0.6, sup_ignore_id=1024)
+    seen = {}
+    for name, t in (("pred_s1", ps1), ("pred_s2", ps2), ("pred_t1", pt1), ("pred_t2", pt2), ("feat_s", fs), ("feat_t", ft)):
+        assert torch.isfinite(t).all(), name
+        t.register_hook(lambda g, name=name: seen.__setitem__(name, bool(torch.isfinite(g).all())))
+    loss = loss_calc([ps1, ps2], big_batch["label_s"], loss_fn=state.loss_fn_s, multi=True) + \
+        loss_calc_uvem([pt1, pt2], hard, soft, loss_fn=state.loss_fn_t, multi=True)
+    opt.zero_grad()
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(soft).all()
+    assert all(seen.values()) and len(seen) >= 4, f"non-finite gradient w.r.t. {[k for k, v in seen.items() if not v]}"
     bad = [name for name, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
-    assert not bad, f"non-finite gradients in {bad[:8]} ({len(bad)} tensors)"
+    assert not bad, f"non-finite gradients (before the clip) in {bad[:8]} ({len(bad)} tensors)"
+    al.prototypes = big_batch["prototypes"].clone()
+    out = ssl_step(model, al, opt, state, big_batch, 1e-3, sup_ignore_id=1024)
+    arena, garena, n = model.flat_parameters()
     assert torch.isfinite(out["loss_source"]) and torch.isfinite(out["loss_target"]) and torch.isfinite(out["grad_norm"]).all()
     assert torch.isfinite(arena[:n]).all() and torch.isfinite(garena[:n]).all()

@@ -34,10 +34,10 @@ struct ConvP {
     int x_ld, y_ld;
     int accumulate;
     int relu;
-    float* tile_stats;     // optional [tiles_m][2][Cout]: per-128-row-tile column sums of y and y*y (fused BN statistics)
+    float* tile_stats;     // optional [2][Cout][tiles_m]: per-128-row-tile column sums of y and y*y (fused BN statistics)
     // data-gradient only: fused first pass of the BatchNorm(+ReLU) backward of the layer this gradient feeds.
     // y here is dA (grad wrt the post-ReLU activation); with z = that layer's raw conv output the epilogue also
-    // leaves per-tile column sums of dp = dA*[z*sc+sh > 0] and dp*xhat in tile_bnbwd[tiles_m][2][Cout].
+    // leaves per-tile column sums of dp = dA*[z*sc+sh > 0] and dp*xhat in tile_bnbwd[2][Cout][tiles_m].
     const float* bn_z;
     const float* bn_vec;   // (4, Cout): scale, shift, mean, invstd
     float* tile_bnbwd;
@@ -222,10 +222,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
 
-    if (KT > 0) {
-        load_tiles(0);
-        store_tiles(0);
-    }
+    if (KT > 0) load_tiles(0);
+    // the prologue operands in Ssc were written by other threads: they must be visible before the first store_tiles
+    // reads them (without this barrier a late wave 0 -- cold instruction cache on a kernel's first launch -- let the
+    // other waves transform the first k-tile with stale LDS contents)
+    if (AFFINE) __syncthreads();
+    if (KT > 0) store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = (NBUF == 2) ? (kt & 1) : 0;
@@ -368,9 +370,11 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
             __syncthreads();
         }
         if (p.tile_stats != nullptr && tid < BN) {
-            float* ts = p.tile_stats + (size_t)(m0 / BM) * 2 * p.Cout + n0 + tid;
+            // channel-major [2][Cout][tiles]: the per-channel finalize then streams contiguous rows
+            const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
+            float* ts = p.tile_stats + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
             ts[0] = cs1;
-            ts[p.Cout] = cs2;
+            ts[(size_t)p.Cout * tiles_m] = cs2;
         }
         if (MODE == 1 && p.tile_bnbwd != nullptr) {
             // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again)
@@ -382,9 +386,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
                 float b = 0.f, g = 0.f;
 #pragma unroll
                 for (int q = 0; q < RPP; ++q) { b += red[(0 * RPP + q) * BN + tid]; g += red[(1 * RPP + q) * BN + tid]; }
-                float* tb = p.tile_bnbwd + (size_t)(m0 / BM) * 2 * p.Cout + n0 + tid;
+                const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
+                float* tb = p.tile_bnbwd + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
                 tb[0] = b;
-                tb[p.Cout] = g;
+                tb[(size_t)p.Cout * tiles_m] = g;
             }
         }
         return;

@@ -59,3 +59,4 @@ extern "C" int uemdbg_mfma_rate(float* out, int blocks, int iters, int mode, voi
     else mfma_rate_kernel<2><<<blocks, 256, 0, st>>>(out, iters);
     return uem_check_launch("mfma_rate");
 }
+

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const float* __re
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
     }
 }
-// statistics from the conv epilogue's per-tile column sums: tile_stats[tile][0][c] = sum y, [tile][1][c] = sum y*y
+// statistics from the conv epilogue's per-tile column sums: tile_stats[0][c][tile] = sum y, [1][c][tile] = sum y*y
 // over the tile's `rows` rows; tiles are merged with the same Chan combination as the stand-alone path
 __global__ __launch_bounds__(64) void bn_stats_tiles_finalize_kernel(const float* __restrict__ ts, int tiles, int rows, int M, int C,
                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void bn_stats_tiles_finalize_kernel(const float
     const float nb = (float)rows;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int j = lane; j < tiles; j += 64) {
-        const float s1 = ts[(size_t)j * 2 * C + c], s2 = ts[(size_t)j * 2 * C + C + c];
+        const float s1 = ts[(size_t)c * tiles + j], s2 = ts[((size_t)C + c) * tiles + j];
         const float mb = s1 / nb;
         const float qb = fmaxf(s2 - s1 * mb, 0.f);
         if (n == 0.f) { n = nb; mean = mb; m2 = qb; }
@@ -359,13 +359,13 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
         if (acc_beta) acc_beta[c] += b;
     }
 }
-// dgamma / dbeta from the data-gradient epilogue's per-tile partials: tiles[tile][0][c] = sum dp, [tile][1][c] = sum dp*xhat
+// dgamma / dbeta from the data-gradient epilogue's per-tile partials: tiles[0][c][tile] = sum dp, [1][c][tile] = sum dp*xhat
 __global__ __launch_bounds__(64) void bn_bwd_tiles_finalize_kernel(const float* __restrict__ tp, int tiles, int C,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                    float* __restrict__ acc_gamma, float* __restrict__ acc_beta) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float b = 0.f, g = 0.f;
-    for (int j = lane; j < tiles; j += 64) { b += tp[(size_t)j * 2 * C + c]; g += tp[(size_t)j * 2 * C + C + c]; }
+    for (int j = lane; j < tiles; j += 64) { b += tp[(size_t)c * tiles + j]; g += tp[((size_t)C + c) * tiles + j]; }
     b = wave_sum(b);
     g = wave_sum(g);
     if (lane == 0) {

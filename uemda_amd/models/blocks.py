@@ -68,8 +68,7 @@ class StemFn(Function):
         a = ops.affine_act(z, st, relu=True)
         need = any(ctx.needs_input_grad)
         y, idx = ops.maxpool_fwd(a, need)
-        if resnet.bn1.training:
-            resnet.bn1.num_batches_tracked.add_(1)
+        ops.nbt_inc(resnet.bn1)
         if need:
             ctx.resnet = resnet
             ctx.training = st.training

@@ -42,13 +42,11 @@ class PPMHeadFn(Function):
             call("uem_bilinear_up_fwd", ptr(z), ptr(cat[..., cin + 512 * i:]), n, s, s, 512, h, w, ctot, 0,
                  ptr(st.scale), ptr(st.shift), 1, stream())
             saved_branch += [p, z, _st_tensor(st)]
-            if bn.training:
-                bn.num_batches_tracked.add_(1)
+            ops.nbt_inc(bn)
         conv0, bn0, drop, conv4 = head.conv_last[0], head.conv_last[1], head.conv_last[3], head.conv_last[4]
         zc = ops.conv2d(cat, ops.weight_ohwi(conv0.weight), pad=1)
         stc = _BN.stats(zc, bn0)
-        if bn0.training:
-            bn0.num_batches_tracked.add_(1)
+        ops.nbt_inc(bn0)
         a = ops.affine_act(zc, stc, relu=True)
         mask = None
         if training and drop.p > 0:

@@ -39,6 +39,13 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def nbt_inc(bn):
+    """num_batches_tracked += 1 of a training-mode BatchNorm, unless its counter lives in a model-level arena that
+    the model's forward bumps once for all layers (Deeplabv2._nbt_step)."""
+    if bn.training and not getattr(bn, "_uem_nbt_arena", False):
+        bn.num_batches_tracked.add_(1)
+
+
 class _Profiler:
     """Optional per-launch HIP-event timing of the conv kernels (bench.py's `roofline` leg).  Events are
     recorded on torch's current stream, which is the stream every kernel here is launched on."""
@@ -71,8 +78,35 @@ class _Profiler:
 PROF = _Profiler()
 
 
+# UEM_TRACE_NONFINITE=1: debugging aid -- after every entry-point call, synchronise and report which of the float
+# tensors handed to it (inputs and outputs) hold NaN/Inf.  The first call with clean inputs and a dirty output is
+# where a non-finite value is born.
+TRACE_NONFINITE = os.environ.get("UEM_TRACE_NONFINITE", "0") != "0"
+_trace_args = []
+_lib_call = call
+
+
 def ptr(t):
+    if TRACE_NONFINITE and t is not None:
+        _trace_args.append(t)
     return None if t is None else t.data_ptr()
+
+
+if TRACE_NONFINITE:
+    def call(name, *args):          # noqa: F811  (debug wrapper around _lib.call)
+        tensors = list(_trace_args)
+        _trace_args.clear()
+        rc = _lib_call(name, *args)
+        torch.cuda.synchronize()
+        dirty = []
+        for i, t in enumerate(tensors):
+            if t.is_floating_point() and t.numel() > 0 and not bool(torch.isfinite(t).all()):
+                bad = (~torch.isfinite(t)).reshape(-1)
+                first = int(bad.nonzero()[0])
+                dirty.append(f"arg{i}{tuple(t.shape)}: {int(bad.sum())} bad, first at flat index {first}")
+        if dirty:
+            print(f"[uem trace] {name}: non-finite in {dirty}", flush=True)
+        return rc
 
 
 def need_gpu(*tensors):

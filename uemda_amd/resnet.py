@@ -44,7 +44,7 @@ class Bottleneck(nn.Module):
 
     def _nbt_add(self):
         for bn in self._bns():
-            bn.num_batches_tracked.add_(1)
+            ops.nbt_inc(bn)
 
     def forward(self, x):                      # x: (N,H,W,C) dense NHWC
         return blocks.BottleneckFn.apply(x, self, *list(self.parameters()))
