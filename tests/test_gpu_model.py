@@ -458,3 +458,38 @@ def test_ragged_batch_and_tile_size_ssl_step_vs_oracle():
     torch.testing.assert_close(out["loss_target"].cpu(), ref["loss_target"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(al.prototypes.cpu(), ref["prototypes"], rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), ref["grad_norm"].reshape(()), rtol=2e-2, atol=1e-4)
+
+
+def test_resnet101_aspp_src_step_vs_oracle():
+    """BASELINE config 5's architecture (ResNet-101 encoder) on the train_src path: one source-only step at B=2,
+    128x128 against the oracle (forward logits, loss, gradient norm, a deep and a shallow weight update)."""
+    from oracle import synth
+    from oracle.model import OracleDeeplabv2
+    from oracle.step import HYPER as OH, SGDState, src_step as oracle_src
+    from oracle.weights import det_state_dict
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import StepState, src_step
+    cfg = dict(backbone=dict(resnet_type="resnet101", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    sd = det_state_dict("resnet101", C, False, seed=99)
+    names = ("layer5.conv2d_list.0.weight", "encoder.resnet.layer3.22.conv3.weight")
+    w0 = {n: sd[n].clone() for n in names}
+    bc = synth.make_batch(B=2, H=128, W=128, C=C, k=2048, seed=5)
+    om = OracleDeeplabv2({k: v.clone() for k, v in sd.items()}, "resnet101", C, False)
+    ref = oracle_src(om, SGDState(om.parameters(), 0.9, 5e-4), bc, 5e-3, OH)
+    model = Deeplabv2(cfg)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model = model.cuda()
+    out = src_step(model, FusedSGD(model, 1e-2, 0.9, 5e-4), StepState(C), {k: v.cuda() for k, v in bc.items()}, 5e-3)
+    for k in ("pred_s1", "pred_s2"):
+        err = (out[k].cpu() - ref[k]).abs().max() / ref[k].abs().max()
+        assert err < 1e-3, (k, float(err))
+    torch.testing.assert_close(out["loss_source"].cpu(), ref["loss_source"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), ref["grad_norm"].reshape(()), rtol=2e-2, atol=1e-4)
+    post = dict(om.named_parameters())
+    for name in names:
+        got, want = dict(model.named_parameters())[name].detach().cpu(), post[name].detach()
+        upd, upd_ref = got - w0[name], want - w0[name]
+        assert (upd - upd_ref).norm() / upd_ref.norm() < 6e-2, name
