@@ -86,7 +86,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local if args.device is None else args.device)
-    from oracle import synth                      # input generator only (seeded synthetic tiles)
+    from uemda_amd.utils import synth             # seeded synthetic tiles
     from uemda_amd.gast.alignment import Aligner
     from uemda_amd.models.Encoder import Deeplabv2
     from uemda_amd.optim import FusedSGD

@@ -4,7 +4,7 @@ achieved GB/s against the algorithmic bytes of SURVEY.md section 8(d) (HBM peak 
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import synth
+from uemda_amd.utils import synth
 from uemda_amd.gast.alignment import Aligner
 from uemda_amd.gast.balance import CrossEntropy, UVEMLoss, loss_calc_uvem
 from uemda_amd.gast.pseudo_generation import pseudo_selection

@@ -8,7 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from oracle import synth
+from uemda_amd.utils import synth
 from uemda_amd import ops
 from uemda_amd.gast.alignment import Aligner
 from uemda_amd.models.Encoder import Deeplabv2

@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from oracle import synth
+from uemda_amd.utils import synth
 from uemda_amd.gast.alignment import Aligner
 from uemda_amd.models.Encoder import Deeplabv2
 from uemda_amd.optim import FusedSGD

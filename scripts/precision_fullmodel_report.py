@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from oracle import synth
+from uemda_amd.utils import synth
 from oracle.weights import det_state_dict
 from uemda_amd import ops
 from uemda_amd.gast.alignment import Aligner
