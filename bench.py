@@ -94,6 +94,7 @@ def main():
     from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
 
     ops.set_conv_precision(args.conv_prec)
+    side_stream_on = bool(ops._side_stream_enabled())    # off under data parallel and in the event-timed last step
     C, B, S = 6, args.batch, args.size
     seed_torch(2333)
     cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
@@ -211,7 +212,8 @@ def main():
             "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text}, "
                                    f"random init; tiles counted = source + target",
-                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}"},
+                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
+                       "wgrad_side_stream": side_stream_on},
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }

@@ -19,9 +19,21 @@ s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 NC, NB = 20, 60
 
 
+dyc = torch.randn(B, 32, 32, 512, device="cuda")
+dw = torch.zeros_like(w)
+KIND = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+
+
+def conv_once():
+    if KIND == "wgrad":
+        ops.conv2d_wgrad(x, dyc, dw, pad=1)
+    else:
+        ops.conv2d(x, w, pad=1, out=y)
+
+
 def conv_loop():
     for _ in range(NC):
-        ops.conv2d(x, w, pad=1, out=y)
+        conv_once()
 
 
 def bn_loop():
@@ -58,7 +70,7 @@ def interleaved():
     s1.wait_stream(cur); s2.wait_stream(cur)
     for i in range(NC):
         with torch.cuda.stream(s1):
-            ops.conv2d(x, w, pad=1, out=y)
+            conv_once()
         with torch.cuda.stream(s2):
             for _ in range(NB // NC):
                 ops.bn_backward(z, dz, st, gg, gb, None, True, dx=out)
@@ -68,4 +80,4 @@ def interleaved():
 both()
 t2 = timed(both)
 t3 = timed(interleaved)
-print(f"conv alone {tc:.2f} ms, bn alone {tb:.2f} ms, sum {tc + tb:.2f} ms; two streams {t2:.2f} ms; interleaved issue {t3:.2f} ms")
+print(f"[{KIND}] conv alone {tc:.2f} ms, bn alone {tb:.2f} ms, sum {tc + tb:.2f} ms; two streams {t2:.2f} ms; interleaved issue {t3:.2f} ms")

@@ -12,6 +12,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 def init(backend=None, device=None):
     """Initialise the default process group from the torchrun environment; returns (rank, world, local_rank).
@@ -97,11 +99,13 @@ class DataParallel:
         self._bwd_calls += 1
         if self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
             _, garena, n = self.model.flat_parameters()
+            ops.join_side_stream()          # weight gradients run on a side stream: the tail must be complete first
             self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def reduce_gradients(self):
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
+        ops.join_side_stream()
         if self.world > 1:
             if self._pending is not None:
                 dist.all_reduce(garena[:self._split], op=dist.ReduceOp.SUM)
