@@ -101,7 +101,7 @@ def main():
                cascade=False, use_ppm=(args.head == "ppm"), ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
                inchannels=2048, num_classes=C, is_ins_norm=True)
     model = Deeplabv2(cfg).cuda()                 # random init of the reference's architecture (no checkpoints)
-    wrapper = udp.DataParallel(model, overlap=not args.no_overlap) if world > 1 else None
+    wrapper = udp.DataParallel(model, overlap=not args.no_overlap) if (world > 1 or udp.FORCE) else None
     # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
     pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + rank)
     rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]

@@ -15,13 +15,18 @@ import torch.distributed as dist
 from . import ops
 
 
+# UEM_DP_FORCE=1: take the data-parallel code paths (process group, broadcast, bucketed all-reduce) even with a single
+# rank -- a one-GPU smoke test of the RCCL plumbing (the collectives are then trivial but real).
+FORCE = os.environ.get("UEM_DP_FORCE", "0") != "0"
+
+
 def init(backend=None, device=None):
     """Initialise the default process group from the torchrun environment; returns (rank, world, local_rank).
     `device` overrides LOCAL_RANK as the CUDA device index (single-GPU rehearsals with the gloo backend)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -38,7 +43,7 @@ def world_size():
 
 def broadcast_flat(flat, src=0):
     """Make every replica start from rank `src`'s parameters / buffers."""
-    if world_size() > 1:
+    if world_size() > 1 or (FORCE and dist.is_initialized()):
         dist.broadcast(flat, src=src)
     return flat
 
@@ -72,7 +77,8 @@ class DataParallel:
         self._pending = None
         self._fwd_calls = 0
         self._bwd_calls = 0
-        if overlap and self.world > 1:
+        self._active = self.world > 1 or (FORCE and dist.is_initialized())
+        if overlap and self._active:
             self._install_overlap()
 
     # ---- overlap machinery -------------------------------------------------------------------------------
@@ -106,7 +112,7 @@ class DataParallel:
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
         ops.join_side_stream()
-        if self.world > 1:
+        if self._active:
             if self._pending is not None:
                 dist.all_reduce(garena[:self._split], op=dist.ReduceOp.SUM)
                 self._pending.wait()
