@@ -94,7 +94,7 @@ def main():
     from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
 
     ops.set_conv_precision(args.conv_prec)
-    side_stream_on = bool(ops._side_stream_enabled())    # off under data parallel and in the event-timed last step
+    side_stream_on = bool(ops._side_stream_enabled())    # (off in the event-timed last step)
     C, B, S = 6, args.batch, args.size
     seed_torch(2333)
     cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
@@ -225,6 +225,10 @@ def main():
                   "clip_sgd": 5 * 4 * model.flat_parameters()[2] / 1e6}
             line["phases_ms"] = ph
             line["phases_hbm_GBps"] = {k: round(v / 1e3 / (ph[k] * 1e-3), 1) for k, v in mb.items() if ph.get(k, 0) > 0}
+        ms = torch.cuda.memory_stats()
+        line["device_memory"] = {"peak_allocated_GB": round(ms.get("allocated_bytes.all.peak", 0) / 1e9, 1),
+                                 "peak_reserved_GB": round(ms.get("reserved_bytes.all.peak", 0) / 1e9, 1),
+                                 "alloc_retries": int(ms.get("num_alloc_retries", 0))}
         if others:
             line["other_precisions"] = others
         if world == 1 and not args.no_cpu_baseline:

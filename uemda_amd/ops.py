@@ -42,28 +42,30 @@ def stream():
 # Weight-gradient kernels (MFMA-bound, nothing downstream in the backward pass reads their output) can run on a side
 # stream beside the HBM-bound BatchNorm backward passes of the main stream (scripts/overlap_probe.py: 43 % of the
 # BatchNorm time disappears under a concurrently running wgrad).  blocks.BottleneckFn issues them through defer_on_side / flush_side.
-# Default: on in a single-process run, off under data parallel (there the gradient all-reduce already runs beside the
-# backward pass on the collective library's stream; the two-rank rehearsal on one GPU with the gloo backend showed
-# multi-second stalls when a third active stream was added, and RCCL on 8 GPUs cannot be rehearsed here).
-# UEM_WGRAD_STREAM=1 / 0 forces it either way.
-_WGRAD_STREAM_ENV = os.environ.get("UEM_WGRAD_STREAM")
-WGRAD_STREAM = _WGRAD_STREAM_ENV != "0"
+# UEM_WGRAD_STREAM=0 turns it off.  (A first version used Tensor.record_stream for the tensors the side stream reads;
+# that made the caching allocator reserve 4x the memory, the step time unstable and the 2-rank rehearsal stall for
+# seconds -- the explicit lifetime rule in flush_side() replaced it.)
+WGRAD_STREAM = os.environ.get("UEM_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 
 
 def _side_stream_enabled():
-    if PROF.enabled:            # per-launch event timing wants every kernel alone on the device
-        return False
-    if _WGRAD_STREAM_ENV is not None or not WGRAD_STREAM:
-        return WGRAD_STREAM
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    # per-launch event timing (bench.py's roofline leg) wants every kernel alone on the device
+    return WGRAD_STREAM and not PROF.enabled
+
+
+_SIDE_LOW_PRIORITY = os.environ.get("UEM_SIDE_PRIORITY", "normal") == "low"
+_SIDE_DEFER = os.environ.get("UEM_SIDE_DEFER", "1") != "0"
 
 
 def side_stream():
     dev = torch.cuda.current_device()
     if dev not in _side_streams:
-        _side_streams[dev] = torch.cuda.Stream(device=dev)
+        if _SIDE_LOW_PRIORITY:
+            lo, hi = torch.cuda.Stream.priority_range()       # (least, greatest); larger number = lower priority
+            _side_streams[dev] = torch.cuda.Stream(device=dev, priority=lo)
+        else:
+            _side_streams[dev] = torch.cuda.Stream(device=dev)
     return _side_streams[dev]
 
 
@@ -75,6 +77,7 @@ def join_side_stream():
     dev = torch.cuda.current_device()
     if dev in _side_streams:
         torch.cuda.current_stream().wait_stream(_side_streams[dev])
+        _inflight.clear()
 
 
 _join_scheduled = False
@@ -91,6 +94,8 @@ def defer_on_side(fn, *tensors):
     if not _side_stream_enabled():
         return fn()
     _deferred.append((fn, tensors))
+    if not _SIDE_DEFER:
+        flush_side()
     if not _join_scheduled:
         _join_scheduled = True
         main = torch.cuda.current_stream()
@@ -101,6 +106,7 @@ def defer_on_side(fn, *tensors):
             with torch.cuda.stream(main):
                 flush_side()
                 main.wait_stream(side_stream())
+                _inflight.clear()
         try:
             from torch.autograd import Variable
             Variable._execution_engine.queue_callback(_end_of_backward)
@@ -108,19 +114,28 @@ def defer_on_side(fn, *tensors):
             _end_of_backward()
 
 
+_inflight = []          # (event recorded on the side stream after a flushed group, the tensors that group touches)
+
+
 def flush_side():
-    """Launch everything queued by defer_on_side on the side stream, ordered after the current stream's work."""
+    """Launch everything queued by defer_on_side on the side stream, ordered after the current stream's work.
+    Tensor lifetime: the group's tensors stay referenced until the current stream has waited for the group's
+    completion event (at the next flush or join), so the caching allocator cannot hand their memory to a
+    main-stream kernel that would run beside the side-stream reader.  (Tensor.record_stream would do the same
+    job, but made the allocator reserve 4x the memory and the step time unstable.)"""
     if not _deferred:
         return
     main, side = torch.cuda.current_stream(), side_stream()
+    while _inflight:
+        ev, _keep = _inflight.pop(0)
+        main.wait_event(ev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         for fn, _ in _deferred:
             fn()
-    for _, tensors in _deferred:
-        for t in tensors:
-            if t is not None:
-                t.record_stream(side)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    _inflight.append((ev, [t for _, tensors in _deferred for t in tensors if t is not None]))
     _deferred.clear()
 
 
