@@ -853,7 +853,8 @@ static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     static const int forced = getenv("UEM_WGRAD_SPLITS") ? atoi(getenv("UEM_WGRAD_SPLITS")) : 0;
     static const int forced_rounds = getenv("UEM_WGRAD_ROUNDS") ? atoi(getenv("UEM_WGRAD_ROUNDS")) : 0;
     constexpr int BLOCKS_PER_CU = TM * TN >= 128 * 128 ? 3 : (TM * TN >= 32 * 128 ? 4 : 6);
-    const int slots = 256 * BLOCKS_PER_CU;
+    static const int bpc_env = getenv("UEM_WGRAD_BLOCKS_PER_CU") ? atoi(getenv("UEM_WGRAD_BLOCKS_PER_CU")) : 0;
+    const int slots = 256 * (bpc_env > 0 && TM * TN >= 128 * 128 ? bpc_env : BLOCKS_PER_CU);
     const int max_splits = (int)uem_cdiv(p.M, 4 * BK);
     int rounds = 3;
     if (tiles <= 32) {
@@ -870,8 +871,9 @@ static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     splits = (int)uem_cdiv(p.M, rps);
     p.rows_per_split = rps;
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
-    if (affine) conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, true, PREC><<<grid, 256, 0, st>>>(p);
-    else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false, PREC><<<grid, 256, 0, st>>>(p);
+    static const int lds_pad = getenv("UEM_WGRAD_LDS_PAD") ? atoi(getenv("UEM_WGRAD_LDS_PAD")) : 0;   // residency experiments
+    if (affine) conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, true, PREC><<<grid, 256, lds_pad, st>>>(p);
+    else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false, PREC><<<grid, 256, lds_pad, st>>>(p);
 }
 
 extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift, float* dw,
