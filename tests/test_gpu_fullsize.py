@@ -112,3 +112,33 @@ def test_forward_is_deterministic_and_step_is_finite_at_b32(big_batch):
     arena, garena, n = model.flat_parameters()
     assert torch.isfinite(out["loss_source"]) and torch.isfinite(out["loss_target"]) and torch.isfinite(out["grad_norm"]).all()
     assert torch.isfinite(arena[:n]).all() and torch.isfinite(garena[:n]).all()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,dil,hin", [
+    (64, 256, 1, 1, 1, 128),        # layer1 expand: small K, 8192 tiles
+    (128, 128, 3, 2, 1, 128),       # layer2 strided 3x3 (parity-class data gradient)
+    (256, 512, 1, 2, 1, 128),       # layer2 downsample, stride 2
+    (512, 512, 3, 1, 2, 32),        # layer4 dilated 3x3
+    (1024, 2048, 1, 1, 1, 32),      # layer4 downsample (largest filter bank)
+])
+def test_conv_adjoint_identities_at_b32(cin, cout, k, stride, dil, hin):
+    """<conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)>: the three kernels are adjoints of one bilinear map, so
+    the identity holds at any size without an oracle, and a tile that is skipped, doubled or mis-indexed breaks it
+    (linearity alone would not notice)."""
+    from uemda_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + k)
+    pad = dil * (k - 1) // 2
+    x = torch.randn(B, hin, hin, cin, device="cuda", generator=g)
+    w = torch.randn(cout, k, k, cin, device="cuda", generator=g) / (cin * k * k) ** 0.5
+    y = ops.conv2d(x, w, stride=stride, pad=pad, dil=dil)
+    dy = torch.randn(y.shape, device="cuda", generator=g)
+    dx = ops.conv2d_dgrad(dy, ops.weight_transpose(w), x.shape, stride=stride, pad=pad, dil=dil)
+    dw = torch.zeros_like(w)
+    ops.conv2d_wgrad(x, dy, dw, stride=stride, pad=pad, dil=dil)
+    ops.join_side_stream()
+    a = (y.double() * dy.double()).sum()
+    b = (x.double() * dx.double()).sum()
+    c = (w.double() * dw.double()).sum()
+    scale = (y.double().norm() * dy.double().norm())
+    assert abs(a - b) / scale < 1e-5 and abs(a - c) / scale < 1e-5, (float(a), float(b), float(c))
+    assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
