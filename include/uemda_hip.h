@@ -196,6 +196,10 @@ int uem_pseudo_select(const float* mask, const uint32_t* plane_max, int64_t* har
 /* DownscaleLabel: majority vote over scale x scale cells             alignment.py:484-509          */
 int uem_downscale_label(const int64_t* label, int64_t* out, int B, int H, int W, int scale, int n_classes,
                         int64_t ignore_label, float min_ratio, void* stream);
+/* superpixel edge shrinking: keep an id only where the whole (2*win+1)^2 window (clipped) agrees, else ignore_id
+ * (gast/superpixels.py:129-152; label and out are (B,H,W) int32, the on-disk .tif dtype; out != label)            */
+int uem_superpixel_shrink(const int32_t* label, int32_t* out, int B, int H, int W, int win_size, int32_t ignore_id,
+                          void* stream);
 /* class-masked feature sums: sums[c][k], counts[c]                    alignment.py:340-348         */
 int uem_proto_sums(const float* feat, const int64_t* label_ds, float* sums, float* counts,
                    float* workspace /* >= UEM_PROTO_SPLIT*C*k + UEM_PROTO_SPLIT*C floats */, int n, int k,

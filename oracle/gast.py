@@ -264,3 +264,20 @@ def learning_rate(i_iter, base_lr, preheat_steps, num_steps, power=0.9):
     if i_iter < preheat_steps:
         return base_lr * (float(i_iter) / preheat_steps)
     return base_lr * ((1 - float(i_iter) / num_steps) ** power)
+
+
+def edge_shrinking(label, win_size=3, region_size=16):
+    """reference gast/superpixels.py:129-150 (three nested Python loops) restated with shifted comparisons:
+    keep the id where every pixel of the clipped (2*win+1)^2 window equals it, else int(H/region * W/region)."""
+    import numpy as np
+    lab = np.asarray(label)
+    h, w = lab.shape
+    cnt_sup = int(h / region_size * w / region_size)
+    keep = np.ones((h, w), dtype=bool)
+    for dy in range(-win_size, win_size + 1):
+        for dx in range(-win_size, win_size + 1):
+            ys, ye = max(0, -dy), min(h, h - dy)
+            xs, xe = max(0, -dx), min(w, w - dx)
+            same = lab[ys:ye, xs:xe] == lab[ys + dy:ye + dy, xs + dx:xe + dx]
+            keep[ys:ye, xs:xe] &= same
+    return np.where(keep, lab, cnt_sup).astype(lab.dtype)

@@ -179,3 +179,23 @@ def test_mining_at_benchmark_tile_size_vs_oracle_and_properties():
     ds = al.update_prototype(dev(feat), dev(b["label_s"]))
     assert torch.equal(ds.cpu(), ds_ref)
     torch.testing.assert_close(al.prototypes.cpu(), protos_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_superpixel_edge_shrinking_golden_and_file_round_trip(tmp_path):
+    """HIP edge shrinking == the reference's function (golden) and == the oracle on a 512x512 irregular map; the id
+    map survives the `<name>.tif` wire format and feeds label_refine's layout (1,H,W) int64."""
+    from oracle import gast, synth
+    from uemda_amd.gast.superpixels import edge_shrinking, load_superpixels, save_superpixels
+    g = load_golden("superpixel_shrink")
+    for k in ("a", "b", "c"):
+        got = edge_shrinking(g[f"in_{k}"].cuda(), 3, 16)
+        assert got.dtype == torch.int32 and torch.equal(got.cpu(), g[f"out_{k}"])
+    big = synth.irregular_superpixels(2, 512, 512, 900, seed=4)[:, 0].to(torch.int32)
+    got = edge_shrinking(big.cuda(), 3, 16)
+    for b in range(2):
+        assert (got[b].cpu().numpy() == gast.edge_shrinking(big[b].numpy(), 3, 16)).all()
+    assert int(got.max()) == 1024                                   # ignored id = 512/16 * 512/16
+    p = str(tmp_path / "tile.tif")
+    save_superpixels(p, got[0])
+    back = load_superpixels(p)
+    assert back.shape == (1, 512, 512) and back.dtype == torch.int64 and torch.equal(back[0].int(), got[0])

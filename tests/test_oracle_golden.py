@@ -282,3 +282,12 @@ def test_stage2_alignment_losses_golden():
     torch.testing.assert_close(lc.detach(), g["coral"], rtol=1e-5, atol=1e-9)
     torch.testing.assert_close(s.grad, g["coral_gsrc"], rtol=1e-4, atol=1e-9)
     torch.testing.assert_close(t.grad, g["coral_gtgt"], rtol=1e-4, atol=1e-9)
+
+
+def test_superpixel_edge_shrinking_golden():
+    """oracle restatement == the reference's own edge_shrinking (fixture: tests/golden/make_golden_superpixels.py)."""
+    from oracle import gast
+    g = load_golden("superpixel_shrink")
+    for k in ("a", "b", "c"):
+        got = gast.edge_shrinking(g[f"in_{k}"].numpy(), 3, 16)
+        assert (got == g[f"out_{k}"].numpy()).all(), k

@@ -75,6 +75,7 @@ SIGNATURES = {
     "uem_plane_max": [P, P, I, I, L, P],
     "uem_pseudo_select": [P, P, P, P, I, I, L, F, F, L, P],
     "uem_downscale_label": [P, P, I, I, I, I, I, L, F, P],
+    "uem_superpixel_shrink": [P, P, I, I, I, I, I, P],
     "uem_proto_sums": [P, P, P, P, P, I, I, I, L, P],
     "uem_proto_ema": [P, P, P, I, I, F, P],
     "uem_ce_upsampled": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, F, P],

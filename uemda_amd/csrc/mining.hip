@@ -660,3 +660,32 @@ extern "C" int uem_scatter(const float* src, const int64_t* index, float* out, f
     if (reduce != 1) scatter_finish_kernel<<<(int)uem_cdiv(total, 256), 256, 0, st>>>(out, workspace, total, C, reduce);
     return uem_check_launch("scatter");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// superpixel edge shrinking (gast/superpixels.py:129-152): a pixel keeps its superpixel id only if every pixel of
+// the (2*win+1)^2 window around it (clipped at the image border) carries the same id; the others get `ignore_id`
+// (= H/16 * W/16, the id label_refine treats as "no superpixel").  Offline preprocessing in the reference (three
+// nested Python loops per image); one thread per pixel here, the window comes out of L1/L2.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void superpixel_shrink_kernel(const int32_t* __restrict__ label, int32_t* __restrict__ out,
+                                                                int B, int H, int W, int win, int32_t ignore_id) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int32_t* img = label + (i - (int64_t)y * W - x);
+    const int32_t v = img[(size_t)y * W + x];
+    bool keep = true;
+    const int y0 = max(0, y - win), y1 = min(H - 1, y + win), x0 = max(0, x - win), x1 = min(W - 1, x + win);
+    for (int yy = y0; yy <= y1 && keep; ++yy)
+        for (int xx = x0; xx <= x1; ++xx)
+            if (img[(size_t)yy * W + xx] != v) { keep = false; break; }
+    out[i] = keep ? v : ignore_id;
+}
+extern "C" int uem_superpixel_shrink(const int32_t* label, int32_t* out, int B, int H, int W, int win_size, int32_t ignore_id,
+                                     void* stream) {
+    UEM_REQUIRE(label && out && label != out, "superpixel_shrink: needs distinct input and output buffers");
+    UEM_REQUIRE(B > 0 && H > 0 && W > 0 && win_size >= 0 && win_size <= 16, "superpixel_shrink: bad arguments");
+    const int64_t n = (int64_t)B * H * W;
+    superpixel_shrink_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(label, out, B, H, W, win_size, ignore_id);
+    return uem_check_launch("superpixel_shrink");
+}
