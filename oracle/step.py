@@ -72,15 +72,25 @@ def ssl_step(model, opt, prototypes, batch, lr, hp=HYPER, dropout=False, n_class
                 pred_s1=ps1.detach(), pred_s2=ps2.detach(), feat_s=feat_s.detach())
 
 
-def src_step(model, opt, batch, lr, hp=HYPER, dropout=False):
+def src_step(model, opt, batch, lr, hp=HYPER, dropout=False, align_domain=False):
+    """reference tools/train_src.py:112-141; align_domain = the script's --align-domain (:126-135)."""
     model.train()
-    ps1, ps2, _feat = model(batch["images_s"], dropout) if model.use_ppm else model(batch["images_s"])
-    loss = gast.loss_calc([ps1, ps2], batch["label_s"], hp["ignore_label"])
+    ps1, ps2, feat_s = model(batch["images_s"], dropout) if model.use_ppm else model(batch["images_s"])
+    loss_seg = gast.loss_calc([ps1, ps2], batch["label_s"], hp["ignore_label"])
+    loss = loss_seg
+    out = {}
+    if align_domain:
+        _p1, _p2, feat_t = model(batch["images_t"], dropout) if model.use_ppm else model(batch["images_t"])
+        k = feat_s.shape[1]
+        loss_domain = gast.coral_loss(feat_s.permute(0, 2, 3, 1).reshape(-1, k), feat_t.permute(0, 2, 3, 1).reshape(-1, k))
+        loss = loss_seg + loss_domain
+        out["loss_domain"] = loss_domain.detach()
     opt.zero_grad()
     loss.backward()
     gnorm = opt.clip_grad_norm(hp["max_norm"])
     opt.step(lr)
-    return dict(loss_source=loss.detach(), grad_norm=gnorm, pred_s1=ps1.detach(), pred_s2=ps2.detach())
+    out.update(loss_source=loss_seg.detach(), grad_norm=gnorm, pred_s1=ps1.detach(), pred_s2=ps2.detach())
+    return out
 
 
 def align_step(model, opt, prototypes, batch, lr, hp=HYPER, n_classes=6, align_domain=True, pcl_temp=8.0):

@@ -56,3 +56,30 @@ def test_align_step_vs_oracle():
     assert (ref["label_t_hard"] >= 0).float().mean() > 0.2 and torch.isfinite(ref["loss_align"])
     torch.testing.assert_close(al.prototypes.cpu(), ref["prototypes"], rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), ref["grad_norm"].reshape(()), rtol=2e-2, atol=1e-4)
+
+
+def test_src_step_with_domain_alignment_vs_oracle():
+    """Stage 1 with --align-domain (tools/train_src.py:126-135): source CE + CORAL(feat_s, feat_t), one step."""
+    from oracle import synth
+    from oracle.model import OracleDeeplabv2
+    from oracle.step import HYPER as OH, SGDState, src_step as oracle_src
+    from oracle.weights import det_state_dict
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, src_step
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    sd = det_state_dict("resnet50", C, False, seed=2333)
+    bc = synth.make_batch(B=2, H=128, W=128, C=C, k=2048, seed=21)
+    om = OracleDeeplabv2({k: v.clone() for k, v in sd.items()}, "resnet50", C, False)
+    ref = oracle_src(om, SGDState(om.parameters(), 0.9, 5e-4), bc, 3e-3, OH, align_domain=True)
+    model = Deeplabv2(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    out = src_step(model, FusedSGD(model, 1e-2, 0.9, 5e-4), StepState(C), {k: v.cuda() for k, v in bc.items()}, 3e-3,
+                   aligner=al, align_domain=True)
+    torch.testing.assert_close(out["loss_source"].cpu().reshape(()), ref["loss_source"].reshape(()), rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(out["loss_domain"].cpu().reshape(()), ref["loss_domain"].reshape(()).float(), rtol=2e-3, atol=1e-8)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), ref["grad_norm"].reshape(()), rtol=2e-2, atol=1e-4)

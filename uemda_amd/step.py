@@ -55,18 +55,28 @@ def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id
                 grad_norm=optimizer.last_grad_norm)
 
 
-def src_step(model, optimizer, state, batch, lr, dp=None):
+def src_step(model, optimizer, state, batch, lr, dp=None, aligner=None, align_domain=False):
+    """Stage-1 iteration (tools/train_src.py:112-141); with `align_domain` (the script's --align-domain) the target
+    tiles are pushed through the network too and CORAL between the two feature sets joins the loss (:126-135)."""
     hp = state.hp
     model.train()
     optimizer.param_groups[0]["lr"] = lr
-    pred_s1, pred_s2, _feat = model(batch["images_s"])                          # train_src.py:116
-    loss = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :132
+    pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # train_src.py:116
+    loss_seg = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :132
+    loss_domain = None
+    if align_domain:
+        _p1, _p2, feat_t = model(batch["images_t"])                             # :127
+        loss_domain = aligner.align_domain(feat_s, feat_t)                      # :134
+    loss = loss_seg + loss_domain if align_domain else loss_seg
     optimizer.zero_grad()
     loss.backward()
     prescale = dp.reduce_gradients() if dp is not None else 1.0
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
-    return dict(loss_source=loss.detach(), pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
-                grad_norm=optimizer.last_grad_norm)
+    out = dict(loss_source=loss_seg.detach(), pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
+               grad_norm=optimizer.last_grad_norm)
+    if align_domain:
+        out["loss_domain"] = loss_domain.detach()
+    return out
 
 
 def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None, align_domain=True, pcl_temp=8.0):
