@@ -89,3 +89,23 @@ def test_init_prototypes_and_pseudo_generation_roundtrip(tmp_path):
     assert hards[0].shape == (1, 512, 768)
     res, miou = evaluate(model, [(imgs[0], torch.randint(-1, C, (1, 512, 768)).cuda())], C, ignore_labels=[0])
     assert 0.0 <= miou <= 1.0 and res["confusion"].sum() > 0
+
+
+@pytest.mark.parametrize("hw", [(128, 128), (96, 160)])
+def test_tta_d4_batched_equals_sequential(hw):
+    """The 8 D4 views as one batch (square tile) or two batches of 4 (non-square) == 8 single-image forwards."""
+    from oracle.weights import det_state_dict
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.utils.tools import tta_predict
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    model = Deeplabv2(cfg)
+    model.load_state_dict(det_state_dict("resnet50", C, False, seed=2333))
+    model = model.cuda().eval()
+    img = torch.randn(1, 3, *hw, generator=torch.Generator().manual_seed(9)).cuda()
+    with torch.no_grad():
+        a = tta_predict(model, img, batched=True)
+        b = tta_predict(model, img, batched=False)
+    assert a.shape == (1, C, *hw)
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    assert ((a.sum(1) - 1).abs() < 1e-5).all()

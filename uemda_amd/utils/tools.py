@@ -71,22 +71,36 @@ def pad_image(img, target_size):
     return tnf.pad(img, (0, 0, rows_missing, cols_missing), 'constant', 0)
 
 
-def tta_predict(model, img):
-    """hflip x rot90{0,90,180,270}: 8 eval forwards, de-augmented and averaged (tools.py:132-152; ttach semantics:
+def tta_predict(model, img, batched=True):
+    """hflip x rot90{0,90,180,270}: 8 eval-mode views, de-augmented and averaged (tools.py:132-152; ttach semantics:
     augment = hflip then rot90(k), de-augment = rot90(-k) then hflip).  Like the reference, the mean is taken over
-    the concatenated batch dimension, so it is only meaningful for batch size 1."""
+    the concatenated batch dimension, so it is only meaningful for batch size 1.
+
+    `batched` (SURVEY 8 f1, D4-symmetry batching): views of equal shape go through the network as ONE batch -- all 8
+    for a square tile, 4 + 4 otherwise -- instead of 8 single-image forwards that cannot fill the device (a 512x512
+    tile is 8 row tiles of the layer-4 GEMMs).  Eval-mode outputs do not depend on the batch they travel in and
+    the de-augmented views are summed in the same order, so the result is the same as the sequential form."""
     from .. import ops
     if img.shape[0] != 1:
         raise UemError("tta_predict: the reference averages over cat(xs, 0); use batch size 1")
+    combos = [(flip, k) for flip in (False, True) for k in range(4)]
+    views = [torch.rot90(img.flip(3) if flip else img, k, (2, 3)).contiguous() for flip, k in combos]
+    outs = [None] * 8
+    if batched and not getattr(model, "training", False):
+        groups = {}
+        for i, v in enumerate(views):
+            groups.setdefault(tuple(v.shape[2:]), []).append(i)
+        for idx in groups.values():
+            y = model(torch.cat([views[i] for i in idx], 0))
+            for j, i in enumerate(idx):
+                outs[i] = y[j:j + 1]
+    else:
+        outs = [model(v) for v in views]
     acc = None
-    for flip in (False, True):
-        for k in range(4):
-            aug = img.flip(3) if flip else img
-            aug = torch.rot90(aug, k, (2, 3)).contiguous()
-            x = model(aug)
-            x = torch.rot90(x, -k, (2, 3))
-            x = (x.flip(3) if flip else x).contiguous()
-            acc = x if acc is None else ops.add_(acc, x)
+    for (flip, k), x in zip(combos, outs):
+        x = torch.rot90(x, -k, (2, 3))
+        x = (x.flip(3) if flip else x).contiguous()
+        acc = x.clone() if acc is None else ops.add_(acc, x)
     ops.call("uem_scale", ops.ptr(acc), acc.numel(), 1.0 / 8.0, ops.stream())
     return acc
 
