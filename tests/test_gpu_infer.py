@@ -87,6 +87,14 @@ def test_init_prototypes_and_pseudo_generation_roundtrip(tmp_path):
     assert prob.shape == (C, 512, 768) and prob.dtype == torch.float32
     assert torch.allclose(prob.sum(0), torch.ones(512, 768), atol=1e-4)
     assert hards[0].shape == (1, 512, 768)
+    # fp16 files (half the bytes) load back as fp32 within half precision
+    from uemda_amd.gast.pseudo_generation import load_target_pseudo
+    half_dir = os.path.join(str(tmp_path), "half")
+    gener_target_pseudo(model, imgs[:1], ["a.png"], half_dir, C, slide=True, save_dtype=torch.float16)
+    assert torch.load(os.path.join(half_dir, "a.png.pt")).dtype == torch.float16
+    back = load_target_pseudo(os.path.join(half_dir, "a.png.pt"))
+    assert back.dtype == torch.float32 and back.is_cuda
+    torch.testing.assert_close(back.cpu(), prob, rtol=2e-3, atol=1e-3)
     res, miou = evaluate(model, [(imgs[0], torch.randint(-1, C, (1, 512, 768)).cuda())], C, ignore_labels=[0])
     assert 0.0 <= miou <= 1.0 and res["confusion"].sum() > 0
 

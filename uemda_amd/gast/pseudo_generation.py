@@ -35,10 +35,12 @@ def pseudo_selection(mask, cutoff_top=0.8, cutoff_low=0.6, return_type='ndarray'
 
 
 def gener_target_pseudo(model, images, names, save_pseudo_label_path, num_classes, slide=True, save_prob=True,
-                        size=None, cutoff_top=0.8, cutoff_low=0.6, ignore_label=-1):
+                        size=None, cutoff_top=0.8, cutoff_low=0.6, ignore_label=-1, save_dtype=torch.float32):
     """Offline pseudo-label generation (pseudo_generation.py:96-155): eval-mode sliding-window forward with the
     8-way TTA, then `<fname>.pt` = torch.save of the (C,H,W) fp32 probability map (the wire format
     `BaseData.__getitem__` loads, basedata.py:87).  `images` yields (1,3,H,W) CUDA tensors, `names` the file names.
+    `save_dtype=torch.float16` halves the files (SURVEY 8 f1 option; `load_target_pseudo` returns fp32 either way;
+    the reference's loader would need `.float()` for such a file).
     Returns the hard labels selected from each map (what the reference only renders as colour PNGs)."""
     import os
     from ..utils.tools import pre_slide
@@ -52,6 +54,14 @@ def gener_target_pseudo(model, images, names, save_pseudo_label_path, num_classe
                 raise UemError("gener_target_pseudo: resizing to a different `size` is not implemented "
                                "(the ISPRS / LoveDA tiles are generated at their native size)")
             if save_prob:
-                torch.save(cls.squeeze(dim=0).cpu(), os.path.join(save_pseudo_label_path, name + '.pt'))
+                torch.save(cls.squeeze(dim=0).to("cpu", save_dtype), os.path.join(save_pseudo_label_path, name + '.pt'))
             hards.append(pseudo_selection(cls, cutoff_top, cutoff_low, 'tensor', ignore_label))
     return hards
+
+
+def load_target_pseudo(path, device="cuda"):
+    """`<fname>.pt` -> (C,H,W) fp32 soft pseudo label on `device` (basedata.py:87 reads the same file with torch.load)."""
+    t = torch.load(path, map_location="cpu")
+    if t.dim() != 3:
+        raise UemError(f"{path}: expected a (C,H,W) probability map, got shape {tuple(t.shape)}")
+    return t.float().to(device)
