@@ -762,18 +762,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         for (int mb = mbeg; mb < mend; mb += BK) {
             if (mb + BK < mend) load_tiles(mb + BK);
             if constexpr (PREC == 0) {
+                // operand fragments of pixel pair kp+1 are fetched before the MFMAs of pair kp are issued
+                float a[2][MT], b[2][NT];
+                {
+                    const int k = wk * KPW + fh;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) a[0][i] = Ds[k * TM + wm + i * 32 + fr];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) b[0][j] = Xs[k * TN + wn + j * 32 + fr];
+                }
 #pragma unroll
                 for (int kp = 0; kp < KPW / 2; ++kp) {
-                    const int k = wk * KPW + kp * 2 + fh;
-                    float a[MT], b[NT];
+                    if (kp + 1 < KPW / 2) {
+                        const int k = wk * KPW + (kp + 1) * 2 + fh;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) a[i] = Ds[k * TM + wm + i * 32 + fr];
+                        for (int i = 0; i < MT; ++i) a[(kp + 1) & 1][i] = Ds[k * TM + wm + i * 32 + fr];
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) b[j] = Xs[k * TN + wn + j * 32 + fr];
+                        for (int j = 0; j < NT; ++j) b[(kp + 1) & 1][j] = Xs[k * TN + wn + j * 32 + fr];
+                    }
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp & 1][i], b[kp & 1][j], acc[i][j], 0, 0, 0);
+                    // keep that order in the machine schedule: the LDS reads of the next pair, then this pair's MFMAs
+                    // (left alone, the scheduler sinks each read group behind the MFMAs and waits for it at once)
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
                 }
             } else {
 #pragma unroll
