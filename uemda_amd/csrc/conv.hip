@@ -229,11 +229,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
     if (AFFINE) __syncthreads();
     if (KT > 0) store_tiles(0);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = (NBUF == 2) ? (kt & 1) : 0;
+    // MFMA phase over the k-tile staged in LDS stage `cur`
+    auto mfma_phase = [&](int cur) {
         const float* const As = As0 + cur * A_SZ;
         const float* const Bs = Bs0 + cur * B_SZ;
-        if (kt + 1 < KT) load_tiles(kt + 1);            // in flight during the MFMA phase
         if constexpr (PREC == 0) {
 #pragma unroll
             for (int ks = 0; ks < BK / 8; ++ks) {
@@ -287,17 +286,28 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
                     for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
         }
+    };
+    // The last k-tile is peeled off so that the loop body loads tile kt+1 UNCONDITIONALLY: with `if (kt + 1 < KT)`
+    // around the load the prefetch registers became loop-carried, and the compiler copied them (after an
+    // s_waitcnt vmcnt(0)) in front of the MFMA phase -- every wave waited out its own global-load latency before
+    // its MFMAs instead of underneath them.
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+        const int cur = (NBUF == 2) ? (kt & 1) : 0;
+        load_tiles(kt + 1);                             // in flight during the MFMA phase
+        mfma_phase(cur);
         if (NBUF == 2) {
             // the other stage was last read in iteration kt-1, which every wave left through the barrier below
-            if (kt + 1 < KT) store_tiles(cur ^ 1);
+            store_tiles(cur ^ 1);
             __syncthreads();
         } else {
             __syncthreads();
-            if (kt + 1 < KT) {
-                store_tiles(0);
-                __syncthreads();
-            }
+            store_tiles(0);
+            __syncthreads();
         }
+    }
+    if (KT > 0) {
+        mfma_phase((NBUF == 2) ? ((KT - 1) & 1) : 0);
+        __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------
@@ -622,7 +632,7 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const unsigned char* img, int ld, 
 }
 
 template <int TM, int TN, int WM, int WN, int WK, int MODE, bool AFFINE, int PREC>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
     constexpr int MT = TM / WM / 32, NT = TN / WN / 32;
     constexpr int DTPR = TM / 4, DRPP = 256 / DTPR, DPASS = (BK + DRPP - 1) / DRPP;   // dY loader
     constexpr int XTPR = TN / 4, XRPP = 256 / XTPR, XPASS = (BK + XRPP - 1) / XRPP;   // X loader
@@ -759,8 +769,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
         load_tiles(mbeg);
         store_tiles();
         __syncthreads();
-        for (int mb = mbeg; mb < mend; mb += BK) {
-            if (mb + BK < mend) load_tiles(mb + BK);
+        // MFMA phase over the pixel block staged in LDS; the last block is peeled off so that the loop body prefetches
+        // UNCONDITIONALLY (a conditional prefetch makes the registers loop-carried and the compiler then waits for the
+        // loads and copies them in front of the MFMAs -- see conv_fwd_kernel)
+        auto mfma_phase = [&]() {
             if constexpr (PREC == 0) {
                 // operand fragments of pixel pair kp+1 are fetched before the MFMAs of pair kp are issued
                 float a[2][MT], b[2][NT];
@@ -821,12 +833,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
                         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
             }
+        };
+        int mb = mbeg;
+        for (; mb + BK < mend; mb += BK) {
+            load_tiles(mb + BK);
+            mfma_phase();
             __syncthreads();
-            if (mb + BK < mend) {
-                store_tiles();
-                __syncthreads();
-            }
+            store_tiles();
+            __syncthreads();
         }
+        mfma_phase();
     }
     const size_t row_ld = (size_t)taps * p.Cin;         // dW[o][tap][i]
     float* wbase = p.dw + (size_t)tap * p.Cin;
