@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
     unsigned aoff[4], boff[BROWS];                      // element offsets from p.x / p.w (every tensor here < 2^32 floats)
 #pragma unroll
     for (int j = 0; j < 4; ++j) aoff[j] = 0;
+    unsigned bvalid = 0;                                // bit j: filter row j of this thread exists (ragged Cout)
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) boff[j] = 0;
+    for (int j = 0; j < BROWS; ++j) { boff[j] = 0; bvalid |= (n0 + lrow + 32 * j < p.Cout ? 1u : 0u) << j; }
     auto setup_tap = [&](int t) {
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
         const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);   // tap/3 for tap < 16
@@ -156,14 +157,18 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
         if (lci0 == 0) setup_tap(lt);                   // block-uniform branch
         pci0 = lci0;
         okmask = tapok;
+        // Branch-free: a row that is out of bounds loads from offset 0 (always mapped) and is zeroed when the tile
+        // goes to LDS (okmask / bvalid).  A predicated load (`ok ? load : 0`) costs an exec-mask region per row, and
+        // the compiler likes to sink the consumer of the value into that region -- an s_waitcnt vmcnt(0) behind
+        // every single load.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ra[j] = ((tapok >> j) & 1u) ? *reinterpret_cast<const float4*>(p.x + aoff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[j] = *reinterpret_cast<const float4*>(p.x + (((tapok >> j) & 1u) ? aoff[j] : 0u));
             aoff[j] += BK;
         }
 #pragma unroll
         for (int j = 0; j < BROWS; ++j) {
-            rb[j] = (n0 + lrow + 32 * j < p.Cout) ? *reinterpret_cast<const float4*>(p.w + boff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[j] = *reinterpret_cast<const float4*>(p.w + (((bvalid >> j) & 1u) ? boff[j] : 0u));
             boff[j] += BK;
         }
         lci0 += BK;
@@ -201,14 +206,22 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = ra[j];
-            if (AFFINE && ((okmask >> j) & 1u)) {
+            const bool ok = (okmask >> j) & 1u;
+            if (AFFINE) {
                 v.x = v.x * psc.x + psh.x; v.y = v.y * psc.y + psh.y; v.z = v.z * psc.z + psh.z; v.w = v.w * psc.w + psh.w;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
+            // zero padding comes after the transform (out-of-bounds rows stay 0)
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
             put(As, lrow + 32 * j, v);
         }
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j) put(Bs, lrow + 32 * j, rb[j]);
+        for (int j = 0; j < BROWS; ++j) {
+            float4 v = rb[j];
+            const bool ok = (bvalid >> j) & 1u;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            put(Bs, lrow + 32 * j, v);
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -683,21 +696,24 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
         xoy[j] = rem / p.Wo;
         xox[j] = rem - xoy[j] * p.Wo;
     }
+    unsigned dok = 0;
     auto load_tiles = [&](int mb) {
+        // branch-free: rows / columns outside the problem load from offset 0 and are zeroed at the LDS store (dok / xok)
         xok = 0;
+        dok = 0;
 #pragma unroll
         for (int j = 0; j < DPASS; ++j) {
             const int r = drow + j * DRPP;
             const int m = mb + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < BK && m < mend && (co0 + dc4) < p.Cout) v = *reinterpret_cast<const float4*>(p.dy + (size_t)m * p.dy_ld + co0 + dc4);
-            rd[j] = v;
+            const bool ok = r < BK && m < mend && (co0 + dc4) < p.Cout;
+            rd[j] = *reinterpret_cast<const float4*>(p.dy + (ok ? (size_t)m * p.dy_ld + co0 + dc4 : (size_t)0));
+            dok |= (ok ? 1u : 0u) << j;
         }
 #pragma unroll
         for (int j = 0; j < XPASS; ++j) {
             const int r = xrow + j * XRPP;
             const int m = mb + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            size_t off = 0;
             if (r < BK && m < mend) {
                 const int n = xn[j], oy = xoy[j], ox = xox[j];
                 int iy, ix;
@@ -705,12 +721,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
                 else { iy = oy * p.stride - p.pad + ky * p.dil; ix = ox * p.stride - p.pad + kx * p.dil; }
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                     const size_t pix = ((size_t)n * p.H + iy) * p.W + ix;
-                    if (MODE == 2) v = *reinterpret_cast<const float4*>(p.x + pix * 4);
-                    else v = *reinterpret_cast<const float4*>(p.x + pix * p.x_ld + ci0 + xc4);
+                    off = (MODE == 2) ? pix * 4 : pix * p.x_ld + ci0 + xc4;
                     xok |= 1u << j;
                 }
             }
-            rx[j] = v;
+            rx[j] = *reinterpret_cast<const float4*>(p.x + off);
             // advance this row slot by BK pixels for the next step
             xox[j] += BK;
             while (xox[j] >= p.Wo) { xox[j] -= p.Wo; ++xoy[j]; }
@@ -732,19 +747,24 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int j = 0; j < DPASS; ++j) {
             const int r = drow + j * DRPP;
+            float4 v = rd[j];
+            const bool ok = (dok >> j) & 1u;
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
             if (r < BK) {
-                if constexpr (PREC == 0) *reinterpret_cast<float4*>(&Ds[r * TM + dc4]) = rd[j];
-                else put_bf16(Dsm, LDD, r, dc4, rd[j]);
+                if constexpr (PREC == 0) *reinterpret_cast<float4*>(&Ds[r * TM + dc4]) = v;
+                else put_bf16(Dsm, LDD, r, dc4, v);
             }
         }
 #pragma unroll
         for (int j = 0; j < XPASS; ++j) {
             const int r = xrow + j * XRPP;
             float4 v = rx[j];
-            if (AFFINE && ((xok >> j) & 1u)) {          // prologue applied after the MFMA phase (see conv_fwd_kernel)
+            const bool ok = (xok >> j) & 1u;
+            if (AFFINE) {                               // prologue applied after the MFMA phase (see conv_fwd_kernel)
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             }
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
             if (r < BK) {
                 if constexpr (PREC == 0) *reinterpret_cast<float4*>(&Xs[r * TN + xc4]) = v;
                 else put_bf16(Xsm, LDX, r, xc4, v);
