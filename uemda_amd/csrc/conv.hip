@@ -352,17 +352,26 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
                             stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
             }
             __syncthreads();
+            // global loads of the epilogue (the tensor being accumulated into, the z of the fused BatchNorm backward) are
+            // issued in batches of up to 4 rows before their consumers: written row by row they compiled to
+            // load - s_waitcnt vmcnt(0) - use, 8 to 16 serialised memory latencies per block
+            constexpr int NRP = 64 / RPP, RB = NRP < 4 ? NRP : 4;
 #pragma unroll
-            for (int rp = 0; rp < 64 / RPP; ++rp) {
-                const int row = srow + rp * RPP;
-                float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
-                v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-                float* dst = p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4;
+            for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
+                float4 o[RB];
                 if (p.accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(dst);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        o[u] = *reinterpret_cast<const float4*>(p.y + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
                 }
-                *reinterpret_cast<float4*>(dst) = v;
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int row = srow + (rp0 + u) * RPP;
+                    float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                    v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                    if (p.accumulate) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
+                    *reinterpret_cast<float4*>(p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4) = v;
+                }
             }
             if (MODE == 1 && p.tile_bnbwd != nullptr) {
                 // each thread owns 4 columns x (64/RPP) rows of this half: accumulate dbeta / dgamma partials
@@ -371,15 +380,22 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
                 const float4 mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.Cout + n0 + sc4);
                 const float4 is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.Cout + n0 + sc4);
 #pragma unroll
-                for (int rp = 0; rp < 64 / RPP; ++rp) {
-                    const int row = srow + rp * RPP;
-                    const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
-                    const float4 z = *reinterpret_cast<const float4*>(p.bn_z + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4);
-                    const float dx_ = (z.x * sc.x + sh.x > 0.f) ? d.x : 0.f, dy_ = (z.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
-                    const float dz_ = (z.z * sc.z + sh.z > 0.f) ? d.z : 0.f, dw_ = (z.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
-                    bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
-                    bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
-                    bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
+                for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
+                    float4 zz[RB];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int row = srow + (rp0 + u) * RPP;
+                        const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                        const float4 z = zz[u];
+                        const float dx_ = (z.x * sc.x + sh.x > 0.f) ? d.x : 0.f, dy_ = (z.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+                        const float dz_ = (z.z * sc.z + sh.z > 0.f) ? d.z : 0.f, dw_ = (z.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+                        bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
+                        bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
+                        bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
+                    }
                 }
             }
             if (p.tile_stats != nullptr && tid < BN) {
