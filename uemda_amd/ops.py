@@ -54,18 +54,10 @@ def _side_stream_enabled():
     return WGRAD_STREAM and not PROF.enabled
 
 
-_SIDE_LOW_PRIORITY = os.environ.get("UEM_SIDE_PRIORITY", "normal") == "low"
-_SIDE_DEFER = os.environ.get("UEM_SIDE_DEFER", "1") != "0"
-
-
 def side_stream():
     dev = torch.cuda.current_device()
     if dev not in _side_streams:
-        if _SIDE_LOW_PRIORITY:
-            lo, hi = torch.cuda.Stream.priority_range()       # (least, greatest); larger number = lower priority
-            _side_streams[dev] = torch.cuda.Stream(device=dev, priority=lo)
-        else:
-            _side_streams[dev] = torch.cuda.Stream(device=dev)
+        _side_streams[dev] = torch.cuda.Stream(device=dev)
     return _side_streams[dev]
 
 
@@ -94,8 +86,6 @@ def defer_on_side(fn, *tensors):
     if not _side_stream_enabled():
         return fn()
     _deferred.append((fn, tensors))
-    if not _SIDE_DEFER:
-        flush_side()
     if not _join_scheduled:
         _join_scheduled = True
         main = torch.cuda.current_stream()
