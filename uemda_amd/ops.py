@@ -42,16 +42,25 @@ def stream():
 # Weight-gradient kernels (MFMA-bound, nothing downstream in the backward pass reads their output) can run on a side
 # stream beside the HBM-bound BatchNorm backward passes of the main stream (scripts/overlap_probe.py: 43 % of the
 # BatchNorm time disappears under a concurrently running wgrad).  blocks.BottleneckFn issues them through defer_on_side / flush_side.
-# UEM_WGRAD_STREAM=0 turns it off.  (A first version used Tensor.record_stream for the tensors the side stream reads;
-# that made the caching allocator reserve 4x the memory, the step time unstable and the 2-rank rehearsal stall for
-# seconds -- the explicit lifetime rule in flush_side() replaced it.)
-WGRAD_STREAM = os.environ.get("UEM_WGRAD_STREAM", "1") != "0"
+# Default: on in a single-process run, off under data parallel with more than one rank: in the 2-rank rehearsal
+# (two processes sharing ONE GPU, gloo backend) the extra active stream made the step time unstable (286-458 ms
+# against 125-131 ms without it) -- most likely the inter-process time slicing of one device, which a real
+# one-process-per-GPU run does not have (the single-rank RCCL smoke is faster with it) -- but an 8-GPU RCCL run
+# cannot be rehearsed here, so the conservative default stands.  UEM_WGRAD_STREAM=1 / 0 forces it either way.
+# (A first version used Tensor.record_stream for the tensors the side stream reads; that made the caching allocator
+# reserve 4x the memory and the step time drift -- the explicit lifetime rule in flush_side() replaced it.)
+_WGRAD_STREAM_ENV = os.environ.get("UEM_WGRAD_STREAM")
+WGRAD_STREAM = _WGRAD_STREAM_ENV != "0"
 _side_streams = {}
 
 
 def _side_stream_enabled():
-    # per-launch event timing (bench.py's roofline leg) wants every kernel alone on the device
-    return WGRAD_STREAM and not PROF.enabled
+    if not WGRAD_STREAM or PROF.enabled:        # per-launch event timing wants every kernel alone on the device
+        return False
+    if _WGRAD_STREAM_ENV is not None:
+        return True
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def side_stream():
