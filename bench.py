@@ -30,31 +30,57 @@ BF16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the
 GFLOP_PER_TILE = {("resnet50", "aspp", 512): (66.66, 198.8)}       # BASELINE.md section 3 (fwd, fwd+bwd)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle's SSL step (R50-ASPP, fp32) on the host cores, on 512x512 tiles like the metric but at the
-    per-domain batch 2 of BASELINE config 1 (a bounded sample: ~1.5 s per step on 16 threads)."""
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (CPU restatement of the reference, kind "port") on the host cores, as SURVEY 8(d) specifies: BASELINE
+    config 1 (B=2, 256x256, fp32), R50-ASPP and R50-PPM, (i) train_src-style and (ii) train_ssl_uem-style steps, 1 warm-up
+    + 3 timed steps each on all of the box's CPU share, plus one timed step of the ASPP pair pinned to ONE thread.
+    `value` is the leg that matches the metric (R50-ASPP ssl step on 512x512 tiles, counting source + target)."""
     from oracle import synth
     from oracle.model import OracleDeeplabv2
-    from oracle.step import HYPER, SGDState, ssl_step
+    from oracle.step import HYPER, SGDState, src_step, ssl_step
     from oracle.weights import det_state_dict
     threads = min(16, os.cpu_count() or 1)            # the one-GPU box's CPU share
+    t_stop = time.time() + seconds_budget
+
+    def leg(head, style, size, nthreads, warm, timed):
+        torch.set_num_threads(nthreads)
+        ppm = head == "ppm"
+        sd = det_state_dict("resnet50", 6, ppm, seed=2333)
+        model = OracleDeeplabv2(sd, "resnet50", 6, ppm)
+        opt = SGDState(model.parameters(), 0.9, 5e-4)
+        batch = synth.make_batch(B=2, H=size, W=size, C=6, k=2048, seed=2333)
+        protos = batch["prototypes"]
+        times = []
+        for i in range(warm + timed):
+            t0 = time.time()
+            if style == "ssl":
+                protos = ssl_step(model, opt, protos, batch, 1e-3, HYPER)["prototypes"]
+            else:
+                src_step(model, opt, batch, 1e-3, HYPER)
+            if i >= warm:
+                times.append(time.time() - t0)
+            if time.time() > t_stop and times:
+                break
+        best = min(times)
+        return dict(tiles_per_s=round((4.0 if style == "ssl" else 2.0) / best, 3), s_per_step=round(best, 3),
+                    timed_steps=len(times), threads=nthreads)
+
+    headline = leg("aspp", "ssl", 512, threads, 1, 3)
+    cfg1 = {}
+    for head in ("aspp", "ppm"):
+        for style in ("src", "ssl"):
+            if time.time() < t_stop:
+                cfg1[f"r50-{head} {style} {threads} threads"] = leg(head, style, 256, threads, 1, 3)
+    for style in ("src", "ssl"):
+        if time.time() < t_stop:
+            cfg1[f"r50-aspp {style} 1 thread"] = leg("aspp", style, 256, 1, 0, 1)       # no warm-up: one cold step
     torch.set_num_threads(threads)
-    sd = det_state_dict("resnet50", 6, False, seed=2333)
-    model = OracleDeeplabv2(sd, "resnet50", 6, False)
-    opt = SGDState(model.parameters(), 0.9, 5e-4)
-    batch = synth.make_batch(B=2, H=512, W=512, C=6, k=2048, seed=2333)
-    protos = batch["prototypes"]
-    out = ssl_step(model, opt, protos, batch, 1e-3, HYPER)           # warm-up
-    times = []
-    t_end = time.time() + seconds_budget
-    while len(times) < 3 or (time.time() < t_end and len(times) < 8):
-        t0 = time.time()
-        out = ssl_step(model, opt, out["prototypes"], batch, 1e-3, HYPER)
-        times.append(time.time() - t0)
-    best = min(times)
-    return dict(value=round(4.0 / best, 3), unit="tiles/s", cores=threads, kind="port",
-                sample=f"oracle (CPU restatement) ssl_step, R50-ASPP, 2 source + 2 target 512x512 tiles per step, fp32, best of {len(times)} steps "
-                       f"({best:.3f} s/step), {os.cpu_count()} host CPUs visible")
+    return dict(value=headline["tiles_per_s"], unit="tiles/s", cores=threads, kind="port",
+                sample=f"oracle (CPU restatement) ssl_step, R50-ASPP, 2 source + 2 target 512x512 tiles per step, fp32, best of "
+                       f"{headline['timed_steps']} steps ({headline['s_per_step']:.3f} s/step), {os.cpu_count()} host CPUs visible; "
+                       f"config1 = BASELINE config 1 (B=2, 256x256 tiles: tiles/s counts 256x256 tiles, src = 2 per step, "
+                       f"ssl = 4 per step)",
+                config1=cfg1)
 
 
 def main():
@@ -70,7 +96,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force the CUDA device index (rehearsal on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="all-reduce the whole gradient arena after backward")
-    ap.add_argument("--dump-params", default="", help="write a parameter checksum after the run (DP rehearsals)")
+    ap.add_argument("--dump-params", default="", help="write a parameter checksum after the run (DP rehearsals); with "
+                    "<path>.rank<r>.pt: prototypes, post-run parameter samples and the FIRST step's reduced gradient")
+    ap.add_argument("--data-rank", type=int, default=None, help="use this rank's synthetic tiles (single-process leg of the "
+                    "data-parallel test: the gradient rank r contributes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--conv-prec", default="fp32", choices=["fp32", "mixed", "bf16x3", "bf16"],
@@ -103,12 +132,15 @@ def main():
     model = Deeplabv2(cfg).cuda()                 # random init of the reference's architecture (no checkpoints)
     wrapper = udp.DataParallel(model, overlap=not args.no_overlap) if (world > 1 or udp.FORCE) else None
     # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
-    pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + rank)
+    data_rank = rank if args.data_rank is None else args.data_rank
+    pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + data_rank)
     rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]
     batch = {k: (v.cuda().repeat((rep,) + (1,) * (v.dim() - 1))[:B].contiguous() if k != "prototypes" else v.cuda())
              for k, v in pool.items()}
     aligner = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
-    aligner.prototypes = batch["prototypes"].clone()
+    # replicas start from the same prototypes: seeded independently of the rank, then broadcast
+    aligner.prototypes = synth.make_batch(B=1, H=32, W=32, C=C, k=2048, seed=2333)["prototypes"].cuda().contiguous()
+    udp.broadcast_flat(aligner.prototypes)
     opt = FusedSGD(model, lr=HYPER["lr"], momentum=HYPER["momentum"], weight_decay=HYPER["weight_decay"])
     state = StepState(C)
     sup_ignore = (S // 16) * (S // 16)            # explicit ignored superpixel id (DP-safe)
@@ -125,10 +157,19 @@ def main():
         ev.record()
         marks.append((name, ev))
 
+    first_grad = {}
+
+    def grab_first_grad(name):          # --dump-params: the reduced gradient of the very first step, before the optimizer
+        if name == "grad_allreduce_wait" and not first_grad:
+            _, garena, n = model.flat_parameters()
+            scale = 1.0 / world
+            first_grad["sample"] = (garena[:n:101].double() * scale).cpu()
+            first_grad["norm"] = float((garena[:n].double() * scale).norm())
+
     def one_step(i, marked=False):
         if args.workload == "ssl":
             return ssl_step(model, aligner, opt, state, batch, lr_at(i + 1), dp=wrapper, sup_ignore_id=sup_ignore,
-                            mark=mark if marked else None)
+                            mark=mark if marked else (grab_first_grad if args.dump_params and not first_grad else None))
         return src_step(model, opt, state, batch, lr_at(i + 1), dp=wrapper)
 
     def barrier():
@@ -190,10 +231,15 @@ def main():
         if prof:
             fam, agg = max(prof.items(), key=lambda kv: kv[1]["ms"])
             ach = agg["flops"] / (agg["ms"] * 1e-3) / 1e12
+            # HBM bytes per launch of that family from the PMC passes (scripts/pmc_traffic.py), valid ONLY for the
+            # configuration they were collected on: any other run reports null
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}"
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(fam)
+                tj = json.load(open(tfile))
+                if tj.get("config") == key:
+                    traffic = tj.get(fam)
             roof = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic,
                         launches_per_step=agg["launches"] // prof_steps,
@@ -214,7 +260,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text}, "
-                                   f"random init; tiles counted = source + target",
+                                   f"random init; tiles counted = source + target; the batch repeats {min(B, 4)} unique seeded "
+                                   f"tiles x{rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
+                                   f"events with the wgrad side stream off",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
                        "wgrad_side_stream": side_stream_on},
             "loss_source": round(float(out["loss_source"]), 5),
@@ -244,6 +292,10 @@ def main():
         arena, _, n = model.flat_parameters()
         with open(f"{args.dump_params}.rank{rank}", "w") as f:
             f.write(f"{float(arena[:n].double().sum()):.10e} {float(arena[:n].double().abs().sum()):.10e}\n")
+        torch.save(dict(params_sample=arena[:n:101].cpu(), params_sum=float(arena[:n].double().sum()),
+                        prototypes=aligner.prototypes.cpu(), first_grad_sample=first_grad.get("sample"),
+                        first_grad_norm=first_grad.get("norm"), unpaired_forwards=getattr(wrapper, "unpaired_forwards", None),
+                        wgrad_side_stream=side_stream_on), f"{args.dump_params}.rank{rank}.pt")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -170,9 +170,13 @@ int uem_index_max(const int64_t* idx, int64_t count, int64_t* out, void* stream)
 int uem_scatter(const float* src, const int64_t* index, float* out, float* workspace /* B*S floats */,
                 int B, int N, int C, int S, int reduce, void* stream);
 /* per-superpixel max of an NCHW-planar soft label: seg_keys[b][s][c] (order-preserving uint keys,
- * caller zero-fills), LDS-table pre-reduction per 64x16 pixel tile.         alignment.py:244-245   */
+ * caller zero-fills), LDS-table pre-reduction per 64x16 pixel tile.         alignment.py:244-245
+ * The reference sizes the table from the batch (dim_size = index.max()+1, alignment.py:241-245); here S is the
+ * caller's capacity and `out_of_range` (device int, caller zero-fills, may be NULL) receives the largest id
+ * outside [0, S) (INT_MAX for a negative one): such ids are skipped here and uem_label_refine leaves their
+ * pixels' weights untouched, so a too-small table is reported, never folded into another segment.          */
 int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_keys, int B, int C,
-                           int H, int W, int S, void* stream);
+                           int H, int W, int S, int* out_of_range, void* stream);
 /* fused three-view refinement (alignment.py:209-293) for modes all / s / p / l:
  *   soft_out = normalise( weight * soft ), and per-(b,c) max of soft_out into plane_max (uint bits of
  *   non-negative floats; written, not accumulated) for the selection pass.  sim / logits are (B,h,w,C). */

@@ -38,9 +38,11 @@ def collect(dirname, counter):
 
 
 def main():
+    # usage: pmc_traffic.py <fetch_dir> <write_dir> "<config key>"   (key = bench.py's: "<model>-<head> <workload> B=.. size=.. prec=..")
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    config = sys.argv[3] if len(sys.argv) > 3 else "resnet50-aspp ssl B=32 size=512 prec=fp32"
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
-    out = {}
+    out = {"config": config}
     for fam in fe:
         nf, vf = fe[fam]
         nw, vw = wr.get(fam, (1, 0.0))

@@ -73,6 +73,136 @@ def test_two_rank_gloo_data_parallel_contract():
     assert res[0][1] == pytest.approx(res[1][1], rel=0, abs=0)         # replicas agree bit-for-bit
 
 
+class _Trig(torch.autograd.Function):
+    """stands in for blocks.BottleneckFn: identity forward, calls the block's data-parallel trigger in backward"""
+
+    @staticmethod
+    def forward(ctx, x, blk):
+        ctx.blk = blk
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        cb = getattr(ctx.blk, "_uem_after_backward", None)
+        if cb is not None:
+            cb()
+        return g, None
+
+
+def _toy_model():
+    """The attributes DataParallel touches (flat_parameters, encoder.resnet.layer3[0], forward pre-hook) around a
+    three-layer network whose parameters are views of one flat arena, in forward order like Deeplabv2's."""
+    import torch.nn as nn
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = nn.Module()
+            self.encoder.resnet = nn.Module()
+            self.encoder.resnet.stem = nn.Linear(8, 8, bias=False)
+            self.encoder.resnet.layer3 = nn.ModuleList([nn.Linear(8, 8, bias=False)])
+            self.head = nn.Linear(8, 4, bias=False)
+            ps = list(self.parameters())
+            n = sum(p.numel() for p in ps)
+            self._arena, self._garena, self._n = torch.zeros(n), torch.zeros(n), n
+            off = 0
+            g = torch.Generator().manual_seed(3)
+            for p in ps:
+                v = self._arena[off:off + p.numel()].view_as(p)
+                v.copy_(torch.randn(p.shape, generator=g))
+                p.data = v
+                p.grad = self._garena[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+        def flat_parameters(self):
+            return self._arena, self._garena, self._n
+
+        def forward(self, x):
+            r = self.encoder.resnet
+            return self.head(_Trig.apply(r.layer3[0](torch.relu(r.stem(x))), r.layer3[0]))
+
+    return Toy()
+
+
+def _dp_object_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from uemda_amd import dp
+    from uemda_amd.ops import UemError
+    dp.init("gloo")
+    torch.manual_seed(100 + rank)                      # every rank would start from different weights ...
+    model = _toy_model()
+    model._arena.add_(float(rank))
+    wrap = dp.DataParallel(model)                      # ... until the broadcast
+    assert wrap._split == 64 and wrap._active
+    w0 = model._arena.clone()
+    g = torch.Generator().manual_seed(rank)
+    xs, xt = torch.randn(5, 8, generator=g), torch.randn(5, 8, generator=g)
+    model.train()
+    model._garena.zero_()
+    loss = model(xs).square().mean() + model(xt).square().mean()       # two forwards, ONE backward (the SSL step)
+    loss.backward()
+    assert wrap._pending is not None and wrap._bwd_calls == 2          # the tail bucket left during backward
+    prescale = wrap.reduce_gradients()
+    reduced = model._garena.clone() * prescale
+    # reference: every rank's local gradient, recomputed without the wrapper, averaged
+    torch.testing.assert_close(reduced, sum(_solo_grad(w0, r, (0, 1)) for r in range(world)) / world, rtol=1e-6, atol=1e-7)
+    # a forward that never sees a backward: no early bucket, full all-reduce, counters reset, replicas still agree
+    model._garena.zero_()
+    model(xs)
+    model(xt).square().mean().backward()
+    assert wrap._pending is None
+    wrap.reduce_gradients()
+    assert wrap.unpaired_forwards == 1 and wrap._fwd_calls == 0
+    torch.testing.assert_close(model._garena * prescale, sum(_solo_grad(w0, r, (1,)) for r in range(world)) / world,
+                               rtol=1e-6, atol=1e-7)
+    # a train-mode forward after the early bucket went out must not pass silently
+    model._garena.zero_()
+    model(xs).square().mean().backward()
+    try:
+        model(xt)
+        raised = False
+    except UemError:
+        raised = True
+    assert raised
+    wrap.reduce_gradients()
+    out.put((rank, float(w0.sum()), float(reduced.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _solo_grad(w0, r, which):
+    """gradient of rank r's loss over its inputs `which` (0 = first, 1 = second tensor of its seeded pair), no wrapper"""
+    m = _toy_model()
+    m._arena.copy_(w0)
+    g = torch.Generator().manual_seed(r)
+    xs = [torch.randn(5, 8, generator=g), torch.randn(5, 8, generator=g)]
+    m._garena.zero_()
+    sum(m(xs[i]).square().mean() for i in which).backward()
+    return m._garena.clone()
+
+
+def test_two_rank_gloo_data_parallel_object():
+    """uemda_amd.dp.DataParallel itself with two ranks: broadcast, bucket split at layer3[0], trigger counting over two
+    forwards and one backward, asynchronous tail all-reduce + head all-reduce, the pairing guards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_object_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1:] == res[1][1:]                                   # same start weights, same reduced gradient
+
+
+def test_dropout_seed_is_per_rank():
+    from uemda_amd.models.ppm import dropout_seed
+    assert len({dropout_seed(1, r) for r in range(8)}) == 8 and dropout_seed(1, 0) != dropout_seed(2, 0)
+
+
 def test_weak_scaling_accounting():
     """bench.py counts source + target tiles of every rank per step (value = whole-job tiles/s)."""
     B, world, steps, elapsed = 32, 8, 5, 2.0

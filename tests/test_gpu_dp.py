@@ -1,31 +1,137 @@
-"""RCCL plumbing on one GPU: the data-parallel code paths (process group over backend nccl = RCCL, parameter
-broadcast, two-bucket gradient all-reduce overlapped with backward, prototype-sum all-reduce) forced on with a single
-rank.  The collectives are trivial at world size 1 but real; the multi-rank arithmetic is covered by the gloo tests
-(tests/test_dp_gloo.py).  Runs bench.py in a child process so that the test process keeps no process group."""
+"""Data parallel on the GPU box (one MI355X): the REAL `uemda_amd.dp.DataParallel` object that bench.py runs under
+torchrun -- parameter broadcast, forward/backward pairing, the layer3[0] bucket trigger, the asynchronous tail
+all-reduce, the side-stream join, the prototype partial-sum all-reduce -- driven by two fresh child processes that
+share device 0 (backend gloo: RCCL refuses two ranks on one device).  Plus the single-rank RCCL plumbing smoke.
+Every run is `bench.py` in child processes, so the test process keeps no process group and never re-execs."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--batch", "4", "--size", "256", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-precisions",
+          "--no-kernel-events"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def _bench(extra_env, *args):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "4", "--size", "256", "--steps", "2",
-                          "--warmup", "1", "--no-cpu-baseline", "--no-other-precisions", *args],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, *args],
                          env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, out.stderr[-2000:]
     return json.loads(lines[-1])
 
 
+def _two_ranks(path, *args, env=None):
+    """bench.py as 2 ranks on device 0; returns (rank-0 JSON line, [rank dumps])."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
+                 LOCAL_RANK=str(r), WORLD_SIZE="2", **(env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--device", "0", *COMMON, "--dump-params", path, *args],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    return line, [torch.load(f"{path}.rank{r}.pt") for r in range(2)]
+
+
 def test_single_rank_rccl_step_matches_plain_step():
     plain = _bench({})
-    forced = _bench({"UEM_DP_FORCE": "1", "MASTER_PORT": "29533"})
+    forced = _bench({"UEM_DP_FORCE": "1", "MASTER_PORT": str(_free_port())})
     assert forced["n_gpus"] == 1 and forced["value"] > 0
     # same seeds, same arithmetic: the source loss after the same number of steps agrees (atomics reorder the last bits)
     assert forced["loss_source"] == pytest.approx(plain["loss_source"], rel=1e-4)
+
+
+def test_two_rank_data_parallel_object(tmp_path):
+    line, (r0, r1) = _two_ranks(str(tmp_path / "ov"))
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2"
+    # replicas: parameters (3 optimizer steps) and prototypes bit-identical on both ranks
+    assert r0["params_sum"] == r1["params_sum"] and torch.equal(r0["params_sample"], r1["params_sample"])
+    assert torch.equal(r0["prototypes"], r1["prototypes"])
+    assert r0["unpaired_forwards"] == 0
+    # the reduced gradient every rank steps with is the same one
+    assert torch.equal(r0["first_grad_sample"], r1["first_grad_sample"])
+    # overlap (early tail bucket) vs one all-reduce after backward: the same sums (two RUNS differ in the last bits only
+    # because the split-K weight gradients are accumulated with fp32 atomics)
+    def close(a, b, tol):
+        return float((a.double() - b.double()).norm() / b.double().norm()) < tol
+    _, (n0, n1) = _two_ranks(str(tmp_path / "nov"), "--no-overlap")
+    assert torch.equal(n0["params_sample"], n1["params_sample"]) and torch.equal(n0["prototypes"], n1["prototypes"])
+    assert close(n0["first_grad_sample"], r0["first_grad_sample"], 1e-5)
+    assert close(n0["params_sample"], r0["params_sample"], 1e-5) and close(n0["prototypes"], r0["prototypes"], 1e-5)
+    # the reduced gradient = mean of what each rank computes alone on its own tiles from the same weights
+    alone = []
+    for r in range(2):
+        _bench({}, "--data-rank", str(r), "--dump-params", str(tmp_path / f"solo{r}"))
+        alone.append(torch.load(str(tmp_path / f"solo{r}") + ".rank0.pt"))
+    mean = 0.5 * (alone[0]["first_grad_sample"] + alone[1]["first_grad_sample"])
+    rel = float((r0["first_grad_sample"] - mean).norm() / mean.norm())
+    assert rel < 1e-4, rel                      # fp32 atomics / summation order only
+    assert float((alone[0]["first_grad_sample"] - alone[1]["first_grad_sample"]).norm() / mean.norm()) > 1e-2   # the ranks' tiles differ
+    # with the weight gradients on the side stream (the single-process default) the join before each bucket must hold
+    line_s, (s0, s1) = _two_ranks(str(tmp_path / "side"), env={"UEM_WGRAD_STREAM": "1"})
+    assert line_s["config"]["wgrad_side_stream"] is True and line["config"]["wgrad_side_stream"] is False
+    assert torch.equal(s0["params_sample"], s1["params_sample"]) and torch.equal(s0["prototypes"], s1["prototypes"])
+    rel = float((s0["first_grad_sample"] - mean).norm() / mean.norm())
+    assert rel < 1e-4, rel
+
+
+def test_forward_backward_pairing_guard():
+    """A train-mode forward that never gets a backward must not desynchronise the bucket trigger."""
+    from uemda_amd import dp as udp
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.ops import UemError
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=6, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=6,
+               is_ins_norm=True)
+    model = Deeplabv2(cfg).cuda().train()
+    wrap = udp.DataParallel(model)
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    model(x)                                    # e.g. a validation pass left in .train(): no backward follows
+    p1, p2, _ = model(x)
+    (p1.sum() + p2.sum()).backward()
+    assert wrap._fwd_calls == 2 and wrap._bwd_calls == 1 and wrap._pending is None
+    assert wrap.reduce_gradients() == 1.0
+    assert wrap.unpaired_forwards == 1 and wrap._fwd_calls == 0 and wrap._bwd_calls == 0
+    p1, p2, _ = model(x)                        # the next step pairs up again
+    (p1.sum() + p2.sum()).backward()
+    assert wrap._fwd_calls == 1 and wrap._bwd_calls == 1
+    wrap.reduce_gradients()
+    with pytest.raises(UemError, match="backward passes"):
+        wrap._on_trigger_backward()             # a backward the wrapper saw no forward for
+
+
+def test_dropout_masks_differ_between_ranks():
+    from uemda_amd import ops
+    from uemda_amd.models.ppm import dropout_seed
+    a = torch.ones(8, 4, 4, 512, device="cuda")
+    masks = []
+    for rank in (0, 1):
+        m = torch.empty(8, 512, device="cuda")
+        ops.call("uem_dropout2d", ops.ptr(a), ops.ptr(a.clone()), ops.ptr(m), 8, 16, 512, 0.1, dropout_seed(1, rank), ops.stream())
+        masks.append(m.cpu())
+    assert not torch.equal(masks[0], masks[1])
+    assert dropout_seed(1, 0) != dropout_seed(2, 0)

@@ -45,7 +45,6 @@ def test_pearson_golden(aligner):
 def test_label_refine_golden(aligner, mode):
     g = load_golden("label_refine")
     aligner.prototypes = dev(g["protos"]).contiguous()
-    aligner._sup_capacity = 0
     out = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]), True, mode, 2.0)
     torch.testing.assert_close(out.cpu(), g["out_" + mode], rtol=2e-5, atol=1e-6)
 
@@ -53,7 +52,6 @@ def test_label_refine_golden(aligner, mode):
 def test_label_refine_irregular_single_pred_and_explicit_ignore(aligner):
     g = load_golden("label_refine")
     aligner.prototypes = dev(g["protos"]).contiguous()
-    aligner._sup_capacity = 0
     out = aligner.label_refine(dev(g["sup_irregular"]), dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]), True, "all", 2.0)
     torch.testing.assert_close(out.cpu(), g["out_all_irregular"], rtol=2e-5, atol=1e-6)
     out = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), dev(g["p1"]), dev(g["soft"]), True, "l", 1.5)
@@ -63,6 +61,50 @@ def test_label_refine_irregular_single_pred_and_explicit_ignore(aligner):
     torch.testing.assert_close(out.cpu(), g["out_all"], rtol=2e-5, atol=1e-6)
     same = aligner.label_refine(dev(g["sup"]), dev(g["feat"]), dev(g["p1"]), dev(g["soft"]), refine=False)
     assert torch.equal(same.cpu(), g["soft"])
+
+
+def test_label_refine_superpixel_table_is_sized_per_call_and_reports_overflow():
+    """The reference sizes the scatter from every batch (alignment.py:241-245).  A second batch whose ids exceed the
+    first batch's must be refined exactly (the table used to be frozen by the first call, later ids read
+    segment 0); an id beyond the table's capacity raises instead of borrowing another segment's maxima."""
+    from oracle import gast
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.ops import UemError
+    g = load_golden("label_refine")
+    al = Aligner(None, feat_channels=64, class_num=C, ignore_label=-1, decay=0.996)
+    al.prototypes = dev(g["protos"]).contiguous()
+    args = (g["feat"], [g["p1"], g["p2"]], g["soft"])
+    dargs = (dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]))
+    first = al.label_refine(dev(g["sup"]), *dargs, True, "all", 2.0)
+    torch.testing.assert_close(first.cpu(), g["out_all"], rtol=2e-5, atol=1e-6)
+    # same partition, ids relabelled far beyond the first batch's maximum (a crop of a larger image: ids up to 4096)
+    sup2 = g["sup"] * 97 + 1000
+    sup2[g["sup"] == g["sup"].max()] = 4096
+    assert int(sup2.max()) > int(g["sup"].max())
+    out2 = al.label_refine(dev(sup2), *dargs, True, "all", 2.0)
+    ref2 = gast.label_refine(sup2, args[0], args[1], args[2], g["protos"])
+    torch.testing.assert_close(out2.cpu(), ref2, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(out2.cpu(), g["out_all"], rtol=2e-5, atol=1e-6)      # relabelling changes nothing
+    # explicit ignored id smaller than the ids present (the hole the explicit path had: S = ignore + 1)
+    out3 = al.label_refine(dev(sup2), *dargs, True, "all", 2.0, sup_ignore_id=16)
+    ref3 = gast.label_refine(sup2, args[0], args[1], args[2], g["protos"], sup_ignore_id=16)
+    torch.testing.assert_close(out3.cpu(), ref3, rtol=2e-5, atol=1e-6)
+    al.check_superpixel_ids()
+    # beyond the capacity: reported, never folded into segment 0
+    sup4 = sup2.clone()
+    sup4[sup4 == 4096] = 1 << 20
+    al.label_refine(dev(sup4), *dargs, True, "all", 2.0)
+    with pytest.raises(UemError, match="outside the segment table"):
+        al.check_superpixel_ids()
+    al.sup_capacity = (1 << 20) + 1                                   # the documented remedy
+    out5 = al.label_refine(dev(sup4), *dargs, True, "all", 2.0)
+    al.check_superpixel_ids()
+    torch.testing.assert_close(out5.cpu(), g["out_all"], rtol=2e-5, atol=1e-6)
+    neg = g["sup"].clone()
+    neg[0, 0, 0, 0] = -3
+    al.label_refine(dev(neg), *dargs, True, "s", 2.0)
+    with pytest.raises(UemError):
+        al.check_superpixel_ids()
 
 
 def test_downscale_label_golden():
@@ -148,7 +190,6 @@ def test_ragged_and_empty_edges():
     loss = loss_calc([dev(lg).requires_grad_(True)], dev(all_ign), CrossEntropy(-1), multi=True)
     assert float(loss) == 0.0
     sup_all_ign = torch.full((3, 1, 80, 48), 7, dtype=torch.int64)
-    al._sup_capacity = 0
     out = al.label_refine(dev(sup_all_ign), dev(feat), [dev(p1), dev(p2)], dev(b["label_t_soft"]))
     ref = gast.label_refine(sup_all_ign, feat, [p1, p2], b["label_t_soft"], b["prototypes"])
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=1e-6)

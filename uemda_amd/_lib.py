@@ -69,7 +69,7 @@ SIGNATURES = {
     "uem_pearson_dist": [P, P, P, P, I, I, I, P],
     "uem_index_max": [P, L, P, P],
     "uem_scatter": [P, P, P, P, I, I, I, I, I, P],
-    "uem_segment_max_planar": [P, P, P, I, I, I, I, I, P],
+    "uem_segment_max_planar": [P, P, P, I, I, I, I, I, P, P],
     "uem_label_refine": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
     "uem_label_refine_workspace_floats": [I, I, I, I],
     "uem_plane_max": [P, P, I, I, L, P],

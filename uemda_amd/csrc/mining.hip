@@ -169,7 +169,8 @@ extern "C" int uem_index_max(const int64_t* idx, int64_t count, int64_t* out, vo
 template <int CMAX>
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ soft,
                                                           const int64_t* __restrict__ sup,
-                                                          uint32_t* __restrict__ seg, int C, int H, int W, int S) {
+                                                          uint32_t* __restrict__ seg, int C, int H, int W, int S,
+                                                          int* __restrict__ oor) {
     __shared__ int keys[SEG_SLOTS];
     __shared__ uint32_t vals[SEG_SLOTS][CMAX];
     const int tid = threadIdx.x;
@@ -185,13 +186,16 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
     const float* sb = soft + (size_t)b * C * plane;
     const int64_t* ib = sup + (size_t)b * plane;
     uint32_t* segb = seg + (size_t)b * S * C;
+    int bad = 0;                                        // largest id outside [0, S) seen by this thread (negative ids count as INT_MAX)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int y = blockIdx.y * 16 + (tid >> 6) + 4 * j;
         if (x < W && y < H) {
             const size_t p = (size_t)y * W + x;
-            const int id = (int)ib[p];
-            if (id >= 0 && id < S) {
+            const int64_t id64 = ib[p];
+            const int id = (int)id64;
+            if (id64 < 0 || id64 >= (int64_t)S) bad = max(bad, id64 < 0 || id64 > 0x7fffffffLL ? 0x7fffffff : id);
+            else {
                 uint32_t hsh = ((uint32_t)id * 2654435761u) >> 25;   // 7 bits
                 int slot = -1;
                 for (int probe = 0; probe < SEG_SLOTS; ++probe) {
@@ -219,15 +223,22 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
             if (kv) atomicMax(&segb[(size_t)id * C + c], kv);
         }
     }
+    // ids the table cannot hold are never folded into another segment: they are reported (the host raises) and the
+    // refinement kernel leaves those pixels' weights untouched
+    if (oor != nullptr && __any(bad != 0)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bad = max(bad, __shfl_xor(bad, o, 64));
+        if ((tid & 63) == 0) atomicMax(oor, bad);
+    }
 }
 extern "C" int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_keys, int B, int C,
-                                      int H, int W, int S, void* stream) {
+                                      int H, int W, int S, int* out_of_range, void* stream) {
     UEM_REQUIRE(soft && sup && seg_keys, "segment_max: null pointer");
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && H > 0 && W > 0 && S > 0, "segment_max: bad shape");
     dim3 grid((unsigned)uem_cdiv(W, 64), (unsigned)uem_cdiv(H, 16), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 8) segment_max_kernel<8><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S);
-    else segment_max_kernel<16><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S);
+    if (C <= 8) segment_max_kernel<8><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
+    else segment_max_kernel<16><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
     return uem_check_launch("segment_max");
 }
 
@@ -349,11 +360,18 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
         }
         if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_S) {          // superpixel view
             const int64_t id = sup[(size_t)b * plane + p];
-            const bool ignored = (id == *ignore_id);
+            const bool inrange = id >= 0 && id < (int64_t)S;
+            // an id outside the table (reported by uem_segment_max_planar, the host raises) never borrows another
+            // segment's maxima: the pixel keeps its weight, as an ignored one does
+            const bool ignored = (id == *ignore_id) || !inrange;
             float v[CMAX];
-            const uint32_t* sg = seg + ((size_t)b * S + (size_t)(id >= 0 && id < S ? id : 0)) * C;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) if (c < C) { uint32_t kv = sg[c]; v[c] = kv ? key2f(kv) : 0.f; }
+            for (int c = 0; c < CMAX; ++c) v[c] = 0.f;
+            if (inrange) {
+                const uint32_t* sg = seg + ((size_t)b * S + (size_t)id) * C;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) if (c < C) { uint32_t kv = sg[c]; v[c] = kv ? key2f(kv) : 0.f; }
+            }
             softmax_maxnorm<CMAX>(v, C, inv_temp);
             if (mode == UEM_REFINE_ALL) {
 #pragma unroll

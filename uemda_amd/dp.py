@@ -77,9 +77,10 @@ class DataParallel:
         self._pending = None
         self._fwd_calls = 0
         self._bwd_calls = 0
+        self.unpaired_forwards = 0          # train-mode forwards that never saw a backward (diagnostic)
         self._active = self.world > 1 or (FORCE and dist.is_initialized())
-        if overlap and self._active:
-            self._install_overlap()
+        if overlap:
+            self._install_overlap()     # also with one rank: the forward/backward pairing is checked either way
 
     # ---- overlap machinery -------------------------------------------------------------------------------
     def _install_overlap(self):
@@ -99,11 +100,18 @@ class DataParallel:
 
     def _on_forward(self, module, args):
         if module.training and torch.is_grad_enabled():
+            if self._pending is not None:
+                raise ops.UemError("DataParallel: train-mode forward after the early gradient bucket went out; gradients of "
+                                   "this forward would miss it -- run every forward of a step before its backward, "
+                                   "or construct DataParallel(model, overlap=False)")
             self._fwd_calls += 1
 
     def _on_trigger_backward(self):
         self._bwd_calls += 1
-        if self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
+        if self._bwd_calls > self._fwd_calls:
+            raise ops.UemError(f"DataParallel: {self._bwd_calls} backward passes through the model since the last "
+                               f"reduce_gradients() but only {self._fwd_calls} train-mode forwards were counted")
+        if self._active and self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
             _, garena, n = self.model.flat_parameters()
             ops.join_side_stream()          # weight gradients run on a side stream: the tail must be complete first
             self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
@@ -112,6 +120,15 @@ class DataParallel:
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
         ops.join_side_stream()
+        if self._split is not None and self._fwd_calls != self._bwd_calls:
+            # a train-mode forward whose graph never ran backward (a validation pass left in .train(), a dropped
+            # output): the early bucket was (rightly) not sent, nothing is wrong with THIS step's gradients, but
+            # left alone the counters would pair the next step's backward passes with stale forwards.  The whole
+            # arena goes out below and the counters start afresh.
+            if self._pending is not None:
+                raise ops.UemError("DataParallel: the early gradient bucket was sent before every backward pass had "
+                                   f"run ({self._fwd_calls} forwards, {self._bwd_calls} backwards)")
+            self.unpaired_forwards += self._fwd_calls - self._bwd_calls
         if self._active:
             if self._pending is not None:
                 dist.all_reduce(garena[:self._split], op=dist.ReduceOp.SUM)

@@ -92,7 +92,10 @@ class Aligner:
         """Three-view refinement of the soft pseudo label (alignment.py:194-293).
 
         `sup_ignore_id`: the ignored superpixel id; None reproduces the reference's batch-global
-        `label_t_sup.max()` (computed on the device, no host sync); pass H/16*W/16 under data parallel."""
+        `label_t_sup.max()` (computed on the device, no host sync).  Under data parallel pass the id the dataset's
+        edge shrinking wrote -- cnt_sup = (h/16)*(w/16) of the FULL image the superpixel map was computed on
+        (gast/superpixels.py:131,149), e.g. 1024 for 512x512 ISPRS tiles, 4096 for 1024x1024 LoveDA tiles cropped to
+        512x512 -- so that ranks whose crops miss the ignored id still agree."""
         if mode == 'n':
             raise UemError("label_refine(mode='n'): the kNN view is an n x n cdist over n = B*h*w pixels, "
                            "infeasible at the benchmark batch and flagged unusable by the reference author")
@@ -117,17 +120,16 @@ class Aligner:
                 lg1 = ops.as_nhwc(preds_t.detach()).contiguous()
         if mode in ('all', 's'):
             sup = label_t_sup.detach().contiguous().long()
+            self.check_superpixel_ids()                                # the previous call's range report, if any
             if sup_ignore_id is None:
-                ign = index_max(sup)                                   # alignment.py:241 (device scalar)
-                S = (H // 16) * (W // 16) + 1
-                if getattr(self, "_sup_capacity", 0) < 1:
-                    self._sup_capacity = max(S, int(ign.item()) + 1)   # one-time host sync to size the table
-                S = max(S, self._sup_capacity)
+                ign = index_max(sup)                                   # alignment.py:241 (device scalar, no host sync)
             else:
                 ign = torch.full((), int(sup_ignore_id), device=dev, dtype=torch.int64)
-                S = int(sup_ignore_id) + 1
+            S = self._sup_table_size(H, W, sup_ignore_id)
             seg = torch.zeros((B, S, C), device=dev, dtype=torch.int32)
-            call("uem_segment_max_planar", ptr(soft), ptr(sup), ptr(seg), B, C, H, W, S, stream())
+            oor = torch.zeros((), device=dev, dtype=torch.int32)
+            call("uem_segment_max_planar", ptr(soft), ptr(sup), ptr(seg), B, C, H, W, S, ptr(oor), stream())
+            self._report_superpixel_range(oor, S)
         out = torch.empty_like(soft)
         plane_max = torch.empty((B, C), device=dev, dtype=torch.int32)
         ws = torch.empty(_lib.load().uem_label_refine_workspace_floats(B, C, H, W), device=dev, dtype=torch.float32)
@@ -135,6 +137,44 @@ class Aligner:
              ptr(plane_max), ptr(ws), B, C, h, w, H, W, S, float(temp), _MODES[mode], stream())
         self._last_plane_max = plane_max
         return (out, plane_max) if return_plane_max else out
+
+    # ---- superpixel table capacity ------------------------------------------------------------------------
+    # The reference sizes the scatter from every batch's own maximum id (alignment.py:241-245, one host sync per
+    # call).  Here the table has a capacity fixed WITHOUT looking at the data -- ids of a 1024x1024 LSC map (region
+    # 16: up to 4096 segments + the ignored id 4096, gast/superpixels.py:131,149) or 4x the crop's own grid,
+    # whichever is larger, `sup_capacity` if the dataset's maps are denser -- and the kernels report ids beyond it
+    # through a device flag that is copied back asynchronously and checked at the next call / check_superpixel_ids():
+    # a too-small table raises UemError (pixels with such ids were left unrefined, never given another segment's
+    # maxima) instead of silently reading the wrong segment.
+    sup_capacity = 0
+
+    def _sup_table_size(self, H, W, sup_ignore_id):
+        S = max(4 * (H // 16) * (W // 16) + 1, 4097, int(self.sup_capacity))
+        if sup_ignore_id is not None:
+            S = max(S, int(sup_ignore_id) + 1)
+        return S
+
+    def _report_superpixel_range(self, oor, S):
+        host = torch.empty((), dtype=torch.int32, pin_memory=True)
+        host.copy_(oor, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._oor_pending = (ev, host, S, oor)
+
+    def check_superpixel_ids(self):
+        """Raise if the last label_refine saw a superpixel id outside its table (waits for that call only)."""
+        pend = getattr(self, "_oor_pending", None)
+        if pend is None:
+            return
+        self._oor_pending = None
+        ev, host, S, _keep = pend
+        ev.synchronize()
+        worst = int(host)
+        if worst != 0:
+            raise UemError(f"label_refine: superpixel id {'< 0 or >= 2^31' if worst == 0x7fffffff else worst} is outside the "
+                           f"segment table of {S} entries; the pixels carrying such ids were left unrefined. Set "
+                           f"aligner.sup_capacity to the dataset's superpixel count + 1 (cnt_sup of the full image, "
+                           f"reference gast/superpixels.py:131) and rerun the step")
 
     def refine_and_select(self, label_t_sup, feat_t, preds_t, label_t_soft, mode='all', temp=2.0, cutoff_top=0.8,
                           cutoff_low=0.6, sup_ignore_id=None):

@@ -14,6 +14,15 @@ from .blocks import _BN, _st_from, _st_tensor, grad_buffer, grad_ohwi
 _drop_counter = itertools.count(1)
 
 
+def dropout_seed(call_index, rank=None):
+    """Seed of one Dropout2d call: process seed x call counter x data-parallel rank (SURVEY 8e: per-rank RNG streams;
+    every rank is seeded alike by seed_torch(2333), so without the rank term all replicas would draw one mask)."""
+    if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return ((torch.initial_seed() * 1000003 + call_index) * 8191 + rank * 2654435761) % (2 ** 63 - 1) + 1
+
+
 def _avgpool(x, s):
     n, h, w, c = x.shape
     y = torch.empty((n, s, s, c), device=x.device, dtype=torch.float32)
@@ -51,7 +60,7 @@ class PPMHeadFn(Function):
         mask = None
         if training and drop.p > 0:
             mask = torch.empty((n, 512), device=feat.device, dtype=torch.float32)
-            seed = (torch.initial_seed() * 1000003 + next(_drop_counter)) % (2 ** 63 - 1) + 1
+            seed = dropout_seed(next(_drop_counter))
             call("uem_dropout2d", ptr(a), ptr(a), ptr(mask), n, h * w, 512, float(drop.p), seed, stream())
         C = conv4.weight.shape[0]
         w4 = torch.zeros((32, 1, 1, 512), device=feat.device, dtype=torch.float32)

@@ -49,6 +49,7 @@ def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id
     mark("grad_allreduce_wait")
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)             # :230-232 (clip 32 + SGD)
     mark("clip_sgd")
+    aligner.check_superpixel_ids()        # raises if this step's superpixel ids did not fit the segment table
     return dict(loss_source=loss_source.detach(), loss_target=loss_target.detach(), label_t_soft=soft,
                 label_t_hard=hard, label_s_ds=label_ds, pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
                 pred_t1=pred_t1.detach(), pred_t2=pred_t2.detach(), feat_s=feat_s.detach(), feat_t=feat_t.detach(),
@@ -112,6 +113,7 @@ def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_
     loss.backward()
     prescale = dp.reduce_gradients() if dp is not None else 1.0
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
+    aligner.check_superpixel_ids()
     return dict(loss_seg=loss_seg.detach(), loss_domain=loss_domain.detach() if torch.is_tensor(loss_domain) else loss_domain,
                 loss_align=loss_align.detach(), label_t_hard=hard, pred_s1=pred_s1.detach(), pred_t1=pred_t1.detach(),
                 grad_norm=optimizer.last_grad_norm)
