@@ -110,6 +110,46 @@ def test_conv_operand_prologue_affine_relu():
     torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), wr.grad, rtol=1e-4, atol=1e-3)
 
 
+WGRAD_DMA_CASES = [
+    # N, H, W, Cin, Cout, k, stride, dil, affine      (the shapes the LDS-DMA weight-gradient kernel takes: wgrad.hip)
+    (2, 16, 32, 128, 128, 3, 1, 1, True),       # 3 taps per block, 128x128 tiles, one 32-pixel step per row
+    (2, 16, 64, 64, 64, 3, 1, 1, True),         # 64x64 tiles, two steps per row
+    (1, 20, 32, 128, 64, 3, 1, 2, True),        # dilation 2 (layer4), 64 x 128 tile
+    (2, 24, 64, 64, 128, 3, 2, 1, True),        # stride 2 (first block of layer2/3): 65 staged pixels per step
+    (2, 16, 32, 128, 128, 3, 1, 1, False),      # no prologue (PPM 3x3): padding by the buffer bounds check alone
+    (3, 7, 9, 256, 128, 1, 1, 1, True),         # 1x1, M = 189: ragged last step
+    (2, 16, 16, 64, 256, 1, 1, 1, False),
+    (2, 16, 64, 128, 256, 1, 2, 1, False),      # downsample 1x1 stride 2
+    (2, 16, 64, 128, 64, 1, 2, 1, True),
+    (8, 32, 32, 128, 128, 3, 1, 1, True),       # enough rows for several pixel slices per tile (split-K) and both stages
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_DMA_CASES)
+def test_wgrad_dma_kernel_vs_torch(case):
+    from uemda_amd import ops
+    N, H, W, Cin, Cout, k, s, d, affine = case
+    pad = d * (k - 1) // 2
+    g = torch.Generator().manual_seed(sum(case[:8]) + 11)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    sc[::5] *= -1                                              # negative gammas too
+    xa = (F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if affine else x).double()
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xa, w, stride=s, padding=pad, dilation=d)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+    kw = dict(in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True) if affine else {}
+    ops.conv2d_wgrad(nhwc(x), nhwc(gy), dw, stride=s, pad=pad, dil=d, **kw)
+    ref = w.grad.permute(0, 2, 3, 1)
+    err = float((dw.double().cpu() - ref).norm() / ref.norm())
+    assert err < 2e-6, err
+    # the gradient ACCUMULATES (two forwards add into one arena)
+    ops.conv2d_wgrad(nhwc(x), nhwc(gy), dw, stride=s, pad=pad, dil=d, **kw)
+    assert float((dw.double().cpu() - 2 * ref).norm() / ref.norm()) < 4e-6
+
+
 def test_stem_conv_and_wgrad():
     from uemda_amd import ops
     g = torch.Generator().manual_seed(6)

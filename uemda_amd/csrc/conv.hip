@@ -641,6 +641,8 @@ struct WgradP {
     float* dw;
     int M, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, x_ld, dy_ld, relu;
     int rows_per_split;
+    int dbg;               // UEM_WGRAD_DBG (diagnostic builds of the schedule only; results are wrong when non-zero):
+                           // 1 = no global loads in the loop, 2 = no LDS stores in the loop, 4 = no atomics
 };
 
 // PREC as in conv_fwd_kernel.  The reduction runs over pixels, so both MFMA operands are needed k-major while
@@ -872,13 +874,17 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
         };
         int mb = mbeg;
         for (; mb + BK < mend; mb += BK) {
-            load_tiles(mb + BK);
+            if (!(p.dbg & 1)) load_tiles(mb + BK);
             mfma_phase();
             __syncthreads();
-            store_tiles();
+            if (!(p.dbg & 2)) store_tiles();
             __syncthreads();
         }
         mfma_phase();
+    }
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 1.2345f) p.dw[0] = 1.f;     // keep the accumulators alive
+        return;
     }
     const size_t row_ld = (size_t)taps * p.Cin;         // dW[o][tap][i]
     float* wbase = p.dw + (size_t)tap * p.Cin;
@@ -910,6 +916,8 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
 template <int TM, int TN, int WM, int WN, int WK, int MODE, int PREC = 0>
 static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     WgradP p = p0;
+    static const int dbg = getenv("UEM_WGRAD_DBG") ? atoi(getenv("UEM_WGRAD_DBG")) : 0;
+    p.dbg = dbg;
     const int tiles = (int)(uem_cdiv(p.Cout, TM) * p.KH * p.KW * uem_cdiv(p.Cin, TN));
     // split-K sizing.  The grid is sized to whole ROUNDS of the chip's resident-block slots (256 CUs x blocks per CU
     // at this tile's register footprint): equal-work blocks run in lock step, so 2048 blocks on 768 slots take 3
@@ -943,6 +951,9 @@ static void wgrad_go(const WgradP& p0, bool affine, hipStream_t st) {
     else conv_wgrad_kernel<TM, TN, WM, WN, WK, MODE, false, PREC><<<grid, 256, lds_pad, st>>>(p);
 }
 
+int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, const float* in_shift, float* dw,
+                      const uem_conv_shape* s, int flags, hipStream_t st);      // wgrad.hip
+
 extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift, float* dw,
                                 const uem_conv_shape* s, int flags, void* stream) {
     UEM_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
@@ -951,6 +962,9 @@ extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in
     const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
     UEM_REQUIRE(!affine || (in_scale && in_shift), "conv2d_wgrad: affine prologue needs scale/shift");
     UEM_REQUIRE(s->Cin % 32 == 0 && s->Cout % 4 == 0 && s->y_ld % 4 == 0, "conv2d_wgrad: Cin %% 32, Cout %% 4 required");
+    // 1x1 and row-aligned 3x3 layers with 64-multiple channel counts: the LDS-DMA kernel (wgrad.hip); everything else
+    // (ragged channel counts, 3x3 on rows that are not a multiple of 32 pixels, reduced operand precisions) stays here
+    if (uem_wgrad_dma_try(x, dy, in_scale, in_shift, dw, s, flags, (hipStream_t)stream)) return uem_check_launch("conv2d_wgrad (dma)");
     WgradP p;
     p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
     p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo;

@@ -1,0 +1,338 @@
+// Weight gradient of a convolution, LDS-DMA form (gfx950):   dW[o][tap][i] += sum_m dY[m][o] * A[m'(m,tap)][i]
+//
+// Measured on the register-staged kernel in conv.hip (profiles/r02_a_wgrad_ablation.txt): with the global loads and the
+// ds_write staging removed its MFMA loop runs at 142 TFLOP/s, with them at 107 -- the exact-f32 matrix pipe was
+// starved by operand staging (8 x global_load_dwordx4 + 8 x ds_write_b128 per thread and 32-pixel step), not by its own
+// issue stream.  Here both operand tiles travel global -> LDS by `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write, the
+// buffer descriptor's bounds check supplies the zeros of padding and of the ragged tail), double-buffered with ONE
+// barrier per step, and everything the staging used to do to the data moves to the operand fetch:
+//   * the producer's BatchNorm affine + ReLU (the conv consumed relu(bn(z)), only z is in memory): a lane's input channel
+//     is fixed for the whole kernel, so scale/shift sit in registers and cost 2 VALU per fetched operand;
+//   * zero padding AFTER that transform: a per-row validity word beside each staged tile.
+// 3x3 layers: one block owns the three taps of a filter row (ky) for 32 consecutive pixels of one output row.  The
+// three taps read the SAME staged input pixels shifted by kx*dilation, so a step stages dY (32 x TM) once and
+// 32*stride + 2*dilation input pixels once for 3x the MFMAs: a third of the operand traffic per flop.
+// k-major LDS tiles ([pixel][channel], as the rows sit in NHWC memory) are MFMA operands by plain ds_read (conv.hip).
+// Replaces cuDNN's backward-filter behind nn.Conv2d (reference uemda/_resnets.py:95-110, Encoder.py:35,74).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
+// buffer_load_dwordx4 ... lds: per-lane global offset, LDS destination = wave-uniform base (M0) + lane * 16
+extern "C" __device__ void uem_raw_buffer_load_lds(i32x4 rsrc, lds_u32p lds, int size, int voffset, int soffset, int offset,
+                                                   int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+
+#define WG_BK 32
+#define WG_OOB 0xFFFFFFF0u     // beyond every descriptor's num_records: the load returns zeros
+
+struct WgP {
+    const float* x;
+    const float* dy;
+    const float* in_scale;
+    const float* in_shift;
+    float* dw;
+    int M, N, H, W, Cin, Ho, Wo, Cout, KH, KW, pad, x_ld, dy_ld;
+    int steps_total, steps_per_split, tiles_co, tiles_ci;
+    unsigned x_bytes, dy_bytes;
+};
+
+__device__ __forceinline__ i32x4 wg_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));     // stride 0: raw byte offsets
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;                                                     // gfx9 raw buffer, dword elements
+    return r;
+}
+
+// TM x TN: output channels x input channels of the tile; NTAP: 1 (1x1 conv) or 3 (the kx taps of one filter row);
+// S: conv stride, D: dilation (NTAP == 3 only); AFFINE: BatchNorm affine + ReLU on the input operand;
+// LINEAR: 1x1 stride-1 conv, the 32-pixel steps are plain consecutive rows of x (any M); otherwise a step is 32
+// consecutive pixels of ONE output row (Wo % 32 == 0).
+template <int TM, int TN, int NTAP, int S, int D, bool AFFINE, bool LINEAR>
+struct WgCfg {
+    static constexpr int MT = TM / 64, NT = TN / 64;                       // 2x2 waves, 32x32 MFMA tiles per wave
+    static constexpr int XR = NTAP == 1 ? WG_BK : 31 * S + 2 * D + 1;      // staged input pixels per step
+    static constexpr int RPI_X = 256 / TN;                                 // rows per 1-KiB wave instruction
+    static constexpr int XROWS = (XR + 4 * RPI_X - 1) / (4 * RPI_X) * (4 * RPI_X);
+    static constexpr int D_IPW = WG_BK * TM / 1024;                        // DMA instructions per wave and step
+    static constexpr int X_IPW = XROWS / (4 * RPI_X);
+    static constexpr int D_FLOATS = WG_BK * TM, X_FLOATS = XROWS * TN, V_FLOATS = (XROWS + 4 + 3) / 4 * 4;
+    static constexpr int STAGE_FLOATS = D_FLOATS + X_FLOATS + V_FLOATS;
+    static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+    static constexpr int ACC = NTAP * MT * NT * 16;
+    static constexpr int BPC_LDS = 160 * 1024 / LDS_BYTES;                 // resident blocks per CU: LDS, then registers
+    static constexpr int BPC = BPC_LDS < 1 ? 1 : (BPC_LDS > (ACC <= 64 ? 3 : 2) ? (ACC <= 64 ? 3 : 2) : BPC_LDS);
+};
+
+template <int TM, int TN, int NTAP, int S, int D, bool AFFINE, bool LINEAR>
+__global__ __launch_bounds__(256, (WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>::BPC)) void wgrad_dma_kernel(const WgP p) {
+    using C = WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>;
+    constexpr int MT = C::MT, NT = C::NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- which (tile, filter row, pixel slice) ------------------------------------------------------------
+    const int rows_k = NTAP == 3 ? p.KH : 1;                               // filter rows = tap groups
+    const int ntiles = p.tiles_co * p.tiles_ci * rows_k;
+    const int nwg = gridDim.x;
+    int lin;                                                               // XCD-aware: blocks of one XCD walk consecutive ids
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int split = lin / ntiles;
+    int t_ = lin - split * ntiles;
+    const int ci_t = t_ % p.tiles_ci; t_ /= p.tiles_ci;
+    const int ky = t_ % rows_k;
+    const int co_t = t_ / rows_k;
+    const int co0 = co_t * TM, ci0 = ci_t * TN;
+    const int q_beg = split * p.steps_per_split;
+    const int q_end = min(p.steps_total, q_beg + p.steps_per_split);
+    const int T = q_end - q_beg;
+
+    const i32x4 rs_d = wg_rsrc(p.dy, p.dy_bytes), rs_x = wg_rsrc(p.x, p.x_bytes);
+
+    // ---- per-lane constants of the DMA pattern --------------------------------------------------------------
+    unsigned dconst[C::D_IPW], xconst[C::X_IPW];
+    int xrow[C::X_IPW];
+#pragma unroll
+    for (int j = 0; j < C::D_IPW; ++j) {
+        const int e = (j * 4 + wave) * 256 + lane * 4;
+        dconst[j] = (unsigned)(((e / TM) * p.dy_ld + co0 + (e % TM)) * 4);
+    }
+    constexpr int SX = NTAP == 3 ? 1 : S;                                  // input-pixel distance of consecutive staged rows
+#pragma unroll
+    for (int j = 0; j < C::X_IPW; ++j) {
+        const int e = (j * 4 + wave) * 256 + lane * 4;
+        xrow[j] = e / TN;
+        xconst[j] = (unsigned)((xrow[j] * SX * p.x_ld + ci0 + (e % TN)) * 4);
+    }
+    // position of the next step to issue (ROW mode): image, output row, 32-pixel chunk of that row
+    const int chunks = LINEAR ? 1 : p.Wo / WG_BK;
+    int qi = q_beg, in_ = 0, ioy = 0, ixc = 0;
+    if (!LINEAR) {
+        const int rowid = q_beg / chunks;
+        ixc = q_beg - rowid * chunks;
+        in_ = rowid / p.Ho;
+        ioy = rowid - in_ * p.Ho;
+    }
+    // ONE function takes the stage being refilled and the stage being read as two __restrict__ pointers: after inlining
+    // every DMA carries alias scope "fill" and every ds_read scope "use", which is what lets the compiler's wait-count
+    // pass see that the operand reads of step t do not depend on the DMA of step t+1 issued just before them (without
+    // the scopes it drains vmcnt(0) in front of the first ds_read: every wave then waits out its own prefetch).
+    f32x16 acc[NTAP][MT][NT];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
+    const int fr = lane & 31, fh = lane >> 5;
+    float sc[NT], sh[NT];
+    if (AFFINE) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { sc[j] = p.in_scale[ci0 + wn + j * 32 + fr]; sh[j] = p.in_shift[ci0 + wn + j * 32 + fr]; }
+    }
+
+    auto step = [&](float* __restrict__ fill, const float* __restrict__ use, const bool do_issue, const bool do_phase) {
+        if (do_issue) {
+            float* const Ds = fill;
+            float* const Xs = fill + C::D_FLOATS;
+            float* const Vs = Xs + C::X_FLOATS;
+            const unsigned dbase = (unsigned)qi * (unsigned)(WG_BK * 4) * (unsigned)p.dy_ld;   // dY rows are always linear in m
+#pragma unroll
+            for (int j = 0; j < C::D_IPW; ++j)
+                uem_raw_buffer_load_lds(rs_d, (lds_u32p)(Ds + (j * 4 + wave) * 256), 16, (int)(dconst[j] + dbase), 0, 0, 0);
+            if (LINEAR) {
+                const unsigned xbase = (unsigned)qi * (unsigned)(WG_BK * 4) * (unsigned)p.x_ld;
+#pragma unroll
+                for (int j = 0; j < C::X_IPW; ++j)
+                    uem_raw_buffer_load_lds(rs_x, (lds_u32p)(Xs + (j * 4 + wave) * 256), 16, (int)(xconst[j] + xbase), 0, 0, 0);
+            } else {
+                const int iy = ioy * S - p.pad + ky * D;
+                const int ix0 = ixc * (WG_BK * S) - p.pad;
+                const bool rowok = iy >= 0 && iy < p.H && in_ < p.N;
+                const unsigned xbase = (unsigned)(((in_ * p.H + iy) * p.W + ix0) * p.x_ld) * 4u;
+#pragma unroll
+                for (int j = 0; j < C::X_IPW; ++j) {
+                    const int ix = ix0 + xrow[j] * SX;
+                    const bool ok = rowok && ix >= 0 && ix < p.W && xrow[j] < C::XR;
+                    uem_raw_buffer_load_lds(rs_x, (lds_u32p)(Xs + (j * 4 + wave) * 256), 16, (int)(ok ? xconst[j] + xbase : WG_OOB), 0, 0, 0);
+                    if (AFFINE && NTAP == 3 && (lane % (TN / 4)) == 0) Vs[xrow[j]] = ok ? 1.f : 0.f;
+                }
+                if (NTAP == 3 && tid == 0) Vs[C::XROWS] = rowok ? 1.f : 0.f;
+                if (++ixc == chunks) { ixc = 0; if (++ioy == p.Ho) { ioy = 0; ++in_; } }
+            }
+            ++qi;
+        }
+        if (!do_phase) return;
+        const float* const Ds = use;
+        const float* const Xs = use + C::D_FLOATS;
+        const float* const Vs = Xs + C::X_FLOATS;
+        if (NTAP == 3) {
+            // a filter row that falls into the padding for this output row contributes nothing: skip its MFMAs
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(Vs[C::XROWS])) == 0) return;
+        }
+        // lane-half fh takes pixel k = 2*kp + fh.  With MT == 2 a lane fetches the channel pair (2*fr, 2*fr + 1) of its
+        // wave's 64-channel strip in one ds_read_b64: MFMA tile i then holds output channels wm + 2*row + i.
+        constexpr int RS = NTAP == 3 ? S : 1;                              // staged rows per output pixel
+        const float* const dsl = Ds + fh * TM + wm + (MT == 2 ? 2 * fr : fr);
+        const float* const xsl = Xs + fh * RS * TN + wn + fr;
+        const float* const vsl = Vs + fh * RS;
+#pragma unroll
+        for (int kp = 0; kp < WG_BK / 2; ++kp) {
+            float a[MT], b[NTAP][NT];
+            if (MT == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(dsl + 2 * kp * TM);
+                a[0] = v.x; a[MT - 1] = v.y;
+            } else {
+                a[0] = dsl[2 * kp * TM];
+            }
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int row = 2 * kp * RS + t * D;                      // compile-time: folded into the ds_read offset
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[t][j] = xsl[row * TN + j * 32];
+                if (AFFINE) {
+                    float v = 1.f;
+                    if (NTAP == 3) v = vsl[row];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        float u = b[t][j] * sc[j] + sh[j];               // (-ffp-contract=off: the forward prologue's two roundings)
+                        u = fmaxf(u, 0.f);
+                        b[t][j] = NTAP == 3 ? u * v : u;                  // zero padding comes after the transform
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
+        }
+    };
+    // own DMA of the step about to be read (and the validity words written beside it) complete, then everybody's; past the
+    // barrier every wave has also finished reading the other stage, so it is refilled right away
+#define WG_SYNC()                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                   \
+    asm volatile("" ::: "memory")
+    if (T > 0) {
+        float* const st0 = smem;
+        float* const st1 = smem + C::STAGE_FLOATS;
+        step(st0, st1, true, false);
+        for (int t = 0; t < T; t += 2) {
+            WG_SYNC();
+            step(st1, st0, t + 1 < T, true);
+            if (t + 1 >= T) break;
+            WG_SYNC();
+            step(st0, st1, t + 2 < T, true);
+        }
+    }
+#undef WG_SYNC
+
+    // ---- split-K: fp32 atomics into dW[o][tap][i] (accumulator column = lane => 128 contiguous bytes per half wave) ------
+    const size_t row_ld = (size_t)p.KH * p.KW * p.Cin;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int tap = NTAP == 3 ? ky * p.KW + t : 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float* base = p.dw + (size_t)tap * p.Cin + (ci0 + wn + j * 32 + fr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const int co = co0 + wm + (MT == 2 ? 2 * row + i : row);
+                    atomicAdd(base + (size_t)co * row_ld, acc[t][i][j][r]);
+                }
+            }
+    }
+}
+
+template <int TM, int TN, int NTAP, int S, int D, bool LINEAR>
+static void wg_go(WgP p, bool affine, hipStream_t st) {
+    using C = WgCfg<TM, TN, NTAP, S, D, false, LINEAR>;
+    p.tiles_co = p.Cout / TM;
+    p.tiles_ci = p.Cin / TN;
+    const int tiles = p.tiles_co * p.tiles_ci * (NTAP == 3 ? p.KH : 1);
+    p.steps_total = (int)uem_cdiv(p.M, WG_BK);
+    // split-K sizing: whole rounds of the chip's resident-block slots (conv.hip, wgrad_go); every split adds one fp32-atomic
+    // pass over its tile, so few-tile layers keep >= 32 steps per split
+    static const int forced = getenv("UEM_WGRAD_SPLITS") ? atoi(getenv("UEM_WGRAD_SPLITS")) : 0;
+    static const int forced_rounds = getenv("UEM_WGRAD_ROUNDS") ? atoi(getenv("UEM_WGRAD_ROUNDS")) : 0;
+    const int slots = 256 * C::BPC;
+    int rounds = forced_rounds > 0 ? forced_rounds : 2;
+    int splits = slots * rounds / tiles;
+    const int max_splits = (int)uem_cdiv(p.steps_total, NTAP == 3 ? 8 : 16);
+    if (forced > 0) splits = forced;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (int)uem_cdiv(p.steps_total, splits);
+    splits = (int)uem_cdiv(p.steps_total, p.steps_per_split);
+    const unsigned grid = (unsigned)tiles * (unsigned)splits;
+    if (affine) {
+        auto k = wgrad_dma_kernel<TM, TN, NTAP, S, D, true, LINEAR>;
+        static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
+        (void)attr;
+        k<<<grid, 256, C::LDS_BYTES, st>>>(p);
+    } else {
+        auto k = wgrad_dma_kernel<TM, TN, NTAP, S, D, false, LINEAR>;
+        static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
+        (void)attr;
+        k<<<grid, 256, C::LDS_BYTES, st>>>(p);
+    }
+}
+
+template <int TM, int TN>
+static bool wg_dispatch(const WgP& p, const uem_conv_shape* s, bool affine, hipStream_t st) {
+    if (s->KH == 1 && s->KW == 1 && s->pad == 0) {
+        if (s->stride == 1) { wg_go<TM, TN, 1, 1, 0, true>(p, affine, st); return true; }
+        if (s->stride == 2 && s->Wo % WG_BK == 0) { wg_go<TM, TN, 1, 2, 0, false>(p, affine, st); return true; }
+        return false;
+    }
+    if (s->KH == 3 && s->KW == 3 && s->Wo % WG_BK == 0) {
+        if (s->stride == 1 && s->dil == 1) { wg_go<TM, TN, 3, 1, 1, false>(p, affine, st); return true; }
+        if (s->stride == 1 && s->dil == 2) { wg_go<TM, TN, 3, 1, 2, false>(p, affine, st); return true; }
+        if (s->stride == 2 && s->dil == 1) { wg_go<TM, TN, 3, 2, 1, false>(p, affine, st); return true; }
+    }
+    return false;
+}
+
+// Returns 1 when the LDS-DMA kernel took the launch, 0 when the shape is left to the register-staged kernel (conv.hip).
+int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, const float* in_shift, float* dw,
+                      const uem_conv_shape* s, int flags, hipStream_t st) {
+    static const int off = getenv("UEM_WGRAD_DMA") ? !atoi(getenv("UEM_WGRAD_DMA")) : 0;
+    if (off) return 0;
+    const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
+    if (flags & (UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) return 0;
+    if (affine && !(flags & UEM_CONV_IN_RELU)) return 0;
+    if (s->Cout % 64 != 0 || s->Cin % 64 != 0 || s->x_ld % 4 != 0 || s->y_ld % 4 != 0) return 0;
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return 0;
+    const double xb = (double)s->N * s->H * s->W * s->x_ld * 4.0, db = (double)s->N * s->Ho * s->Wo * s->y_ld * 4.0;
+    if (xb >= 4294967280.0 || db >= 4294967280.0) return 0;               // 32-bit buffer offsets
+    WgP p;
+    p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
+    p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
+    p.KH = s->KH; p.KW = s->KW; p.pad = s->pad; p.x_ld = s->x_ld; p.dy_ld = s->y_ld;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    const bool m128 = s->Cout % 128 == 0, n128 = s->Cin % 128 == 0;
+    bool ok;
+    if (m128 && n128) ok = wg_dispatch<128, 128>(p, s, affine, st);
+    else if (m128) ok = wg_dispatch<128, 64>(p, s, affine, st);
+    else if (n128) ok = wg_dispatch<64, 128>(p, s, affine, st);
+    else ok = wg_dispatch<64, 64>(p, s, affine, st);
+    return ok ? 1 : 0;
+}
