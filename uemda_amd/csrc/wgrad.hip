@@ -24,7 +24,6 @@ typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
 extern "C" __device__ void uem_raw_buffer_load_lds(i32x4 rsrc, lds_u32p lds, int size, int voffset, int soffset, int offset,
                                                    int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 
-#define WG_BK 32
 #define WG_OOB 0xFFFFFFF0u     // beyond every descriptor's num_records: the load returns zeros
 
 struct WgP {
@@ -52,15 +51,15 @@ __device__ __forceinline__ i32x4 wg_rsrc(const void* p, unsigned bytes) {
 // S: conv stride, D: dilation (NTAP == 3 only); AFFINE: BatchNorm affine + ReLU on the input operand;
 // LINEAR: 1x1 stride-1 conv, the 32-pixel steps are plain consecutive rows of x (any M); otherwise a step is 32
 // consecutive pixels of ONE output row (Wo % 32 == 0).
-template <int TM, int TN, int NTAP, int S, int D, bool AFFINE, bool LINEAR>
+template <int BK, int TM, int TN, int NTAP, int S, int D, bool AFFINE, bool LINEAR>
 struct WgCfg {
     static constexpr int MT = TM / 64, NT = TN / 64;                       // 2x2 waves, 32x32 MFMA tiles per wave
-    static constexpr int XR = NTAP == 1 ? WG_BK : 31 * S + 2 * D + 1;      // staged input pixels per step
+    static constexpr int XR = NTAP == 1 ? BK : (BK - 1) * S + 2 * D + 1;      // staged input pixels per step
     static constexpr int RPI_X = 256 / TN;                                 // rows per 1-KiB wave instruction
     static constexpr int XROWS = (XR + 4 * RPI_X - 1) / (4 * RPI_X) * (4 * RPI_X);
-    static constexpr int D_IPW = WG_BK * TM / 1024;                        // DMA instructions per wave and step
+    static constexpr int D_IPW = BK * TM / 1024;                        // DMA instructions per wave and step
     static constexpr int X_IPW = XROWS / (4 * RPI_X);
-    static constexpr int D_FLOATS = WG_BK * TM, X_FLOATS = XROWS * TN, V_FLOATS = (XROWS + 4 + 3) / 4 * 4;
+    static constexpr int D_FLOATS = BK * TM, X_FLOATS = XROWS * TN, V_FLOATS = (XROWS + 4 + 3) / 4 * 4;
     static constexpr int STAGE_FLOATS = D_FLOATS + X_FLOATS + V_FLOATS;
     static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
     static constexpr int ACC = NTAP * MT * NT * 16;
@@ -68,9 +67,9 @@ struct WgCfg {
     static constexpr int BPC = BPC_LDS < 1 ? 1 : (BPC_LDS > (ACC <= 64 ? 3 : 2) ? (ACC <= 64 ? 3 : 2) : BPC_LDS);
 };
 
-template <int TM, int TN, int NTAP, int S, int D, bool AFFINE, bool LINEAR>
-__global__ __launch_bounds__(256, (WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>::BPC)) void wgrad_dma_kernel(const WgP p) {
-    using C = WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>;
+template <int BK, int TM, int TN, int NTAP, int S, int D, bool AFFINE, bool LINEAR>
+__global__ __launch_bounds__(256, (WgCfg<BK, TM, TN, NTAP, S, D, AFFINE, LINEAR>::BPC)) void wgrad_dma_kernel(const WgP p) {
+    using C = WgCfg<BK, TM, TN, NTAP, S, D, AFFINE, LINEAR>;
     constexpr int MT = C::MT, NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(256, (WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>::BP
         xconst[j] = (unsigned)((xrow[j] * SX * p.x_ld + ci0 + (e % TN)) * 4);
     }
     // position of the next step to issue (ROW mode): image, output row, 32-pixel chunk of that row
-    const int chunks = LINEAR ? 1 : p.Wo / WG_BK;
+    const int chunks = LINEAR ? 1 : p.Wo / BK;
     int qi = q_beg, in_ = 0, ioy = 0, ixc = 0;
     if (!LINEAR) {
         const int rowid = q_beg / chunks;
@@ -148,18 +147,18 @@ __global__ __launch_bounds__(256, (WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>::BP
             float* const Ds = fill;
             float* const Xs = fill + C::D_FLOATS;
             float* const Vs = Xs + C::X_FLOATS;
-            const unsigned dbase = (unsigned)qi * (unsigned)(WG_BK * 4) * (unsigned)p.dy_ld;   // dY rows are always linear in m
+            const unsigned dbase = (unsigned)qi * (unsigned)(BK * 4) * (unsigned)p.dy_ld;   // dY rows are always linear in m
 #pragma unroll
             for (int j = 0; j < C::D_IPW; ++j)
                 uem_raw_buffer_load_lds(rs_d, (lds_u32p)(Ds + (j * 4 + wave) * 256), 16, (int)(dconst[j] + dbase), 0, 0, 0);
             if (LINEAR) {
-                const unsigned xbase = (unsigned)qi * (unsigned)(WG_BK * 4) * (unsigned)p.x_ld;
+                const unsigned xbase = (unsigned)qi * (unsigned)(BK * 4) * (unsigned)p.x_ld;
 #pragma unroll
                 for (int j = 0; j < C::X_IPW; ++j)
                     uem_raw_buffer_load_lds(rs_x, (lds_u32p)(Xs + (j * 4 + wave) * 256), 16, (int)(xconst[j] + xbase), 0, 0, 0);
             } else {
                 const int iy = ioy * S - p.pad + ky * D;
-                const int ix0 = ixc * (WG_BK * S) - p.pad;
+                const int ix0 = ixc * (BK * S) - p.pad;
                 const bool rowok = iy >= 0 && iy < p.H && in_ < p.N;
                 const unsigned xbase = (unsigned)(((in_ * p.H + iy) * p.W + ix0) * p.x_ld) * 4u;
 #pragma unroll
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(256, (WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>::BP
         const float* const xsl = Xs + fh * RS * TN + wn + fr;
         const float* const vsl = Vs + fh * RS;
 #pragma unroll
-        for (int kp = 0; kp < WG_BK / 2; ++kp) {
+        for (int kp = 0; kp < BK / 2; ++kp) {
             float a[MT], b[NTAP][NT];
             if (MT == 2) {
                 const float2 v = *reinterpret_cast<const float2*>(dsl + 2 * kp * TM);
@@ -262,51 +261,65 @@ __global__ __launch_bounds__(256, (WgCfg<TM, TN, NTAP, S, D, AFFINE, LINEAR>::BP
     }
 }
 
-template <int TM, int TN, int NTAP, int S, int D, bool LINEAR>
+// tuning overrides (scripts/sweep_wgrad.py): tile TM x TN (0 = rule below), split-K rounds (0 = rule)
+static int g_tm = 0, g_tn = 0, g_rounds = 0, g_bk = 0;
+extern "C" void uemdbg_wgrad_config(int tm, int tn, int rounds, int bk) { g_tm = tm; g_tn = tn; g_rounds = rounds; g_bk = bk; }
+
+template <int BK, int TM, int TN, int NTAP, int S, int D, bool LINEAR>
 static void wg_go(WgP p, bool affine, hipStream_t st) {
-    using C = WgCfg<TM, TN, NTAP, S, D, false, LINEAR>;
+    using C = WgCfg<BK, TM, TN, NTAP, S, D, false, LINEAR>;
     p.tiles_co = p.Cout / TM;
     p.tiles_ci = p.Cin / TN;
     const int tiles = p.tiles_co * p.tiles_ci * (NTAP == 3 ? p.KH : 1);
-    p.steps_total = (int)uem_cdiv(p.M, WG_BK);
-    // split-K sizing: whole rounds of the chip's resident-block slots (conv.hip, wgrad_go); every split adds one fp32-atomic
-    // pass over its tile, so few-tile layers keep >= 32 steps per split
+    p.steps_total = (int)uem_cdiv(p.M, BK);
+    // split-K sizing.  Blocks of one launch run in lock step, so the grid is sized to whole ROUNDS of the chip's resident
+    // block slots; every block ends with one fp32-atomic pass over its tile (chip-wide 1.3 TB/s), so the fewest rounds that
+    // fill the slots to >= 97 % win (profiles/r02_b_wgrad_sweep.txt: 1 round beats 2 and 3 wherever it fills the chip).
     static const int forced = getenv("UEM_WGRAD_SPLITS") ? atoi(getenv("UEM_WGRAD_SPLITS")) : 0;
     static const int forced_rounds = getenv("UEM_WGRAD_ROUNDS") ? atoi(getenv("UEM_WGRAD_ROUNDS")) : 0;
     const int slots = 256 * C::BPC;
-    int rounds = forced_rounds > 0 ? forced_rounds : 2;
-    int splits = slots * rounds / tiles;
-    const int max_splits = (int)uem_cdiv(p.steps_total, NTAP == 3 ? 8 : 16);
+    const int max_splits = (int)uem_cdiv(p.steps_total, 8);                // >= 8 steps per block
+    int splits = 1;
+    {
+        const int fixed = g_rounds > 0 ? g_rounds : forced_rounds;
+        double best_fill = -1.0;
+        for (int r = fixed > 0 ? fixed : 1; r <= (fixed > 0 ? fixed : 3); ++r) {
+            int sp = slots * r / tiles;
+            if (sp > max_splits) sp = max_splits;
+            if (sp < 1) sp = 1;
+            const double fill = (double)tiles * sp / ((double)slots * uem_cdiv((int64_t)tiles * sp, slots));
+            if (fill > best_fill + 1e-9) { best_fill = fill; splits = sp; }
+            if (fill >= 0.97) break;
+        }
+    }
     if (forced > 0) splits = forced;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
     p.steps_per_split = (int)uem_cdiv(p.steps_total, splits);
     splits = (int)uem_cdiv(p.steps_total, p.steps_per_split);
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
     if (affine) {
-        auto k = wgrad_dma_kernel<TM, TN, NTAP, S, D, true, LINEAR>;
+        auto k = wgrad_dma_kernel<BK, TM, TN, NTAP, S, D, true, LINEAR>;
         static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
         (void)attr;
         k<<<grid, 256, C::LDS_BYTES, st>>>(p);
     } else {
-        auto k = wgrad_dma_kernel<TM, TN, NTAP, S, D, false, LINEAR>;
+        auto k = wgrad_dma_kernel<BK, TM, TN, NTAP, S, D, false, LINEAR>;
         static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
         (void)attr;
         k<<<grid, 256, C::LDS_BYTES, st>>>(p);
     }
 }
 
-template <int TM, int TN>
+template <int BK, int TM, int TN>
 static bool wg_dispatch(const WgP& p, const uem_conv_shape* s, bool affine, hipStream_t st) {
     if (s->KH == 1 && s->KW == 1 && s->pad == 0) {
-        if (s->stride == 1) { wg_go<TM, TN, 1, 1, 0, true>(p, affine, st); return true; }
-        if (s->stride == 2 && s->Wo % WG_BK == 0) { wg_go<TM, TN, 1, 2, 0, false>(p, affine, st); return true; }
+        if (s->stride == 1) { wg_go<BK, TM, TN, 1, 1, 0, true>(p, affine, st); return true; }
+        if (s->stride == 2 && s->Wo % BK == 0) { wg_go<BK, TM, TN, 1, 2, 0, false>(p, affine, st); return true; }
         return false;
     }
-    if (s->KH == 3 && s->KW == 3 && s->Wo % WG_BK == 0) {
-        if (s->stride == 1 && s->dil == 1) { wg_go<TM, TN, 3, 1, 1, false>(p, affine, st); return true; }
-        if (s->stride == 1 && s->dil == 2) { wg_go<TM, TN, 3, 1, 2, false>(p, affine, st); return true; }
-        if (s->stride == 2 && s->dil == 1) { wg_go<TM, TN, 3, 2, 1, false>(p, affine, st); return true; }
+    if (s->KH == 3 && s->KW == 3 && s->Wo % BK == 0) {
+        if (s->stride == 1 && s->dil == 1) { wg_go<BK, TM, TN, 3, 1, 1, false>(p, affine, st); return true; }
+        if (s->stride == 1 && s->dil == 2) { wg_go<BK, TM, TN, 3, 1, 2, false>(p, affine, st); return true; }
+        if (s->stride == 2 && s->dil == 1) { wg_go<BK, TM, TN, 3, 2, 1, false>(p, affine, st); return true; }
     }
     return false;
 }
@@ -328,11 +341,23 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
     p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
     p.KH = s->KH; p.KW = s->KW; p.pad = s->pad; p.x_ld = s->x_ld; p.dy_ld = s->y_ld;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
-    const bool m128 = s->Cout % 128 == 0, n128 = s->Cin % 128 == 0;
+    // tile rule (profiles/r02_b_wgrad_sweep.txt): 128 output channels x 64 input channels everywhere -- the narrower input
+    // tile halves the LDS footprint (3 resident blocks per CU instead of 2 on the 1x1 layers) and the per-block atomic pass
+    const bool m128 = s->Cout % 128 == 0 && g_tm != 64, n128 = s->Cin % 128 == 0 && g_tn == 128;
     bool ok;
-    if (m128 && n128) ok = wg_dispatch<128, 128>(p, s, affine, st);
-    else if (m128) ok = wg_dispatch<128, 64>(p, s, affine, st);
-    else if (n128) ok = wg_dispatch<64, 128>(p, s, affine, st);
-    else ok = wg_dispatch<64, 64>(p, s, affine, st);
+    // 32-pixel steps (profiles/r02_b_wgrad_sweep.txt: 16-pixel steps with twice the resident blocks are 2-4 % slower); rows
+    // that are a multiple of 16 but not of 32 pixels (256x256 tiles at output stride 16) take the 16-pixel instantiation
+    const bool pointwise_s1 = s->KH == 1 && s->KW == 1 && s->stride == 1;
+    if (g_bk == 16 || (g_bk == 0 && !pointwise_s1 && s->Wo % 32 != 0)) {
+        if (m128 && n128) ok = wg_dispatch<16, 128, 128>(p, s, affine, st);
+        else if (m128) ok = wg_dispatch<16, 128, 64>(p, s, affine, st);
+        else if (n128) ok = wg_dispatch<16, 64, 128>(p, s, affine, st);
+        else ok = wg_dispatch<16, 64, 64>(p, s, affine, st);
+        return ok ? 1 : 0;
+    }
+    if (m128 && n128) ok = wg_dispatch<32, 128, 128>(p, s, affine, st);
+    else if (m128) ok = wg_dispatch<32, 128, 64>(p, s, affine, st);
+    else if (n128) ok = wg_dispatch<32, 64, 128>(p, s, affine, st);
+    else ok = wg_dispatch<32, 64, 64>(p, s, affine, st);
     return ok ? 1 : 0;
 }
