@@ -123,7 +123,6 @@ def main():
     from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
 
     ops.set_conv_precision(args.conv_prec)
-    side_stream_on = bool(ops._side_stream_enabled())    # (off under multi-rank data parallel and in the event-timed last step)
     C, B, S = 6, args.batch, args.size
     seed_torch(2333)
     cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
@@ -262,9 +261,8 @@ def main():
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text}, "
                                    f"random init; tiles counted = source + target; the batch repeats {min(B, 4)} unique seeded "
                                    f"tiles x{rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
-                                   f"events with the wgrad side stream off",
-                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
-                       "wgrad_side_stream": side_stream_on},
+                                   f"events (660 event records: about 1 ms of command-processor bubbles)",
+                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}"},
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }
@@ -294,8 +292,8 @@ def main():
             f.write(f"{float(arena[:n].double().sum()):.10e} {float(arena[:n].double().abs().sum()):.10e}\n")
         torch.save(dict(params_sample=arena[:n:101].cpu(), params_sum=float(arena[:n].double().sum()),
                         prototypes=aligner.prototypes.cpu(), first_grad_sample=first_grad.get("sample"),
-                        first_grad_norm=first_grad.get("norm"), unpaired_forwards=getattr(wrapper, "unpaired_forwards", None),
-                        wgrad_side_stream=side_stream_on), f"{args.dump_params}.rank{rank}.pt")
+                        first_grad_norm=first_grad.get("norm"), unpaired_forwards=getattr(wrapper, "unpaired_forwards", None)),
+                   f"{args.dump_params}.rank{rank}.pt")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """Data parallel on the GPU box (one MI355X): the REAL `uemda_amd.dp.DataParallel` object that bench.py runs under
 torchrun -- parameter broadcast, forward/backward pairing, the layer3[0] bucket trigger, the asynchronous tail
-all-reduce, the side-stream join, the prototype partial-sum all-reduce -- driven by two fresh child processes that
+all-reduce, the prototype partial-sum all-reduce -- driven by two fresh child processes that
 share device 0 (backend gloo: RCCL refuses two ranks on one device).  Plus the single-rank RCCL plumbing smoke.
 Every run is `bench.py` in child processes, so the test process keeps no process group and never re-execs."""
 import json
@@ -91,12 +91,6 @@ def test_two_rank_data_parallel_object(tmp_path):
     rel = float((r0["first_grad_sample"] - mean).norm() / mean.norm())
     assert rel < 1e-4, rel                      # fp32 atomics / summation order only
     assert float((alone[0]["first_grad_sample"] - alone[1]["first_grad_sample"]).norm() / mean.norm()) > 1e-2   # the ranks' tiles differ
-    # with the weight gradients on the side stream (the single-process default) the join before each bucket must hold
-    line_s, (s0, s1) = _two_ranks(str(tmp_path / "side"), env={"UEM_WGRAD_STREAM": "1"})
-    assert line_s["config"]["wgrad_side_stream"] is True and line["config"]["wgrad_side_stream"] is False
-    assert torch.equal(s0["params_sample"], s1["params_sample"]) and torch.equal(s0["prototypes"], s1["prototypes"])
-    rel = float((s0["first_grad_sample"] - mean).norm() / mean.norm())
-    assert rel < 1e-4, rel
 
 
 def test_forward_backward_pairing_guard():

@@ -45,6 +45,7 @@ struct ConvP {
     // (sub*yy + py, sub*xx + px) and only the taps that can reach that class are walked.
     int sub, py, px, Hs, Ws;          // sub == 1: dense rows (every other use)
     int ntaps;                        // number of taps walked
+    int dbg;                          // diagnostic builds of the schedule (uemdbg_conv_dbg); 0 in production
     unsigned long long tapmask;       // 4 bits per walked tap: tap id = ky*KW + kx (3x3 at most)
 };
 
@@ -52,6 +53,152 @@ struct ConvP {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Accumulators -> global memory (shared by the register-staged and the LDS-DMA main loops): C/D layout
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `smem` must be free (every wave past its last operand read).
+template <int BN, int WM, int WN, int MODE>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
+                                              const int m0, const int n0) {
+    constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+    const bool dense_rows = !(MODE == 1 && p.sub > 1);
+    if (dense_rows && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+        // Full tile: the accumulators go through LDS (the operand stages are dead now) in two 64-row halves and
+        // leave as 16-byte stores, 32 lanes per 512-B row segment.  (64 dword stores per lane made the epilogue
+        // store-issue bound on the small-K layers.)  The staged half is also where the fused BatchNorm statistics
+        // (column sums of y and y*y over the tile) are taken: consecutive threads on consecutive banks.
+        constexpr int LDW = BN + 4;                     // staged row stride (floats), keeps 16-B alignment
+        constexpr int TPR = BN / 4;                     // threads per staged row
+        constexpr int RPP = 256 / TPR;                  // rows per store pass
+        float* const stg = smem;                        // 64 x LDW floats <= the A+B stages
+        const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv4 = *reinterpret_cast<const float4*>(p.bias + n0 + sc4);
+        float cs1 = 0.f, cs2 = 0.f;                     // column tid of the tile (threads < BN)
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;   // fused BN-backward partials (MODE 1)
+#pragma unroll
+        for (int hm = 0; hm < 2; ++hm) {
+            if (wm / 64 == hm) {
+                const int rbase = wm % 64;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
+            }
+            __syncthreads();
+            // global loads of the epilogue (the tensor being accumulated into, the z of the fused BatchNorm backward) are
+            // issued in batches of up to 4 rows before their consumers: written row by row they compiled to
+            // load - s_waitcnt vmcnt(0) - use, 8 to 16 serialised memory latencies per block
+            constexpr int NRP = 64 / RPP, RB = NRP < 4 ? NRP : 4;
+#pragma unroll
+            for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
+                float4 o[RB];
+                if (p.accumulate) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        o[u] = *reinterpret_cast<const float4*>(p.y + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int row = srow + (rp0 + u) * RPP;
+                    float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                    v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
+                    if (p.accumulate) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
+                    *reinterpret_cast<float4*>(p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4) = v;
+                }
+            }
+            if (MODE == 1 && p.tile_bnbwd != nullptr) {
+                // each thread owns 4 columns x (64/RPP) rows of this half: accumulate dbeta / dgamma partials
+                const float4 sc = *reinterpret_cast<const float4*>(p.bn_vec + n0 + sc4);
+                const float4 sh = *reinterpret_cast<const float4*>(p.bn_vec + p.Cout + n0 + sc4);
+                const float4 mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.Cout + n0 + sc4);
+                const float4 is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.Cout + n0 + sc4);
+#pragma unroll
+                for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
+                    float4 zz[RB];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const int row = srow + (rp0 + u) * RPP;
+                        const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                        const float4 z = zz[u];
+                        const float dx_ = (z.x * sc.x + sh.x > 0.f) ? d.x : 0.f, dy_ = (z.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
+                        const float dz_ = (z.z * sc.z + sh.z > 0.f) ? d.z : 0.f, dw_ = (z.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+                        bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
+                        bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
+                        bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
+                    }
+                }
+            }
+            if (p.tile_stats != nullptr && tid < BN) {
+#pragma unroll 8
+                for (int row = 0; row < 64; ++row) {
+                    const float v = stg[row * LDW + tid];
+                    cs1 += v;
+                    cs2 += v * v;
+                }
+            }
+            __syncthreads();
+        }
+        if (p.tile_stats != nullptr && tid < BN) {
+            // channel-major [2][Cout][tiles]: the per-channel finalize then streams contiguous rows
+            const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
+            float* ts = p.tile_stats + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
+            ts[0] = cs1;
+            ts[(size_t)p.Cout * tiles_m] = cs2;
+        }
+        if (MODE == 1 && p.tile_bnbwd != nullptr) {
+            // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again)
+            float* red = stg;                           // [2][RPP][BN]
+            *reinterpret_cast<float4*>(&red[(0 * RPP + srow) * BN + sc4]) = bb;
+            *reinterpret_cast<float4*>(&red[(1 * RPP + srow) * BN + sc4]) = bg;
+            __syncthreads();
+            if (tid < BN) {
+                float b = 0.f, g = 0.f;
+#pragma unroll
+                for (int q = 0; q < RPP; ++q) { b += red[(0 * RPP + q) * BN + tid]; g += red[(1 * RPP + q) * BN + tid]; }
+                const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
+                float* tb = p.tile_bnbwd + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
+                tb[0] = b;
+                tb[(size_t)p.Cout * tiles_m] = g;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn + j * 32 + fr;
+        if (n >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m < p.M) {
+                    size_t opix = (size_t)m;
+                    if (!dense_rows) {
+                        const int hw = p.Hs * p.Ws;
+                        const int ni = m / hw, rem = m - ni * hw;
+                        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
+                        opix = ((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px);
+                    }
+                    float* dst = p.y + opix * p.y_ld + n;
+                    float v = acc[i][j][r] + bv;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
 }
 
 // MODE: 0 = forward gather, 1 = transposed gather (data gradient), 2 = stem (NHWC4, 8 px x 4 ch per tap row)
@@ -323,142 +470,230 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------------------
-    const bool dense_rows = !(MODE == 1 && p.sub > 1);
-    if (dense_rows && m0 + BM <= p.M && n0 + BN <= p.Cout) {
-        // Full tile: the accumulators go through LDS (the operand stages are dead now) in two 64-row halves and
-        // leave as 16-byte stores, 32 lanes per 512-B row segment.  (64 dword stores per lane made the epilogue
-        // store-issue bound on the small-K layers.)  The staged half is also where the fused BatchNorm statistics
-        // (column sums of y and y*y over the tile) are taken: consecutive threads on consecutive banks.
-        constexpr int LDW = BN + 4;                     // staged row stride (floats), keeps 16-B alignment
-        constexpr int TPR = BN / 4;                     // threads per staged row
-        constexpr int RPP = 256 / TPR;                  // rows per store pass
-        float* const stg = smem;                        // 64 x LDW floats <= the A+B stages
-        const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
-        float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv4 = *reinterpret_cast<const float4*>(p.bias + n0 + sc4);
-        float cs1 = 0.f, cs2 = 0.f;                     // column tid of the tile (threads < BN)
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;   // fused BN-backward partials (MODE 1)
-#pragma unroll
-        for (int hm = 0; hm < 2; ++hm) {
-            if (wm / 64 == hm) {
-                const int rbase = wm % 64;
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
-            }
-            __syncthreads();
-            // global loads of the epilogue (the tensor being accumulated into, the z of the fused BatchNorm backward) are
-            // issued in batches of up to 4 rows before their consumers: written row by row they compiled to
-            // load - s_waitcnt vmcnt(0) - use, 8 to 16 serialised memory latencies per block
-            constexpr int NRP = 64 / RPP, RB = NRP < 4 ? NRP : 4;
-#pragma unroll
-            for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
-                float4 o[RB];
-                if (p.accumulate) {
-#pragma unroll
-                    for (int u = 0; u < RB; ++u)
-                        o[u] = *reinterpret_cast<const float4*>(p.y + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
-                }
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {
-                    const int row = srow + (rp0 + u) * RPP;
-                    float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
-                    v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-                    if (p.accumulate) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
-                    *reinterpret_cast<float4*>(p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4) = v;
-                }
-            }
-            if (MODE == 1 && p.tile_bnbwd != nullptr) {
-                // each thread owns 4 columns x (64/RPP) rows of this half: accumulate dbeta / dgamma partials
-                const float4 sc = *reinterpret_cast<const float4*>(p.bn_vec + n0 + sc4);
-                const float4 sh = *reinterpret_cast<const float4*>(p.bn_vec + p.Cout + n0 + sc4);
-                const float4 mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.Cout + n0 + sc4);
-                const float4 is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.Cout + n0 + sc4);
-#pragma unroll
-                for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
-                    float4 zz[RB];
-#pragma unroll
-                    for (int u = 0; u < RB; ++u)
-                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
-#pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const int row = srow + (rp0 + u) * RPP;
-                        const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
-                        const float4 z = zz[u];
-                        const float dx_ = (z.x * sc.x + sh.x > 0.f) ? d.x : 0.f, dy_ = (z.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
-                        const float dz_ = (z.z * sc.z + sh.z > 0.f) ? d.z : 0.f, dw_ = (z.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
-                        bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
-                        bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
-                        bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
-                    }
-                }
-            }
-            if (p.tile_stats != nullptr && tid < BN) {
-#pragma unroll 8
-                for (int row = 0; row < 64; ++row) {
-                    const float v = stg[row * LDW + tid];
-                    cs1 += v;
-                    cs2 += v * v;
-                }
-            }
-            __syncthreads();
-        }
-        if (p.tile_stats != nullptr && tid < BN) {
-            // channel-major [2][Cout][tiles]: the per-channel finalize then streams contiguous rows
-            const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
-            float* ts = p.tile_stats + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
-            ts[0] = cs1;
-            ts[(size_t)p.Cout * tiles_m] = cs2;
-        }
-        if (MODE == 1 && p.tile_bnbwd != nullptr) {
-            // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again)
-            float* red = stg;                           // [2][RPP][BN]
-            *reinterpret_cast<float4*>(&red[(0 * RPP + srow) * BN + sc4]) = bb;
-            *reinterpret_cast<float4*>(&red[(1 * RPP + srow) * BN + sc4]) = bg;
-            __syncthreads();
-            if (tid < BN) {
-                float b = 0.f, g = 0.f;
-#pragma unroll
-                for (int q = 0; q < RPP; ++q) { b += red[(0 * RPP + q) * BN + tid]; g += red[(1 * RPP + q) * BN + tid]; }
-                const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
-                float* tb = p.tile_bnbwd + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
-                tb[0] = b;
-                tb[(size_t)p.Cout * tiles_m] = g;
-            }
-        }
-        return;
+    conv_epilogue<BN, WM, WN, MODE>(p, acc, smem, m0, n0);
+}
+
+// =========================================================================================================
+// LDS-DMA main loop (exact fp32 only).  Same tiles, same epilogue; the operand tiles travel global -> LDS by
+// `buffer_load_dwordx4 ... lds` instead of through VGPRs + ds_write (what that staging cost the matrix pipe:
+// profiles/r02_a_wgrad_ablation.txt), two stages, ONE barrier per k-step.  What the staging did to the data moves to
+// the operand fetch: BatchNorm affine + ReLU on the A fragment (scale/shift of the fragment's 4 channels come from LDS,
+// two broadcast ds_read_b128 per 8-channel step), zero padding through a per-row validity word; rows outside the image
+// are fetched with an out-of-range buffer offset (zeros).  LDS rows are 128 B (32 floats, no padding -- the DMA writes
+// 1 KiB linearly), so the 16-B chunks of a row are XOR-swizzled by (row>>1)&7 on the SOURCE address and on the read:
+// every 16-lane group of a ds_read_b128 then covers 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+// =========================================================================================================
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
+extern "C" __device__ void uem_raw_buffer_load_lds(i32x4 rsrc, lds_u32p lds, int size, int voffset, int soffset, int offset,
+                                                   int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
+#define CONV_OOB 0xFFFFFFF0u
+__device__ __forceinline__ i32x4 conv_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+template <int BN>
+struct ConvDmaCfg {
+    static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, V_FLOATS = BM;
+    static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS + V_FLOATS;
+    static constexpr int EPI_FLOATS = 64 * (BN + 4);                      // the epilogue's staging area
+    static constexpr int BASE_FLOATS = 2 * STAGE_FLOATS > EPI_FLOATS ? 2 * STAGE_FLOATS : EPI_FLOATS;
+    static constexpr int BPC = BN == 128 ? 2 : 3;                         // resident blocks per CU (LDS: 65 / 49 KB)
+};
+
+// MODE 0 forward / 1 data gradient; AFFINE: BatchNorm affine + ReLU on the input operand; PADDED: the filter has taps
+// that can fall outside the image (only then does the affine path need the validity words)
+template <int BN, int MODE, bool AFFINE, bool PADDED>
+__global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
+    using C = ConvDmaCfg<BN>;
+    // 4 x 1 waves: each wave owns 32 of the tile's 128 rows and ALL its columns, so every A element is fetched -- and pushed
+    // through the prologue -- by exactly one wave (2 x 2 waves transformed each element twice: the prologue's VALU work cost
+    // the forward 12 %, profiles/r02_d_conv_ablation.txt)
+    constexpr int WM = 4, WN = 1, MT = BM / WM / 32, NT = BN / WN / 32, BROWS = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Ssc = smem + C::BASE_FLOATS;                            // AFFINE only: [Cin] scale, then [Cin] shift
+    if (AFFINE) {
+        for (int i = threadIdx.x; i < p.Cin; i += 256) { Ssc[i] = p.in_scale[i]; Ssc[p.Cin + i] = p.in_shift[i]; }
     }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = p.Cout / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + 32*j
+    const int lc4 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 4;                 // swizzled source chunk (floats) of this lane
+    const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
+
+    int gy[4], gx[4], gpix[4];                                           // gather geometry of this lane's 4 A rows
+    {
+        const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
+        const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn + j * 32 + fr;
-        if (n >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m < p.M) {
-                    size_t opix = (size_t)m;
-                    if (!dense_rows) {
-                        const int hw = p.Hs * p.Ws;
-                        const int ni = m / hw, rem = m - ni * hw;
-                        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
-                        opix = ((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px);
-                    }
-                    float* dst = p.y + opix * p.y_ld + n;
-                    float v = acc[i][j][r] + bv;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
-                }
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + lrow + 32 * j;
+            if (m < p.M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / Wrow, ox = rem - oy * Wrow;
+                if (MODE == 1) { gy[j] = oy * p.sub + p.py + p.pad; gx[j] = ox * p.sub + p.px + p.pad; }
+                else { gy[j] = oy * p.stride - p.pad; gx[j] = ox * p.stride - p.pad; }
+                gpix[j] = n * p.H * p.W;
+            } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
         }
     }
+    const int cpb = p.Cin / BK, KT = p.ntaps * cpb, Ktot = p.KH * p.KW * p.Cin;
+    // issue-side walk over (tap, channel block); byte offsets from p.x / p.w
+    int lt = 0, lci0 = 0;
+    unsigned tapok = 0, aoff[4], boff[BROWS];
+    auto setup_tap = [&](int t) {
+        const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
+        const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);
+        const int kx = tap - ky * p.KW;
+        tapok = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = gpix[j] >= 0;
+            int iy, ix;
+            if (MODE == 1) {
+                const int ty = gy[j] - ky * p.dil, tx = gx[j] - kx * p.dil;
+                if (p.stride == 1) { iy = ty; ix = tx; }
+                else { iy = ty / p.stride; ix = tx / p.stride; ok = ok && (iy * p.stride == ty) && (ix * p.stride == tx); }
+                ok = ok && ty >= 0 && tx >= 0 && iy < p.H && ix < p.W;
+            } else {
+                iy = gy[j] + ky * p.dil; ix = gx[j] + kx * p.dil;
+                ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            }
+            aoff[j] = ((unsigned)(gpix[j] + iy * p.W + ix) * (unsigned)p.x_ld + (unsigned)lc4) * 4u;
+            tapok |= (ok ? 1u : 0u) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < BROWS; ++j)
+            boff[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc4)) * 4u;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;                                        // (row>>1)&7 of every fragment row of this lane
+    int rci0 = 0;                                                        // read-side channel base of the k-tile being consumed
+
+    // one function, two __restrict__ stages (+ the prologue operands): alias scopes tell the wait-count pass that the
+    // operand reads of tile k do not depend on the DMA of tile k+1 issued just before them (see wgrad.hip)
+    auto step = [&](float* __restrict__ fill, const float* __restrict__ use, const float* __restrict__ ssc, const bool do_issue,
+                    const bool do_phase) {
+        if (do_issue) {
+            float* const As = fill;
+            float* const Bs = fill + C::A_FLOATS;
+            float* const Vs = Bs + C::B_FLOATS;
+            if (lci0 == 0) setup_tap(lt);                                // block-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (tapok >> j) & 1u;
+                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(As + (j * 4 + wave) * 256), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
+                aoff[j] += BK * 4;
+                if (AFFINE && PADDED && (tid & 7) == 0) Vs[lrow + 32 * j] = ok ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < BROWS; ++j) {
+                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(Bs + (j * 4 + wave) * 256), 16, (int)boff[j], 0, 0, 0);
+                boff[j] += BK * 4;
+            }
+            lci0 += BK;
+            if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
+        }
+        if (!do_phase) return;
+        const float* const As = use;
+        const float* const Bs = use + C::A_FLOATS;
+        const float* const Vs = Bs + C::B_FLOATS;
+        float vld[MT];
+        if (AFFINE && PADDED) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) vld[i] = Vs[wm + i * 32 + fr];
+        }
+        // Software pipeline over the four 8-channel steps of the tile: the fragments of step ks+1 are fetched, and pushed
+        // through the prologue, underneath the MFMAs of step ks (fetch + transform in front of their own MFMAs left the matrix
+        // pipe idle for the read latency and the VALU chain of every step: -8 % on the affine forward).
+        float4 fa[2][MT], fb[2][NT], fs[2], fh4[2];
+        auto fetch = [&](const int ks, const int buf) {
+            const int q = ks * 2 + fh;                                   // 16-B chunk (4 channels) of this lane half
+            const int qs = (q ^ sw) * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * BK + qs]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * BK + qs]);
+            if (AFFINE) {
+                fs[buf] = *reinterpret_cast<const float4*>(&ssc[rci0 + q * 4]);
+                fh4[buf] = *reinterpret_cast<const float4*>(&ssc[p.Cin + rci0 + q * 4]);
+            }
+        };
+        auto xform = [&](const int buf) {
+            if (!AFFINE) return;
+            const float4 s4 = fs[buf], h4 = fh4[buf];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float4 v = fa[buf][i];
+                v.x = fmaxf(__builtin_fmaf(v.x, s4.x, h4.x), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, s4.y, h4.y), 0.f);
+                v.z = fmaxf(__builtin_fmaf(v.z, s4.z, h4.z), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, s4.w, h4.w), 0.f);
+                if (PADDED) { v.x *= vld[i]; v.y *= vld[i]; v.z *= vld[i]; v.w *= vld[i]; }   // zero padding after the transform
+                fa[buf][i] = v;
+            }
+        };
+#define MFMA_STEP(Cc, Bf)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[Bf][i].Cc, fb[Bf][j].Cc, acc[i][j], 0, 0, 0);
+        fetch(0, 0);
+        xform(0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            const int cb = ks & 1, nb = cb ^ 1;
+            const bool more = ks + 1 < BK / 8;
+            if (more) fetch(ks + 1, nb);
+            MFMA_STEP(x, cb) MFMA_STEP(y, cb)
+            if (more) xform(nb);
+            MFMA_STEP(z, cb) MFMA_STEP(w, cb)
+            if (more) {
+                // machine order: the reads of the next step, half of this step's MFMAs, the next step's transform, the rest
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT + (AFFINE ? 2 : 0), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+                if (AFFINE) __builtin_amdgcn_sched_group_barrier(0x002, MT * (PADDED ? 12 : 8), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+            }
+        }
+#undef MFMA_STEP
+        rci0 += BK;
+        if (rci0 >= p.Cin) rci0 = 0;
+    };
+#define CONV_SYNC()                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                   \
+    asm volatile("" ::: "memory")
+    if (KT > 0) {
+        float* const st0 = smem;
+        float* const st1 = smem + C::STAGE_FLOATS;
+        step(st0, st1, Ssc, true, false);
+        for (int kt = 0; kt < KT; kt += 2) {
+            CONV_SYNC();
+            step(st1, st0, Ssc, kt + 1 < KT && !p.dbg, true);
+            if (kt + 1 >= KT) break;
+            CONV_SYNC();
+            step(st0, st1, Ssc, kt + 2 < KT && !p.dbg, true);
+        }
+    }
+    __syncthreads();                                                     // every wave is past its last operand read
+#undef CONV_SYNC
+    conv_epilogue<BN, WM, WN, MODE>(p, acc, smem, m0, n0);
 }
 
 static int conv_check(const uem_conv_shape* s) {
@@ -500,8 +735,52 @@ static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
     }
 }
 
+// tuning overrides (scripts/sweep_conv.py): LDS-DMA main loop on/off (-1 = rule), its N tile (0 = rule)
+static int g_conv_dma = -1, g_conv_dma_bn = 0;
+extern "C" void uemdbg_conv_config(int dma, int bn) { g_conv_dma = dma; g_conv_dma_bn = bn; }
+static int g_conv_dbg = 0;      // diagnostic: 1 = the LDS-DMA loop issues no DMA after its first tile (results wrong)
+extern "C" void uemdbg_conv_dbg(int v) { g_conv_dbg = v; }
+
+template <int BN_, int MODE>
+static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, hipStream_t st) {
+    using C = ConvDmaCfg<BN_>;
+    const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
+    const size_t lds = ((size_t)C::BASE_FLOATS + (affine ? 2 * (size_t)p.Cin : 0)) * sizeof(float);
+    const bool padded = p.KH * p.KW > 1;
+    ConvP q = p;
+    q.dbg = g_conv_dbg;
+    auto go = [&](auto k) {
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k<<<grid, 256, lds, st>>>(q, xb, wb);
+    };
+    if (MODE == 0 && affine && padded) go(conv_dma_kernel<BN_, MODE, MODE == 0, MODE == 0>);
+    else if (MODE == 0 && affine) go(conv_dma_kernel<BN_, MODE, MODE == 0, false>);
+    else go(conv_dma_kernel<BN_, MODE, false, false>);
+}
+
+// The LDS-DMA main loop takes exact-fp32 forward / data-gradient launches with 32-multiple input and 64-multiple output
+// channel counts whose tensors fit 32-bit buffer offsets; 1 = launched.
+template <int MODE>
+static int conv_dma_try(const ConvP& p, bool affine, hipStream_t st) {
+    if constexpr (MODE == 2) return 0;
+    static const int env = getenv("UEM_CONV_DMA") ? atoi(getenv("UEM_CONV_DMA")) : 1;
+    if (!(g_conv_dma >= 0 ? g_conv_dma : env)) return 0;
+    if (p.Cin % BK != 0 || p.Cout % 64 != 0 || p.x_ld % 4 != 0 || p.ntaps <= 0) return 0;
+    if (affine && (!p.relu || p.Cin > 1024)) return 0;
+    if (((uintptr_t)p.x | (uintptr_t)p.w) & 15) return 0;
+    const double xb = (double)p.N * p.H * p.W * p.x_ld * 4.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 4.0;
+    if (xb >= 4294967280.0 || wb >= 4294967280.0) return 0;
+    const bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64;
+    if constexpr (MODE != 2) {
+        if (bn128) conv_dma_go<128, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
+        else conv_dma_go<64, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
+    }
+    return 1;
+}
+
 template <int MODE>
 static int conv_launch(const ConvP& p, bool affine, hipStream_t st, int prec = 0) {
+    if (prec == 0 && conv_dma_try<MODE>(p, affine, st)) return uem_check_launch("conv2d (dma)");
     static const int nbuf = getenv("UEM_CONV_NBUF") ? atoi(getenv("UEM_CONV_NBUF")) : 1;
     static const int smallk_bn64 = getenv("UEM_CONV_SMALLK_BN64") ? atoi(getenv("UEM_CONV_SMALLK_BN64")) : 0;
     const int tiles_m = (int)uem_cdiv(p.M, BM);
@@ -569,7 +848,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0;
     p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0;
     p.tile_stats = tile_stats;
     p.bn_z = bnbwd ? bnbwd->z : nullptr; p.bn_vec = bnbwd ? bnbwd->vec : nullptr; p.tile_bnbwd = bnbwd ? bnbwd->tiles : nullptr;
     if (!transposed) {
@@ -621,7 +900,7 @@ extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, i
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
     p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0; p.dbg = 0;
     p.M = N * p.Ho * p.Wo;
     return conv_launch<2>(p, false, (hipStream_t)stream);
 }

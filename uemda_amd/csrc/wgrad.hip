@@ -206,8 +206,7 @@ __global__ __launch_bounds__(256, (WgCfg<BK, TM, TN, NTAP, S, D, AFFINE, LINEAR>
                     if (NTAP == 3) v = vsl[row];
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        float u = b[t][j] * sc[j] + sh[j];               // (-ffp-contract=off: the forward prologue's two roundings)
-                        u = fmaxf(u, 0.f);
+                        float u = fmaxf(__builtin_fmaf(b[t][j], sc[j], sh[j]), 0.f);    // one fused rounding, as the forward's fetch
                         b[t][j] = NTAP == 3 ? u * v : u;                  // zero padding comes after the transform
                     }
                 }

@@ -113,13 +113,11 @@ class DataParallel:
                                f"reduce_gradients() but only {self._fwd_calls} train-mode forwards were counted")
         if self._active and self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
             _, garena, n = self.model.flat_parameters()
-            ops.join_side_stream()          # weight gradients run on a side stream: the tail must be complete first
             self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def reduce_gradients(self):
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
-        ops.join_side_stream()
         if self._split is not None and self._fwd_calls != self._bwd_calls:
             # a train-mode forward whose graph never ran backward (a validation pass left in .train(), a dropped
             # output): the early bucket was (rightly) not sent, nothing is wrong with THIS step's gradients, but

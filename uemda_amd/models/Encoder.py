@@ -146,7 +146,6 @@ class Deeplabv2(nn.Module):
         """Zero the flat gradient arena (one memset) and keep every .grad attached to it."""
         if self._grad_arena is None:
             return super().zero_grad(set_to_none)
-        ops.join_side_stream()
         self._grad_arena.zero_()
         for p in self.parameters():
             if p.grad is None:

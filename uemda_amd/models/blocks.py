@@ -79,7 +79,6 @@ class StemFn(Function):
     def backward(ctx, dy):
         x4, z, stbuf, idx = ctx.saved_tensors
         resnet = ctx.resnet
-        ops.flush_side()
         st = _st_from(stbuf, ctx.training)
         da = ops.maxpool_bwd(dy.contiguous(), idx, z.shape)
         dz = ops.bn_backward(z, da, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias), None, True, dx=da)
@@ -130,33 +129,29 @@ class BottleneckFn(Function):
         s, d = blk.stride, blk.dilation
         W, G, gb = ops.weight_ohwi, grad_ohwi, grad_buffer
         dy = dy.contiguous()
-        ops.flush_side()        # the later block's weight gradients start now, beside this block's BatchNorm passes
         # BN3 + residual + ReLU: mask from the materialised output y; dp = grad of the pre-ReLU sum
         dp = torch.empty_like(dy)
         kw = dict(ymask_bits=ybits) if ybits.dtype == torch.int32 else dict(ymask=ybits)
         dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=True, dres=dp, **kw)
         g3 = G(blk.conv3.weight)
-        ops.defer_on_side(lambda a=z2, b=dz3, g=g3, sc=st2.scale, sh=st2.shift:
-                          ops.conv2d_wgrad(a, b, g, in_scale=sc, in_shift=sh, in_relu=True), z2, dz3, g3, st2.scale)
+        ops.conv2d_wgrad(z2, dz3, g3, in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
         dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose(W(blk.conv3.weight)), z2, st2, gb(blk.bn2.weight),
                                            gb(blk.bn2.bias))
         del dz3
         g2 = G(blk.conv2.weight)
-        ops.defer_on_side(lambda a=z1, b=dz2, g=g2, sc=st1.scale, sh=st1.shift:
-                          ops.conv2d_wgrad(a, b, g, stride=s, pad=d, dil=d, in_scale=sc, in_shift=sh, in_relu=True),
-                          z1, dz2, g2, st1.scale)
+        ops.conv2d_wgrad(z1, dz2, g2, stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
         dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose(W(blk.conv2.weight)), z1, st1, gb(blk.bn1.weight),
                                            gb(blk.bn1.bias), stride=s, pad=d, dil=d)
         del dz2
         g1 = G(blk.conv1.weight)
-        ops.defer_on_side(lambda a=x, b=dz1, g=g1: ops.conv2d_wgrad(a, b, g), x, dz1, g1)
+        ops.conv2d_wgrad(x, dz1, g1)
         wt1 = ops.weight_transpose(W(blk.conv1.weight))
         if ctx.has_ds:
             zd, std = sv[8], _st_from(sv[9], ctx.training)
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
             dzd = ops.bn_backward(zd, dp, std, gb(ds_bn.weight), gb(ds_bn.bias), None, False, dx=dp)
             gd = G(ds_conv.weight)
-            ops.defer_on_side(lambda a=x, b=dzd, g=gd: ops.conv2d_wgrad(a, b, g, stride=s), x, dzd, gd)
+            ops.conv2d_wgrad(x, dzd, gd, stride=s)
             dx = ops.conv2d_dgrad(dz1, wt1, x.shape)
             ops.conv2d_dgrad(dzd, ops.weight_transpose(W(ds_conv.weight)), x.shape, stride=s, out=dx, accumulate=True)
         else:

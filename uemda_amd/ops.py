@@ -39,105 +39,6 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# Weight-gradient kernels (MFMA-bound, nothing downstream in the backward pass reads their output) can run on a side
-# stream beside the HBM-bound BatchNorm backward passes of the main stream (scripts/overlap_probe.py: 43 % of the
-# BatchNorm time disappears under a concurrently running wgrad).  blocks.BottleneckFn issues them through defer_on_side / flush_side.
-# Default: on in a single-process run, off under data parallel with more than one rank: in the 2-rank rehearsal
-# (two processes sharing ONE GPU, gloo backend) the extra active stream made the step time unstable (286-458 ms
-# against 125-131 ms without it) -- most likely the inter-process time slicing of one device, which a real
-# one-process-per-GPU run does not have (the single-rank RCCL smoke is faster with it) -- but an 8-GPU RCCL run
-# cannot be rehearsed here, so the conservative default stands.  UEM_WGRAD_STREAM=1 / 0 forces it either way.
-# (A first version used Tensor.record_stream for the tensors the side stream reads; that made the caching allocator
-# reserve 4x the memory and the step time drift -- the explicit lifetime rule in flush_side() replaced it.)
-_WGRAD_STREAM_ENV = os.environ.get("UEM_WGRAD_STREAM")
-WGRAD_STREAM = _WGRAD_STREAM_ENV != "0"
-_side_streams = {}
-
-
-def _side_stream_enabled():
-    if not WGRAD_STREAM or PROF.enabled:        # per-launch event timing wants every kernel alone on the device
-        return False
-    if _WGRAD_STREAM_ENV is not None:
-        return True
-    import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-
-
-def side_stream():
-    dev = torch.cuda.current_device()
-    if dev not in _side_streams:
-        _side_streams[dev] = torch.cuda.Stream(device=dev)
-    return _side_streams[dev]
-
-
-def join_side_stream():
-    """Make the current stream wait for everything queued on (or still deferred for) the side stream."""
-    flush_side()
-    if not _side_streams:
-        return
-    dev = torch.cuda.current_device()
-    if dev in _side_streams:
-        torch.cuda.current_stream().wait_stream(_side_streams[dev])
-        _inflight.clear()
-
-
-_join_scheduled = False
-_deferred = []          # (launch closure, tensors it touches) waiting to go out on the side stream
-
-
-def defer_on_side(fn, *tensors):
-    """Queue `fn` (kernel launches whose results nothing in the backward pass reads: weight gradients) for the side
-    stream.  The queue is flushed by flush_side() -- blocks.BottleneckFn does that right before it starts the
-    HBM-bound BatchNorm backward of the NEXT block in backward order, so those passes always have MFMA-bound work
-    running beside them -- and, at the latest, when the backward pass ends.  `tensors`: everything fn reads or
-    writes that the caching allocator may otherwise recycle too early."""
-    global _join_scheduled
-    if not _side_stream_enabled():
-        return fn()
-    _deferred.append((fn, tensors))
-    if not _join_scheduled:
-        _join_scheduled = True
-        main = torch.cuda.current_stream()
-
-        def _end_of_backward():
-            global _join_scheduled
-            _join_scheduled = False
-            with torch.cuda.stream(main):
-                flush_side()
-                main.wait_stream(side_stream())
-                _inflight.clear()
-        try:
-            from torch.autograd import Variable
-            Variable._execution_engine.queue_callback(_end_of_backward)
-        except RuntimeError:                    # not inside a backward pass: run in place
-            _end_of_backward()
-
-
-_inflight = []          # (event recorded on the side stream after a flushed group, the tensors that group touches)
-
-
-def flush_side():
-    """Launch everything queued by defer_on_side on the side stream, ordered after the current stream's work.
-    Tensor lifetime: the group's tensors stay referenced until the current stream has waited for the group's
-    completion event (at the next flush or join), so the caching allocator cannot hand their memory to a
-    main-stream kernel that would run beside the side-stream reader.  (Tensor.record_stream would do the same
-    job, but made the allocator reserve 4x the memory and the step time unstable.)"""
-    if not _deferred:
-        return
-    main, side = torch.cuda.current_stream(), side_stream()
-    while _inflight:
-        ev, _keep = _inflight.pop(0)
-        main.wait_event(ev)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        for fn, _ in _deferred:
-            fn()
-        ev = torch.cuda.Event()
-        ev.record(side)
-    _inflight.append((ev, [t for _, tensors in _deferred for t in tensors if t is not None]))
-    _deferred.clear()
-
-
 def nbt_inc(bn):
     """num_batches_tracked += 1 of a training-mode BatchNorm, unless its counter lives in a model-level arena that
     the model's forward bumps once for all layers (Deeplabv2._nbt_step)."""

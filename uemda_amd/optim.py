@@ -18,7 +18,6 @@ def _arena_of(parameters):
 def grad_norm(model):
     """L2 norm of the flat gradient arena -> 1-element device tensor (two-stage deterministic reduce)."""
     arena, garena, n = model.flat_parameters()
-    ops.join_side_stream()                  # weight gradients may still be in flight on the side stream
     partial = torch.empty(_lib.UEM_NORM_BLOCKS, device=arena.device, dtype=torch.float32)
     norm = torch.empty(1, device=arena.device, dtype=torch.float32)
     call("uem_grad_sqnorm", ptr(garena), n, ptr(partial), ptr(norm), stream())
@@ -57,7 +56,6 @@ class FusedSGD(torch.optim.Optimizer):
     def step(self, closure=None, max_norm=None, grad_prescale=1.0):
         g = self.param_groups[0]
         arena, garena, n = self.model.flat_parameters()
-        ops.join_side_stream()
         norm = None
         if max_norm is not None:
             norm = grad_norm(self.model)
