@@ -180,13 +180,31 @@ def main():
         one_step(i)
     ops.PROF.enabled = False
     ops.PROF.records = []
+    # Host hygiene: the interpreter's cyclic collector runs a full (generation-2) pass every so many allocations; over the
+    # model's ~10^5 long-lived objects that pass takes ~60 ms and, landing in the first step after the barrier (empty device
+    # queue), stalled the device for as long (steps_ms[0] = 180-220 ms against 134).  Collect now and move the survivors
+    # out of the collector's reach; the steady-state loop is unaffected either way (the host runs half a step ahead).
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_host = []
     t0 = time.perf_counter()
+    step_events[0].record()
     for i in range(args.steps):
         # per-launch HIP events (the `roofline` leg) are recorded during the LAST timed step only: 660 event
         # records per step put ~10 ms of command-processor bubbles into a 160 ms step when left on throughout
         ops.PROF.enabled = (not args.no_kernel_events) and i == args.steps - 1
-        out = one_step(args.warmup + i, marked=(i == args.steps - 1))
+        if i == 0 and os.environ.get("UEM_BENCH_PROFILE_FIRST"):
+            import cProfile, pstats
+            pr = cProfile.Profile(); pr.enable()
+            out = one_step(args.warmup + i, marked=False)
+            pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+        else:
+            out = one_step(args.warmup + i, marked=(i == args.steps - 1))
+        step_events[i + 1].record()
+        step_host.append(time.perf_counter() - t0)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
@@ -266,6 +284,9 @@ def main():
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }
+        # device time of every timed step (one HIP event per step boundary) and when the host had finished enqueuing it
+        line["steps_ms"] = [round(a.elapsed_time(b), 2) for a, b in zip(step_events[:-1], step_events[1:])]
+        line["host_enqueued_at_ms"] = [round(1e3 * t, 1) for t in step_host]
         if marks:
             # per-phase wall time of the last timed step (HIP events on the compute stream) and, for the HBM-bound
             # phases, algorithmic bytes (SURVEY 8d per-tile figures x tiles) over that time

@@ -71,6 +71,18 @@ int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, 
  * a UEM_CONV_PREC_* bit only.                                                                            */
 int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* bn_z,
                            const float* bn_vec, float* tile_partials, int flags, void* stream);
+/* The data gradient that closes a bottleneck block's backward (dx of its first 1x1 conv, or of its downsample conv) with
+ * the residual bookkeeping in its epilogue (reference autograd through uemda/_resnets.py:92-112):
+ *   dx  = dgrad(dy)  +  acc_src * [acc_bits]     identity gradient of THIS block gated by its output ReLU mask (packed bits
+ *                                                of uem_affine_act), never materialised; acc_src may alias dx.  With
+ *                                                acc_src == NULL and UEM_CONV_ACCUMULATE in flags: dx += dgrad(dy).
+ *   tile_partials[2][Cin][M/128] = per-tile sums of dp = dx * [bn_bits] and dp * xhat(bn_z)   -- the reduction pass of the
+ *                                                PREVIOUS block's bn3 backward (its z3, (4,Cin) vectors and output mask),
+ *                                                taken while dx is still on chip; bn_* may be NULL.
+ * Needs stride 1, M % 128 == 0, Cin % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise).                                         */
+int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* acc_src,
+                          const uint32_t* acc_bits, const float* bn_z, const float* bn_vec, const uint32_t* bn_bits,
+                          float* tile_partials, int flags, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
 /* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */

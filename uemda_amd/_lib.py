@@ -34,6 +34,7 @@ SIGNATURES = {
     "uem_conv2d_fwd": [P, P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_fwd_stats": [P, P, P, P, P, POINTER(ConvShape), I, P, P],
     "uem_conv2d_dgrad_bnbwd": [P, P, P, POINTER(ConvShape), P, P, P, c_int, P],
+    "uem_conv2d_dgrad_tail": [P, P, P, POINTER(ConvShape), P, P, P, P, P, P, c_int, P],
     "uem_conv2d_stem_fwd": [P, P, P, I, I, I, P],
     "uem_conv2d_wgrad": [P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_stem_wgrad": [P, P, P, I, I, I, P],

@@ -41,6 +41,12 @@ struct ConvP {
     const float* bn_z;
     const float* bn_vec;   // (4, Cout): scale, shift, mean, invstd
     float* tile_bnbwd;
+    // residual tail of a bottleneck block's backward (uem_conv2d_dgrad_tail): the tensor accumulated into is acc_src gated
+    // by the packed ReLU bits acc_bits (the identity gradient dy*[y>0], never materialised), and the fused BatchNorm reduction
+    // takes its ReLU mask from the packed bits bn_bits (the PREVIOUS block's output mask) instead of recomputing it from z
+    const float* acc_src;
+    const uint32_t* acc_bits;
+    const uint32_t* bn_bits;
     // strided data-gradient only: one launch per output-parity class (py, px); rows enumerate the pixels
     // (sub*yy + py, sub*xx + px) and only the taps that can reach that class are walked.
     int sub, py, px, Hs, Ws;          // sub == 1: dense rows (every other use)
@@ -99,17 +105,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
 #pragma unroll
             for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
                 float4 o[RB];
+                uint32_t ob[RB];
                 if (p.accumulate) {
+                    const float* const asrc = p.acc_src ? p.acc_src : p.y;
 #pragma unroll
-                    for (int u = 0; u < RB; ++u)
-                        o[u] = *reinterpret_cast<const float4*>(p.y + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
+                    for (int u = 0; u < RB; ++u) {
+                        const size_t off = (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4;
+                        o[u] = *reinterpret_cast<const float4*>(asrc + off);
+                        if (p.acc_bits) ob[u] = p.acc_bits[off >> 5] >> (off & 31);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     const int row = srow + (rp0 + u) * RPP;
                     float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
                     v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-                    if (p.accumulate) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
+                    if (p.accumulate) {
+                        if (p.acc_bits) {
+                            const uint32_t m = ob[u];
+                            o[u].x = (m & 1u) ? o[u].x : 0.f; o[u].y = (m & 2u) ? o[u].y : 0.f;
+                            o[u].z = (m & 4u) ? o[u].z : 0.f; o[u].w = (m & 8u) ? o[u].w : 0.f;
+                        }
+                        v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w;
+                        // the fused BatchNorm reduction below works on the FINAL gradient
+                        if (MODE == 1 && p.tile_bnbwd != nullptr) *reinterpret_cast<float4*>(&stg[row * LDW + sc4]) = v;
+                    }
                     *reinterpret_cast<float4*>(p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4) = v;
                 }
             }
@@ -122,16 +142,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
 #pragma unroll
                 for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
                     float4 zz[RB];
+                    uint32_t zb[RB];
 #pragma unroll
-                    for (int u = 0; u < RB; ++u)
-                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4);
+                    for (int u = 0; u < RB; ++u) {
+                        const size_t off = (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4;
+                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + off);
+                        if (p.bn_bits) zb[u] = p.bn_bits[off >> 5] >> (off & 31);
+                    }
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
                         const int row = srow + (rp0 + u) * RPP;
                         const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
                         const float4 z = zz[u];
-                        const float dx_ = (z.x * sc.x + sh.x > 0.f) ? d.x : 0.f, dy_ = (z.y * sc.y + sh.y > 0.f) ? d.y : 0.f;
-                        const float dz_ = (z.z * sc.z + sh.z > 0.f) ? d.z : 0.f, dw_ = (z.w * sc.w + sh.w > 0.f) ? d.w : 0.f;
+                        bool kx, ky, kz, kw;
+                        if (p.bn_bits) { const uint32_t m = zb[u]; kx = m & 1u; ky = m & 2u; kz = m & 4u; kw = m & 8u; }
+                        else { kx = z.x * sc.x + sh.x > 0.f; ky = z.y * sc.y + sh.y > 0.f; kz = z.z * sc.z + sh.z > 0.f; kw = z.w * sc.w + sh.w > 0.f; }
+                        const float dx_ = kx ? d.x : 0.f, dy_ = ky ? d.y : 0.f, dz_ = kz ? d.z : 0.f, dw_ = kw ? d.w : 0.f;
                         bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
                         bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
                         bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
@@ -806,7 +832,7 @@ static int conv_launch(const ConvP& p, bool affine, hipStream_t st, int prec = 0
     return uem_check_launch("conv2d");
 }
 
-struct BnBwdFuse { const float* z; const float* vec; float* tiles; };
+struct BnBwdFuse { const float* z; const float* vec; float* tiles; const float* acc_src; const uint32_t* acc_bits; const uint32_t* bn_bits; };
 static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, const float* in_scale,
                            const float* in_shift, float* y, const uem_conv_shape* s, int flags, float* tile_stats,
                            const BnBwdFuse* bnbwd, void* stream);
@@ -820,9 +846,23 @@ extern "C" int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* 
     UEM_REQUIRE(bn_z && bn_vec && tile_partials && s, "conv2d_dgrad_bnbwd: null pointer");
     if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin)
         return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_bnbwd: needs stride 1, M %% 128 == 0, Cin %% 64 == 0");
-    BnBwdFuse f{bn_z, bn_vec, tile_partials};
+    BnBwdFuse f{bn_z, bn_vec, tile_partials, nullptr, nullptr, nullptr};
     UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_dgrad_bnbwd: only precision flags are accepted");
     return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED | flags, nullptr, &f, stream);
+}
+extern "C" int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* acc_src,
+                                     const uint32_t* acc_bits, const float* bn_z, const float* bn_vec, const uint32_t* bn_bits,
+                                     float* tile_partials, int flags, void* stream) {
+    UEM_REQUIRE(s && dx, "conv2d_dgrad_tail: null pointer");
+    UEM_REQUIRE((acc_bits == nullptr) == (acc_src == nullptr), "conv2d_dgrad_tail: acc_src and acc_bits go together");
+    UEM_REQUIRE((bn_z == nullptr) == (tile_partials == nullptr) && (bn_z == nullptr) == (bn_vec == nullptr) && (bn_z || !bn_bits),
+                "conv2d_dgrad_tail: bn_z, bn_vec and tile_partials go together");
+    if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin || s->Cin % 32 != 0)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_tail: needs stride 1, M %% 128 == 0, Cin %% 64 == 0, dense rows");
+    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16 | UEM_CONV_ACCUMULATE)) == 0, "conv2d_dgrad_tail: bad flags");
+    BnBwdFuse f{bn_z, bn_vec, tile_partials, acc_src, acc_bits, bn_bits};
+    return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED | flags | (acc_src ? UEM_CONV_ACCUMULATE : 0),
+                           nullptr, &f, stream);
 }
 extern "C" int uem_conv2d_fwd_stats(const float* x, const float* w, const float* in_scale, const float* in_shift,
                                     float* y, const uem_conv_shape* s, int flags, float* tile_stats, void* stream) {
@@ -851,6 +891,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0;
     p.tile_stats = tile_stats;
     p.bn_z = bnbwd ? bnbwd->z : nullptr; p.bn_vec = bnbwd ? bnbwd->vec : nullptr; p.tile_bnbwd = bnbwd ? bnbwd->tiles : nullptr;
+    p.acc_src = bnbwd ? bnbwd->acc_src : nullptr; p.acc_bits = bnbwd ? bnbwd->acc_bits : nullptr; p.bn_bits = bnbwd ? bnbwd->bn_bits : nullptr;
     if (!transposed) {
         UEM_REQUIRE(s->Cin % BK == 0, "conv2d_fwd: Cin=%d must be a multiple of 32", s->Cin);
         p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
@@ -899,7 +940,7 @@ extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, i
     p.N = N; p.H = H; p.W = W; p.Cin = 32;               // one tap row = 8 px x 4 ch
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
-    p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr;
+    p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0; p.dbg = 0;
     p.M = N * p.Ho * p.Wo;
     return conv_launch<2>(p, false, (hipStream_t)stream);

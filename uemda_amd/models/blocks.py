@@ -86,6 +86,15 @@ class StemFn(Function):
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class _Link:
+    """What the NEXT block's backward needs to take this block's bn3 reduction pass into its last data-gradient epilogue
+    (ops.conv2d_dgrad_tail): travels as an attribute of the block's output tensor; the next block's forward picks it up."""
+    __slots__ = ("z3", "bits", "vec", "tiles", "dx_ptr")
+
+    def __init__(self, z3, bits, vec):
+        self.z3, self.bits, self.vec, self.tiles, self.dx_ptr = z3, bits, vec, None, 0
+
+
 class BottleneckFn(Function):
     """1x1 -> BN -> ReLU -> 3x3(stride, dilation) -> BN -> ReLU -> 1x1 -> BN (+ downsample) -> add -> ReLU
     (_resnets.py:92-112).  `blk` carries conv1..3, bn1..3, downsample, stride, dilation."""
@@ -118,6 +127,12 @@ class BottleneckFn(Function):
             if has_ds:
                 saved += [zd, _st_tensor(std)]
             ctx.save_for_backward(*saved)
+            # bn3's reduction pass can ride in the next block's last data-gradient epilogue, and the previous block's in ours
+            ctx.link_in = getattr(x, "_uem_link", None)
+            ctx.link_out = None
+            if ybits is not None and st3.training:
+                ctx.link_out = _Link(z3, ybits, _st_tensor(st3))
+                y._uem_link = ctx.link_out
         return y
 
     @staticmethod
@@ -129,33 +144,57 @@ class BottleneckFn(Function):
         s, d = blk.stride, blk.dilation
         W, G, gb = ops.weight_ohwi, grad_ohwi, grad_buffer
         dy = dy.contiguous()
-        # BN3 + residual + ReLU: mask from the materialised output y; dp = grad of the pre-ReLU sum
-        dp = torch.empty_like(dy)
-        kw = dict(ymask_bits=ybits) if ybits.dtype == torch.int32 else dict(ymask=ybits)
-        dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=True, dres=dp, **kw)
-        g3 = G(blk.conv3.weight)
-        ops.conv2d_wgrad(z2, dz3, g3, in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
-        dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose(W(blk.conv3.weight)), z2, st2, gb(blk.bn2.weight),
+        packed = ybits.dtype == torch.int32
+        # BN3 + residual + ReLU.  dp = dy*[y > 0] (the gradient of the pre-ReLU sum) is never materialised: bn3's backward,
+        # the downsample BatchNorm's backward and the identity path all read dy through the packed mask.
+        tail_ok = packed and ops.dgrad_tail_ok(x.shape, x.shape[-1])
+        dp = torch.empty_like(dy) if not ctx.has_ds and not tail_ok else None      # shapes the tail epilogue does not take
+        lo = ctx.link_out
+        # dy may be overwritten in place only when it is the buffer the next block's backward allocated for us (a gradient
+        # handed in by the caller, or one autograd summed from several consumers, is left alone)
+        own = lo is not None and lo.dx_ptr == dy.data_ptr()
+        if own and lo.tiles is not None:
+            dz3 = ops.bn_backward_from_partials(z3, dy, st3, lo.tiles, gb(blk.bn3.weight), gb(blk.bn3.bias), ybits, dres=dp)
+            lo.tiles = None
+        else:
+            kw = dict(ymask_bits=ybits) if packed else dict(ymask=ybits)
+            dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=True, dres=dp, **kw)
+        ops.conv2d_wgrad(z2, dz3, G(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
+        dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose_cached(blk.conv3.weight), z2, st2, gb(blk.bn2.weight),
                                            gb(blk.bn2.bias))
         del dz3
-        g2 = G(blk.conv2.weight)
-        ops.conv2d_wgrad(z1, dz2, g2, stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
-        dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose(W(blk.conv2.weight)), z1, st1, gb(blk.bn1.weight),
+        ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
+        dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose_cached(blk.conv2.weight), z1, st1, gb(blk.bn1.weight),
                                            gb(blk.bn1.bias), stride=s, pad=d, dil=d)
         del dz2
-        g1 = G(blk.conv1.weight)
-        ops.conv2d_wgrad(x, dz1, g1)
-        wt1 = ops.weight_transpose(W(blk.conv1.weight))
+        ops.conv2d_wgrad(x, dz1, G(blk.conv1.weight))
+        wt1 = ops.weight_transpose_cached(blk.conv1.weight)
+        # the previous block's bn3 reduction rides in OUR last data-gradient launch when that launch has full dense tiles
+        li = ctx.link_in
+        fuse = li is not None and li.z3.shape == x.shape and ops.dgrad_tail_ok(x.shape, x.shape[-1])
+        bn_args = dict(bn_z=li.z3, bn_vec=li.vec, bn_bits=li.bits) if fuse else {}
+        tp = None
         if ctx.has_ds:
             zd, std = sv[8], _st_from(sv[9], ctx.training)
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
-            dzd = ops.bn_backward(zd, dp, std, gb(ds_bn.weight), gb(ds_bn.bias), None, False, dx=dp)
-            gd = G(ds_conv.weight)
-            ops.conv2d_wgrad(x, dzd, gd, stride=s)
-            dx = ops.conv2d_dgrad(dz1, wt1, x.shape)
-            ops.conv2d_dgrad(dzd, ops.weight_transpose(W(ds_conv.weight)), x.shape, stride=s, out=dx, accumulate=True)
+            kw = dict(ymask_bits=ybits) if packed else dict(ymask=ybits)
+            dzd = ops.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=True, dx=dy if own else None, **kw)
+            ops.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s)
+            wtd = ops.weight_transpose_cached(ds_conv.weight)
+            if s == 1 and tail_ok:
+                dx = ops.conv2d_dgrad(dzd, wtd, x.shape)
+                dx, tp = ops.conv2d_dgrad_tail(dz1, wt1, x.shape, out=dx, accumulate=True, **bn_args)
+            else:
+                # strided downsample: its data gradient reaches one pixel in four, so it goes second (accumulating)
+                dx = ops.conv2d_dgrad(dz1, wt1, x.shape)
+                ops.conv2d_dgrad(dzd, wtd, x.shape, stride=s, out=dx, accumulate=True)
+        elif tail_ok:
+            dx, tp = ops.conv2d_dgrad_tail(dz1, wt1, x.shape, acc_src=dy, acc_bits=ybits, out=dy if own else None,
+                                           **bn_args)                                      # identity gradient + conv1's
         else:
             dx = ops.conv2d_dgrad(dz1, wt1, x.shape, out=dp, accumulate=True)     # identity grad + conv1 dgrad
+        if li is not None:
+            li.tiles, li.dx_ptr = tp, dx.data_ptr()
         cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
         if cb is not None:
             cb()

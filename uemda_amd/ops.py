@@ -251,6 +251,50 @@ def conv2d_dgrad_bn_backward(dy, w_t, z, st, gamma_grad, beta_grad, stride=1, pa
     return da
 
 
+def conv2d_dgrad_tail(dy, w_t, x_shape, acc_src=None, acc_bits=None, out=None, accumulate=False, bn_z=None, bn_vec=None,
+                      bn_bits=None):
+    """The data gradient that closes a bottleneck block's backward, residual bookkeeping in its epilogue:
+    dx = dgrad(dy) + acc_src*[acc_bits] (identity gradient gated by the block's output ReLU bits; acc_src may be `out`), or
+    out += dgrad(dy) with accumulate=True; with bn_z / bn_vec (4,C) / bn_bits also returns the per-tile partial sums of the
+    PREVIOUS block's bn3 backward over the final dx (tiles, 2, C) -- see uem_conv2d_dgrad_tail.  Returns (dx, partials)."""
+    need_gpu(dy, w_t)
+    _f32c(dy, "dgrad dy"), _f32c(w_t, "dgrad w_t")
+    cin, kh, kw, cout = w_t.shape
+    n, h, w, _ = x_shape
+    s = ConvShape()
+    s.N, s.H, s.W, s.Cin = n, h, w, cin
+    s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], cout
+    s.KH, s.KW, s.stride, s.pad, s.dil = kh, kw, 1, (kh - 1) // 2, 1
+    s.x_ld, s.y_ld = cin, cout
+    if out is None:
+        out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
+    M = n * h * w
+    tp = torch.empty((M // 128, 2, cin), device=dy.device, dtype=torch.float32) if bn_z is not None else None
+    flags = CONV_PREC_BWD | (CONV_ACCUMULATE if accumulate else 0)
+    flops = 2.0 * n * dy.shape[1] * dy.shape[2] * cout * kh * kw * cin
+    PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_dgrad_tail", ptr(dy), ptr(w_t), ptr(out), ctypes.byref(s), ptr(acc_src),
+                                               ptr(acc_bits), ptr(bn_z), ptr(bn_vec), ptr(bn_bits), ptr(tp), flags, stream()))
+    return out, tp
+
+
+def dgrad_tail_ok(x_shape, cin):
+    n, h, w, _ = x_shape
+    return (n * h * w) % 128 == 0 and cin % 64 == 0 and FUSE_BN_BACKWARD and CONV_PREC_BWD == 0
+
+
+def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, ymask_bits, dx=None, dres=None):
+    """BatchNorm(+ReLU via packed bits) backward whose reduction pass already ran in a dgrad epilogue (tp = its per-tile
+    partial sums): finalize + apply only."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x) if dx is None else dx
+    tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
+    call("uem_bn_bwd_from_tiles", ptr(tp), tp.shape[0], C, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
+    call("uem_bn_bwd_apply", ptr(x), ptr(dy), ptr(ymask_bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         ptr(tmp[0]), ptr(tmp[1]), M, C, 2, ptr(dx), ptr(dres), stream())
+    return dx
+
+
 def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
                  algo_cout=None):
     """dw (Cout,KH,KW,Cin) += dy^T * im2col(prologue(x)).  dw must be contiguous (atomics land in it)."""
@@ -271,6 +315,26 @@ def weight_transpose(w_ohwi):
     wt = torch.empty((cin, kh, kw, cout), device=w_ohwi.device, dtype=torch.float32)
     call("uem_weight_transpose", ptr(w_ohwi), ptr(wt), cout, kh, kw, cin, stream())
     return wt
+
+
+# (Cin,KH,KW,Cout) copies for the data gradients, kept until the weights change: a step's two backward passes (source and
+# target graph) share them.  Weights change through FusedSGD (bumps WEIGHT_EPOCH: its kernel writes the arena behind
+# torch's back) or through torch in-place ops such as load_state_dict's copy_ (bump the tensor's _version).
+WEIGHT_EPOCH = 0
+
+
+def weights_changed():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def weight_transpose_cached(param):
+    key = (WEIGHT_EPOCH, param._version, param.data_ptr())
+    hit = getattr(param, "_uem_wt", None)
+    if hit is None or hit[0] != key:
+        hit = (key, weight_transpose(weight_ohwi(param)))
+        param._uem_wt = hit
+    return hit[1]
 
 
 def nchw3_to_nhwc4(x):

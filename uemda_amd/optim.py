@@ -64,3 +64,4 @@ class FusedSGD(torch.optim.Optimizer):
              float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(g["momentum"]),
              float(g["weight_decay"]), 1 if self._steps == 0 else 0, float(grad_prescale), stream())
         self._steps += 1
+        ops.weights_changed()
