@@ -280,7 +280,9 @@ def main():
                                    f"random init; tiles counted = source + target; the batch repeats {min(B, 4)} unique seeded "
                                    f"tiles x{rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
                                    f"events (660 event records: about 1 ms of command-processor bubbles)",
-                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}"},
+                       "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
+                       "collective": None if wrapper is None else ("uem_allreduce_flat (RCCL through the C ABI)" if wrapper.native
+                                                                   is not None else f"torch.distributed {args.backend}")},
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }

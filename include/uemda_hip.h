@@ -292,6 +292,20 @@ int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n,
                       float max_norm, float lr, float momentum, float weight_decay, int first_step,
                       float grad_prescale, void* stream);
 
+/* ---- data parallel (new relative to the reference, which is single-GPU: SURVEY 2a, 8e) --------------------------
+ * all-reduce(sum, in place) of a flat fp32 buffer -- the gradient arena, 98 MB for R50-ASPP -- over RCCL on `stream`:
+ * one process per GPU, xGMI inside the node.  Rank 0 draws an id with uem_comm_unique_id, the host ships those 128
+ * bytes to every rank (any side channel: uemda_amd.dp uses the torch.distributed store), every rank calls
+ * uem_comm_init.  This is the library's only state (the communicator handles the caller holds); there is nothing else
+ * to shut down, which is why the header has no uem_shutdown().  RCCL is taken from the host process (PyTorch-ROCm
+ * carries its own librccl.so) and loaded from /opt/rocm only when the process has none.
+ * uemda_amd.dp keeps torch.distributed (backend "nccl" = the same RCCL) as its default transport and switches to these
+ * entry points with UEM_DP_NATIVE=1: with one GPU per box the multi-rank leg of this path cannot be rehearsed here.   */
+int uem_comm_unique_id(void* id_out_128_bytes /* host */);
+int uem_comm_init(void** comm_out, const void* id_128_bytes /* host */, int rank, int world);
+int uem_allreduce_flat(void* comm, float* buf /* device, in place */, int64_t count, void* stream);
+int uem_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

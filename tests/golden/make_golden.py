@@ -344,17 +344,23 @@ def main():
     run_layer("layer_stem", stem, torch.randn(2, 3, 32, 32, generator=g))
 
     # ---------------- G-model / G-step ---------------------------------------------------------
-    for use_ppm in (False, True):
-        tag = "ppm" if use_ppm else "aspp"
-        print("G-model", tag)
+    def ssl_step_reference(use_ppm, mkldnn=True, ulp_noise=False):
+        """One train_ssl_uem.py iteration of the REFERENCE on the seeded batch; returns everything the fixture stores.
+        ulp_noise: the two image batches are perturbed by one unit in the last place (x * (1 +- 2^-23), seeded)."""
+        torch.backends.mkldnn.enabled = mkldnn
         sd = det_state_dict("resnet50", C, use_ppm, seed=2333)
         model = ref.Encoder.Deeplabv2(model_cfg(use_ppm, C))
-        missing = model.load_state_dict(sd, strict=True)
+        model.load_state_dict(sd, strict=True)
         assert list(model.state_dict().keys()) == list(sd.keys()), "state_dict key order mismatch"
         if use_ppm:
             model.layer5.conv_last[3].p = 0.0
             model.layer6.conv_last[3].p = 0.0
         batch = synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333)
+        if ulp_noise:
+            gn = torch.Generator().manual_seed(77)
+            for k in ("images_s", "images_t"):
+                sgn = torch.randint(0, 2, batch[k].shape, generator=gn).float() * 2 - 1
+                batch[k] = batch[k] * (1.0 + sgn * 2.0 ** -23)
         # eval forward
         model.eval()
         with torch.no_grad():
@@ -388,21 +394,49 @@ def main():
             gr = named[n].grad
             grads["grad:" + n] = gr if gr.numel() <= 8192 else gr.reshape(-1)[:: max(1, gr.numel() // 4096)][:4096]
         gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=32, norm_type=2)
+        # the UPDATE of every parameter tensor, 256 strided samples each: -lr * (clipped grad + wd * w), what SGD's first
+        # step applies (momentum buffer = gradient), evaluated in float64 from the reference's own fp32 gradients -- the
+        # difference w_post - w_pre itself is quantised to the weights' last place (8 % of a BatchNorm gamma's update)
+        upd = {n: (-lr * (p.grad.detach().double() + 5e-4 * p.detach().double())).reshape(-1)[:: max(1, p.numel() // 256)][:256]
+               .clone() for n, p in named.items()}
         opt.step()
+        torch.backends.mkldnn.enabled = True
+        return dict(model=model, prob=prob, ps1=ps1, ps2=ps2, pt1=pt1, pt2=pt2, feat_s=feat_s, feat_t=feat_t, soft=soft, hard=hard,
+                    loss_s=loss_s, loss_t=loss_t, al=al, gnorm=gnorm, lr=lr, grads=grads, upd=upd)
+
+    for use_ppm in (False, True):
+        tag = "ppm" if use_ppm else "aspp"
+        print("G-model", tag)
+        r = ssl_step_reference(use_ppm)
+        model, feat_t = r["model"], r["feat_t"]
         cs = checksum(model.parameters())
         post = model.state_dict()
         idx = torch.from_numpy(np.random.default_rng(3).integers(0, feat_t.numel(), 4096))
-        save(f"model_{tag}_r50_b2_256", eval_prob_sample=prob[:, :, ::8, ::8],
-             pred_s1=ps1, pred_s2=ps2, pred_t1=pt1, pred_t2=pt2, feat_idx=idx,
-             feat_t_sample=feat_t.reshape(-1)[idx], feat_s_sample=feat_s.reshape(-1)[idx],
+        # fp32 noise floor of every update: the same reference step with the other CPU conv backend (different summation
+        # order flips ~1e-5 of the ReLU masks per layer); stored per tensor so that the test holds each tensor
+        # to ITS floor instead of one global tolerance
+        # (a) the other CPU conv backend (different summation order in the conv backward passes), (b) the input images
+        # perturbed by one unit in the last place: the least any independent fp32 implementation differs from this one.
+        # Both are amplified by the ~50 training-mode BatchNorm backward passes (B = 2) between a tensor and the loss.
+        r2 = ssl_step_reference(use_ppm, mkldnn=False)
+        r3 = ssl_step_reference(use_ppm, ulp_noise=True)
+        names = list(r["upd"].keys())
+        noise = np.array([max(float((r["upd"][n] - q["upd"][n]).norm() / (r["upd"][n].norm() + 1e-30)) for q in (r2, r3))
+                          for n in names])
+        upd_flat = torch.cat([r["upd"][n] for n in names])
+        upd_off = np.cumsum([0] + [r["upd"][n].numel() for n in names])
+        save(f"model_{tag}_r50_b2_256", eval_prob_sample=r["prob"][:, :, ::8, ::8],
+             pred_s1=r["ps1"], pred_s2=r["ps2"], pred_t1=r["pt1"], pred_t2=r["pt2"], feat_idx=idx,
+             feat_t_sample=feat_t.reshape(-1)[idx], feat_s_sample=r["feat_s"].reshape(-1)[idx],
              feat_t_chmean=feat_t.mean(dim=(0, 2, 3)), feat_t_chvar=feat_t.var(dim=(0, 2, 3)),
-             soft_sample=soft[:, :, ::4, ::4], hard=hard.to(torch.int8), loss_source=loss_s, loss_target=loss_t,
-             prototypes=al.prototypes, grad_norm=gnorm, lr=lr, post_checksum=np.array(cs),
+             soft_sample=r["soft"][:, :, ::4, ::4], hard=r["hard"].to(torch.int8), loss_source=r["loss_s"], loss_target=r["loss_t"],
+             prototypes=r["al"].prototypes, grad_norm=r["gnorm"], lr=r["lr"], post_checksum=np.array(cs),
              post_bn1_running_mean=post["encoder.resnet.bn1.running_mean"],
              post_bn1_running_var=post["encoder.resnet.bn1.running_var"],
              post_l4_bn3_running_var=post["encoder.resnet.layer4.2.bn3.running_var"],
              post_conv1_sample=post["encoder.resnet.conv1.weight"].reshape(-1)[::7],
-             nbt=post["encoder.resnet.bn1.num_batches_tracked"], **grads)
+             nbt=post["encoder.resnet.bn1.num_batches_tracked"],
+             upd_names=np.array(names), upd_offsets=upd_off, upd_samples=upd_flat, upd_noise_floor=noise, **r["grads"])
     print("done")
 
 

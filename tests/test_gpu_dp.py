@@ -65,6 +65,15 @@ def test_single_rank_rccl_step_matches_plain_step():
     assert forced["loss_source"] == pytest.approx(plain["loss_source"], rel=1e-4)
 
 
+def test_single_rank_native_rccl_allreduce_through_the_c_abi():
+    """uem_comm_unique_id / uem_comm_init / uem_allreduce_flat (SURVEY 8b `allreduce_flat`) driving the same DataParallel
+    object: one rank, so the collective is trivial, but it is RCCL on a stream of ours, loaded from the host process."""
+    plain = _bench({})
+    native = _bench({"UEM_DP_FORCE": "1", "UEM_DP_NATIVE": "1", "MASTER_PORT": str(_free_port())})
+    assert native["n_gpus"] == 1 and native["config"]["collective"] == "uem_allreduce_flat (RCCL through the C ABI)"
+    assert native["loss_source"] == pytest.approx(plain["loss_source"], rel=1e-4)
+
+
 def test_two_rank_data_parallel_object(tmp_path):
     line, (r0, r1) = _two_ranks(str(tmp_path / "ov"))
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2"

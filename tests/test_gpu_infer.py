@@ -80,21 +80,56 @@ def test_init_prototypes_and_pseudo_generation_roundtrip(tmp_path):
     model = Deeplabv2(cfg)
     model.load_state_dict(det_state_dict("resnet50", C, False, seed=2333))
     model = model.cuda()
-    # 512x768: two overlapping 512-px windows (images smaller than the tile give 0/0 in the reference too)
-    imgs = [torch.randn(1, 3, 512, 768, generator=gen).cuda() for _ in range(2)]
-    hards = gener_target_pseudo(model, imgs, ["a.png", "b.png"], str(tmp_path), C, slide=True, size=(512, 768))
-    prob = torch.load(os.path.join(str(tmp_path), "a.png.pt"))
+    # 512x768: two overlapping 512-px windows (images smaller than the tile give 0/0 in the reference too).  The call is
+    # the reference's: (_cfg, model, pseudo_loader, path, slide, save_prob, size, ignore_label), train_ssl_uem.py:186-187
+    from types import SimpleNamespace
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    from uemda_amd.utils.tools import pre_slide
+    imgs = [torch.randn(1, 3, 512, 768, generator=gen) for _ in range(2)]
+    loader = [(imgs[0], {"fname": ["a.tif"]}), (imgs[1], {"fname": ["b.tif"]})]
+    cfg_run = SimpleNamespace(DATASETS="IsprsDA", SNAPSHOT_DIR=str(tmp_path), CUTOFF_TOP=0.8, CUTOFF_LOW=0.6, PSEUDO_SELECT=True)
+    out_dir = os.path.join(str(tmp_path), "pseudo")
+    gener_target_pseudo(cfg_run, model, loader, out_dir, size=(512, 768), save_prob=True, slide=True, ignore_label=-1)
+    prob = torch.load(os.path.join(out_dir, "a.tif.pt"))
     assert prob.shape == (C, 512, 768) and prob.dtype == torch.float32
     assert torch.allclose(prob.sum(0), torch.ones(512, 768), atol=1e-4)
-    assert hards[0].shape == (1, 512, 768)
+    with torch.no_grad():
+        direct = pre_slide(model, imgs[0].cuda(), num_classes=C, tta=True)
+    assert torch.equal(prob, direct[0].cpu())
+    from PIL import Image
+    import numpy as np
+    prev = np.array(Image.open(os.path.join(out_dir + "_color", "a.png")))           # colour preview of the selected labels
+    assert prev.shape == (512, 768)
+    sel = pseudo_selection(direct, 0.8, 0.6, "ndarray", -1)[0]
+    # (ignored pixels are written as uint8(-1) like the reference's VisualizeSegmm; Pillow folds that index into the
+    # palette's bit depth, so only the labelled pixels are compared)
+    assert (prev[sel >= 0] == sel[sel >= 0]).all()
+    # a different `size`: the map is resized with bilinear align_corners=True (pseudo_generation.py:135)
+    small_dir = os.path.join(str(tmp_path), "small")
+    gener_target_pseudo(cfg_run, model, loader[:1], small_dir, size=(256, 384), save_prob=True)
+    small = torch.load(os.path.join(small_dir, "a.tif.pt"))
+    ref_small = torch.nn.functional.interpolate(direct.cpu(), (256, 384), mode="bilinear", align_corners=True)[0]
+    torch.testing.assert_close(small, ref_small, rtol=1e-5, atol=1e-6)
+    # class-id branch (save_prob=False): uint8 image of id + 1, 0 = ignored; selection or plain argmax
+    ids_dir = os.path.join(str(tmp_path), "ids")
+    gener_target_pseudo(cfg_run, model, loader[:1], ids_dir, size=(512, 768), save_prob=False)
+    ids = np.array(Image.open(os.path.join(ids_dir, "a.tif")))
+    assert (ids == pseudo_selection(direct, return_type="ndarray")[0] + 1).all()
+    cfg_run.PSEUDO_SELECT = False
+    gener_target_pseudo(cfg_run, model, loader[:1], ids_dir, size=(512, 768), save_prob=False)
+    ids = np.array(Image.open(os.path.join(ids_dir, "a.tif")))
+    am = direct.argmax(dim=1)[0].cpu().numpy()
+    assert (ids == am + 1).all() and len(np.unique(am)) > 1
+    assert (np.array(Image.open(os.path.join(ids_dir + "_color", "a.png"))) == am).all()       # the colour preview of those labels
     # fp16 files (half the bytes) load back as fp32 within half precision
     from uemda_amd.gast.pseudo_generation import load_target_pseudo
     half_dir = os.path.join(str(tmp_path), "half")
-    gener_target_pseudo(model, imgs[:1], ["a.png"], half_dir, C, slide=True, save_dtype=torch.float16)
-    assert torch.load(os.path.join(half_dir, "a.png.pt")).dtype == torch.float16
-    back = load_target_pseudo(os.path.join(half_dir, "a.png.pt"))
+    gener_target_pseudo(cfg_run, model, loader[:1], half_dir, size=(512, 768), save_prob=True, save_dtype=torch.float16)
+    assert torch.load(os.path.join(half_dir, "a.tif.pt")).dtype == torch.float16
+    back = load_target_pseudo(os.path.join(half_dir, "a.tif.pt"))
     assert back.dtype == torch.float32 and back.is_cuda
     torch.testing.assert_close(back.cpu(), prob, rtol=2e-3, atol=1e-3)
+    imgs = [i.cuda() for i in imgs]
     res, miou = evaluate(model, [(imgs[0], torch.randint(-1, C, (1, 512, 768)).cuda())], C, ignore_labels=[0])
     assert 0.0 <= miou <= 1.0 and res["confusion"].sum() > 0
 

@@ -388,18 +388,80 @@ def test_full_model_aspp_ssl_step_matches_reference_golden(conv_precision):
             # (mkldnn on/off) differ by 1-2 % in the deepest gradients (scripts/grad_noise_floor.py)
             err = (got - v).norm() / (v.norm() + 1e-12)
             assert err < 5e-2, (k, float(err))
-    s, a = checksum([p.cpu().contiguous() for p in model.parameters()])
-    assert a == pytest.approx(float(g["post_checksum"][1]), rel=1e-5)
     sd = model.state_dict()
     torch.testing.assert_close(sd["encoder.resnet.bn1.running_mean"].cpu(), g["post_bn1_running_mean"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(sd["encoder.resnet.layer4.2.bn3.running_var"].cpu(), g["post_l4_bn3_running_var"], rtol=1e-3, atol=1e-5)
     assert int(sd["encoder.resnet.bn1.num_batches_tracked"]) == 2
-    # one SGD step: compare the UPDATE (w_post - w_pre), which carries the stem gradient's mask-flip noise
+    _check_updates(model, g, False)
+
+
+def _check_updates(model, g, use_ppm):
+    """One optimizer step seen through the UPDATE of EVERY parameter tensor (256 strided samples each).  The fixture holds
+    the reference's update -lr * (clipped grad + wd * w) in float64 (w_post - w_pre itself is quantised to the weights' last
+    place: 8 % of a BatchNorm gamma's update) and, per tensor, its fp32 noise floor: how far the reference's own step moves
+    when (a) the CPU conv backend changes (mkldnn on / off) or (b) the input images move by one unit in the last place --
+    ~1e-6 at the heads, 2-3 % in the encoder, whose gradients pass ~50 training-mode BatchNorm backward passes (B = 2).
+    Checked: (1) every tensor's update against the reference within 3 x its floor (1e-3 where the floor is rounding level),
+    and over the encoder as a whole no farther from the reference than the reference is from itself; (2) the fused optimizer
+    kernel applied exactly that update to the weights.  (A Sum|w| checksum after one lr = 3e-3 step could not see a wrong
+    update: VERDICT r1.)"""
     from oracle.weights import det_state_dict
-    w0 = det_state_dict("resnet50", C, False, seed=2333)["encoder.resnet.conv1.weight"].reshape(-1)[::7]
-    upd = sd["encoder.resnet.conv1.weight"].cpu().reshape(-1)[::7] - w0
-    upd_ref = g["post_conv1_sample"] - w0
-    assert (upd - upd_ref).norm() / upd_ref.norm() < 6e-2
+    w0 = det_state_dict("resnet50", C, use_ppm, seed=2333)
+    lr, wd = float(g["lr"]), 5e-4
+    names, off, ref, floor = [str(n) for n in g["upd_names"]], g["upd_offsets"], g["upd_samples"], g["upd_noise_floor"]
+    named = dict(model.named_parameters())
+    assert set(names) == set(named), "the fixture covers every parameter tensor"
+    ratios, report = [], []
+    for i, n in enumerate(names):
+        p = named[n]
+        st = max(1, p.numel() // 256)
+        w_pre = w0[n].reshape(-1)[::st][:256].double()
+        grad = p.grad.detach().cpu().reshape(-1)[::st][:256].double()            # post-clip (the fused step scales .grad)
+        upd = -lr * (grad + wd * w_pre)
+        r = ref[int(off[i]):int(off[i + 1])].double()
+        err = float((upd - r).norm() / (r.norm() + 1e-300))
+        fl = float(floor[i])
+        report.append((err, fl, n))
+        if fl < 2.5e-4:
+            assert err < 1e-3, (n, err, fl)              # head side: rounding level
+        else:
+            assert err < 3.0 * fl, (n, err, fl)          # a wrong update of ONE tensor is 10-100x its floor
+            ratios.append(err / fl)
+        # (2) the optimizer kernel: w_post = fp32(w_pre + update), to the last place of w plus the rounding of the update
+        w_post = p.detach().cpu().reshape(-1)[::st][:256].double()
+        ulp = torch.maximum(w_pre.abs(), w_post.abs()).float().clamp_min(1e-30)
+        ulp = (torch.nextafter(ulp, torch.full_like(ulp, float("inf"))) - ulp).double()
+        assert ((w_post - (w_pre + upd)).abs() <= 1.5 * ulp + 2e-6 * upd.abs()).all(), n
+    ratios.sort()
+    median = ratios[len(ratios) // 2]
+    print(f"update error / reference noise floor over {len(ratios)} encoder tensors: median {median:.2f}, max {ratios[-1]:.2f}; "
+          f"worst absolute {max(report)[:2]} {max(report)[2]}")
+    assert median < 1.5, median
+
+
+def test_fused_sgd_matches_torch_sgd_with_clipping():
+    """uem_sgd_clip_step over the flat arenas == clip_grad_norm_(32) + torch.optim.SGD(momentum .9, wd 5e-4) over three steps
+    (train_ssl_uem.py:169-170,228-232): momentum buffer, weight decay, clip coefficient, the data-parallel prescale."""
+    from uemda_amd.optim import FusedSGD
+    model = _model(False)
+    ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in model.parameters()]
+    ref_opt = torch.optim.SGD(ref_params, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    gen = torch.Generator().manual_seed(12)
+    for step, (lr, scale, prescale) in enumerate([(3e-3, 40.0, 1.0), (5e-3, 0.01, 0.5), (1e-2, 3.0, 1.0)]):
+        opt.zero_grad()
+        for p, q in zip(model.parameters(), ref_params):
+            gq = torch.randn(q.shape, generator=gen) * scale / q.numel() ** 0.5          # total norm ~ scale * sqrt(#tensors)
+            q.grad = gq * prescale
+            p.grad.copy_(gq.cuda() if p.grad.dim() < 4 else gq.cuda().contiguous(memory_format=torch.channels_last))
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref_params, max_norm=32, norm_type=2)
+        ref_opt.param_groups[0]["lr"] = lr
+        ref_opt.step()
+        opt.param_groups[0]["lr"] = lr
+        opt.step(max_norm=32.0, grad_prescale=prescale)
+        torch.testing.assert_close(opt.last_grad_norm.cpu().reshape(()) * prescale, norm_ref, rtol=1e-5, atol=1e-6)
+        for (n, p), q in zip(model.named_parameters(), ref_params):
+            torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=2e-6, atol=2e-7, msg=lambda m, n=n, s=step: f"{n} step {s}: {m}")
 
 
 def test_layer_ppm_golden():
@@ -459,8 +521,7 @@ def test_full_model_ppm_ssl_step_matches_reference_golden():
     torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=1e-2, atol=1e-4)
-    s, a = checksum([p.cpu().contiguous() for p in model.parameters()])
-    assert a == pytest.approx(float(g["post_checksum"][1]), rel=1e-5)
+    _check_updates(model, g, True)
 
 
 def test_cpu_tensors_fail_loudly():

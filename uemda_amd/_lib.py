@@ -96,6 +96,10 @@ SIGNATURES = {
     "uem_pcl_workspace_floats": [I, I],
     "uem_coral_finish": [P, P, P, P, I, I, I, P, P, P, P, P],
     "uem_negate": [P, P, I, P],
+    "uem_comm_unique_id": [P],
+    "uem_comm_init": [POINTER(c_void_p), P, I, I],
+    "uem_allreduce_flat": [P, P, L, P],
+    "uem_comm_destroy": [P],
     "uem_grad_sqnorm": [P, L, P, P, P],
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
 }

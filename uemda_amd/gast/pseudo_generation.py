@@ -34,29 +34,96 @@ def pseudo_selection(mask, cutoff_top=0.8, cutoff_low=0.6, return_type='ndarray'
     return ret.cpu().numpy() if return_type == 'ndarray' else ret
 
 
-def gener_target_pseudo(model, images, names, save_pseudo_label_path, num_classes, slide=True, save_prob=True,
-                        size=None, cutoff_top=0.8, cutoff_low=0.6, ignore_label=-1, save_dtype=torch.float32):
-    """Offline pseudo-label generation (pseudo_generation.py:96-155): eval-mode sliding-window forward with the
-    8-way TTA, then `<fname>.pt` = torch.save of the (C,H,W) fp32 probability map (the wire format
-    `BaseData.__getitem__` loads, basedata.py:87).  `images` yields (1,3,H,W) CUDA tensors, `names` the file names.
-    `save_dtype=torch.float16` halves the files (SURVEY 8 f1 option; `load_target_pseudo` returns fp32 either way;
-    the reference's loader would need `.float()` for such a file).
-    Returns the hard labels selected from each map (what the reference only renders as colour PNGs)."""
+# What `eval(_cfg.DATASETS)` resolves to in the reference (uemda/datasets/isprsda.py:17-36, loveda.py:17-41): the class
+# count, the palette of the colour previews and the native tile size -- data constants, restated here because the dataset
+# classes themselves (file loaders) are outside the path.
+DATASET_INFO = {
+    "IsprsDA": dict(num_classes=6, size=(512, 512),
+                    palette=[255, 0, 0, 255, 255, 255, 0, 0, 255, 0, 255, 255, 0, 255, 0, 255, 255, 0]),
+    "LoveDA": dict(num_classes=7, size=(1024, 1024),
+                   palette=[255, 255, 255, 255, 0, 0, 255, 255, 0, 0, 0, 255, 159, 129, 183, 0, 255, 0, 255, 195, 128]),
+}
+
+
+def _dataset_info(_cfg, model):
+    name = getattr(_cfg, "DATASETS", None)
+    if isinstance(name, str) and name in DATASET_INFO:
+        return DATASET_INFO[name]
+    if hasattr(name, "LABEL_MAP"):                                  # the dataset class itself
+        return dict(num_classes=len(name.LABEL_MAP), palette=getattr(name, "PALETTE", None), size=getattr(name, "SIZE", None))
+    n = getattr(_cfg, "NUM_CLASSES", None) or getattr(getattr(model, "config", None), "num_classes", None)
+    if n is None:
+        raise UemError(f"gener_target_pseudo: cannot tell the class count of _cfg.DATASETS={name!r}")
+    return dict(num_classes=int(n), palette=None, size=None)
+
+
+def _resize_align_corners(cls, size):
+    """F.interpolate(cls, size, mode='bilinear', align_corners=True) (pseudo_generation.py:135) on the device: every (b, c)
+    plane is a one-channel NHWC image for uem_bilinear_up_fwd."""
+    B, C, h, w = cls.shape
+    H, W = int(size[0]), int(size[1])
+    if (H, W) == (h, w):
+        return cls
+    src = cls.contiguous()
+    out = torch.empty((B, C, H, W), device=cls.device, dtype=torch.float32)
+    call("uem_bilinear_up_fwd", ptr(src), ptr(out), B * C, h, w, 1, H, W, 1, 1, None, None, 0, stream())
+    return out
+
+
+def _save_indexed_png(arr, path, palette):
+    from PIL import Image                                           # the reference's VisualizeSegmm (uemda/viz.py:11-28)
+    import numpy as np
+    im = Image.fromarray(np.asarray(arr).astype(np.uint8).squeeze())
+    if palette is not None:
+        im.putpalette(palette)
+    im.save(path)
+
+
+def gener_target_pseudo(_cfg, model, pseudo_loader, save_pseudo_label_path, slide=True, save_prob=False, size=(1024, 1024),
+                        ignore_label=-1, save_dtype=torch.float32):
+    """Offline pseudo-label generation with the reference's signature and behaviour (uemda/gast/pseudo_generation.py:96-155;
+    caller tools/train_ssl_uem.py:177-190): eval-mode sliding-window forward with the 8-way TTA over `pseudo_loader`
+    (batches `(image (b,3,H,W), {'fname': [...]})`), then per image
+      save_prob=True : `<fname>.pt` = torch.save of the (C, *size) probability map, resized with bilinear
+                       align_corners=True when `size` differs from the image (the wire format BaseData.__getitem__ reads
+                       back, basedata.py:87); colour previews of the selected labels when _cfg.SNAPSHOT_DIR is set;
+      save_prob=False: `<fname>` = uint8 image of class id + 1 (0 = ignored), from pseudo_selection when
+                       _cfg.PSEUDO_SELECT else argmax.
+    `save_dtype=torch.float16` (not in the reference) halves the .pt files; `load_target_pseudo` returns fp32 either way."""
     import os
+    import numpy as np
     from ..utils.tools import pre_slide
-    os.makedirs(save_pseudo_label_path, exist_ok=True)
     model.eval()
-    hards = []
+    info = _dataset_info(_cfg, model)
+    num_classes, palette = info["num_classes"], info["palette"]
+    color_dir = save_pseudo_label_path + '_color'
+    os.makedirs(save_pseudo_label_path, exist_ok=True)
+    os.makedirs(color_dir, exist_ok=True)
+    snapshot = getattr(_cfg, "SNAPSHOT_DIR", None) is not None
     with torch.no_grad():
-        for img, name in zip(images, names):
-            cls = pre_slide(model, img, num_classes=num_classes, tta=True) if slide else model(img)
-            if size is not None and tuple(size) != tuple(cls.shape[-2:]):
-                raise UemError("gener_target_pseudo: resizing to a different `size` is not implemented "
-                               "(the ISPRS / LoveDA tiles are generated at their native size)")
+        for ret, ret_gt in pseudo_loader:
+            ret = ret.cuda()
+            cls = pre_slide(model, ret, num_classes=num_classes, tta=True) if slide else model(ret)      # (b, c, h, w)
+            names = ret_gt['fname']
             if save_prob:
-                torch.save(cls.squeeze(dim=0).to("cpu", save_dtype), os.path.join(save_pseudo_label_path, name + '.pt'))
-            hards.append(pseudo_selection(cls, cutoff_top, cutoff_low, 'tensor', ignore_label))
-    return hards
+                full = _resize_align_corners(cls, size)
+                torch.save(full.squeeze(dim=0).to("cpu", save_dtype), os.path.join(save_pseudo_label_path, names[0] + '.pt'))
+                if snapshot:
+                    hard = pseudo_selection(cls, ignore_label=ignore_label, cutoff_top=_cfg.CUTOFF_TOP, cutoff_low=_cfg.CUTOFF_LOW)
+                    for fname, pred in zip(names, hard):
+                        _save_indexed_png(pred, os.path.join(color_dir, fname.replace('.tif', '.png')), palette)
+            else:
+                if getattr(_cfg, "PSEUDO_SELECT", False):
+                    hard = pseudo_selection(cls, ignore_label=ignore_label)                              # (b, h, w) in -1..C-1
+                else:
+                    pred = torch.empty((cls.shape[0],) + tuple(cls.shape[-2:]), device=cls.device, dtype=torch.int64)
+                    call("uem_argmax_confusion", ptr(cls.contiguous()), None, ptr(pred), None, cls.shape[0], cls.shape[1],
+                         cls.shape[2] * cls.shape[3], stream())
+                    hard = pred.cpu().numpy()
+                _save_indexed_png((hard + 1).reshape(*size), os.path.join(save_pseudo_label_path, names[0]), None)
+                if snapshot:
+                    for fname, pred in zip(names, hard):
+                        _save_indexed_png(pred, os.path.join(color_dir, fname.replace('.tif', '.png')), palette)
 
 
 def load_target_pseudo(path, device="cuda"):
