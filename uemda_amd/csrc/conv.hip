@@ -71,7 +71,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
     const bool dense_rows = !(MODE == 1 && p.sub > 1);
-    if (dense_rows && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+    // strided data gradient (one launch per output-parity class): GEMM row m is pixel (sub*yy + py, sub*xx + px) of its image,
+    // so a staged row still leaves as 16-byte stores, only its base offset is computed per row
+    auto row_off = [&](const int m) -> size_t {
+        if (dense_rows) return (size_t)m * p.y_ld;
+        const int hw = p.Hs * p.Ws;
+        const int ni = m / hw, rem = m - ni * hw;
+        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
+        return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
+    };
+    if ((dense_rows || (p.tile_stats == nullptr && p.tile_bnbwd == nullptr)) && m0 + BM <= p.M && n0 + BN <= p.Cout) {
         // Full tile: the accumulators go through LDS (the operand stages are dead now) in two 64-row halves and
         // leave as 16-byte stores, 32 lanes per 512-B row segment.  (64 dword stores per lane made the epilogue
         // store-issue bound on the small-K layers.)  The staged half is also where the fused BatchNorm statistics
@@ -110,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                     const float* const asrc = p.acc_src ? p.acc_src : p.y;
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
-                        const size_t off = (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4;
+                        const size_t off = row_off(m0 + hm * 64 + srow + (rp0 + u) * RPP) + n0 + sc4;
                         o[u] = *reinterpret_cast<const float4*>(asrc + off);
                         if (p.acc_bits) ob[u] = p.acc_bits[off >> 5] >> (off & 31);
                     }
@@ -130,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                         // the fused BatchNorm reduction below works on the FINAL gradient
                         if (MODE == 1 && p.tile_bnbwd != nullptr) *reinterpret_cast<float4*>(&stg[row * LDW + sc4]) = v;
                     }
-                    *reinterpret_cast<float4*>(p.y + (size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4) = v;
+                    *reinterpret_cast<float4*>(p.y + row_off(m0 + hm * 64 + row) + n0 + sc4) = v;
                 }
             }
             if (MODE == 1 && p.tile_bnbwd != nullptr) {
