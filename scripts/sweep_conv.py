@@ -31,8 +31,8 @@ def timeit(f):
 def main():
     B = int(os.environ.get("B", "32"))
     only = sys.argv[1] if len(sys.argv) > 1 else ""
-    variants = [(0, 0), (1, 0), (1, 64)]
-    names = ["regs", "dma", "dma bn64"]
+    variants = [(0, 0), (1, 0), (1, 64), (1, 16000)]          # (dma, bn + 1000 * channels per k-step)
+    names = ["regs", "dma", "dma bn64", "dma k16"]
     print("shape".ljust(24) + "".join(f"fwd {n}".rjust(14) for n in names) + "".join(f"dgrad {n}".rjust(15) for n in names))
     tot = {(k, v): 0.0 for k in ("f", "d") for v in variants}
     for name, cin, cout, k, s, d, hin, cnt in SHAPES:

@@ -533,24 +533,30 @@ __device__ __forceinline__ i32x4 conv_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
-template <int BN>
+// KB: channels per k-step (32, or 16: half the stage size, so a third / fourth block fits a CU)
+template <int BN, int KB>
 struct ConvDmaCfg {
-    static constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, V_FLOATS = BM;
+    static constexpr int CPR = KB / 4;                                    // 16-B chunks per staged row = DMA lanes per row
+    static constexpr int RPT = 256 / CPR;                                 // rows one pass of the 256 threads covers
+    static constexpr int AR = BM / RPT, BR = BN / RPT;                    // A / B rows per thread
+    static constexpr int A_FLOATS = BM * KB, B_FLOATS = BN * KB, V_FLOATS = BM;
     static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS + V_FLOATS;
     static constexpr int EPI_FLOATS = 64 * (BN + 4);                      // the epilogue's staging area
     static constexpr int BASE_FLOATS = 2 * STAGE_FLOATS > EPI_FLOATS ? 2 * STAGE_FLOATS : EPI_FLOATS;
-    static constexpr int BPC = BN == 128 ? 2 : 3;                         // resident blocks per CU (LDS: 65 / 49 KB)
+    static constexpr int BPC = KB == 16 ? 3 : (BN == 128 ? 2 : 3);        // resident blocks per CU (LDS: 65 / 49 / 34 KB)
 };
 
 // MODE 0 forward / 1 data gradient; AFFINE: BatchNorm affine + ReLU on the input operand; PADDED: the filter has taps
 // that can fall outside the image (only then does the affine path need the validity words)
-template <int BN, int MODE, bool AFFINE, bool PADDED>
-__global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
-    using C = ConvDmaCfg<BN>;
+template <int BN, int KB, int MODE, bool AFFINE, bool PADDED>
+__global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
+    using C = ConvDmaCfg<BN, KB>;
+    constexpr int CPR = C::CPR, RPT = C::RPT, AR = C::AR, BR = C::BR;
+    constexpr int SWS = KB == 32 ? 1 : 2;                                 // swizzle = (row >> SWS) & (CPR - 1): rows per 256-B bank row
     // 4 x 1 waves: each wave owns 32 of the tile's 128 rows and ALL its columns, so every A element is fetched -- and pushed
     // through the prologue -- by exactly one wave (2 x 2 waves transformed each element twice: the prologue's VALU work cost
     // the forward 12 %, profiles/r02_d_conv_ablation.txt)
-    constexpr int WM = 4, WN = 1, MT = BM / WM / 32, NT = BN / WN / 32, BROWS = BN / 32;
+    constexpr int WM = 4, WN = 1, MT = BM / WM / 32, NT = BN / WN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Ssc = smem + C::BASE_FLOATS;                            // AFFINE only: [Cin] scale, then [Cin] shift
     if (AFFINE) {
@@ -561,17 +567,17 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
     const int tiles_n = p.Cout / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + 32*j
-    const int lc4 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 4;                 // swizzled source chunk (floats) of this lane
+    const int lrow = tid / CPR;                                          // DMA: CPR lanes per staged row, rows lrow + RPT*j
+    const int lc4 = ((tid % CPR) ^ ((lrow >> SWS) & (CPR - 1))) * 4;     // swizzled source chunk (floats) of this lane
     const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
 
-    int gy[4], gx[4], gpix[4];                                           // gather geometry of this lane's 4 A rows
+    int gy[AR], gx[AR], gpix[AR];                                        // gather geometry of this lane's A rows
     {
         const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
         const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + lrow + 32 * j;
+        for (int j = 0; j < AR; ++j) {
+            const int m = m0 + lrow + RPT * j;
             if (m < p.M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / Wrow, ox = rem - oy * Wrow;
@@ -581,17 +587,17 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
             } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
         }
     }
-    const int cpb = p.Cin / BK, KT = p.ntaps * cpb, Ktot = p.KH * p.KW * p.Cin;
+    const int cpb = p.Cin / KB, KT = p.ntaps * cpb, Ktot = p.KH * p.KW * p.Cin;
     // issue-side walk over (tap, channel block); byte offsets from p.x / p.w
     int lt = 0, lci0 = 0;
-    unsigned tapok = 0, aoff[4], boff[BROWS];
+    unsigned tapok = 0, aoff[AR], boff[BR];
     auto setup_tap = [&](int t) {
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
         const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);
         const int kx = tap - ky * p.KW;
         tapok = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < AR; ++j) {
             bool ok = gpix[j] >= 0;
             int iy, ix;
             if (MODE == 1) {
@@ -607,8 +613,8 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
             tapok |= (ok ? 1u : 0u) << j;
         }
 #pragma unroll
-        for (int j = 0; j < BROWS; ++j)
-            boff[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc4)) * 4u;
+        for (int j = 0; j < BR; ++j)
+            boff[j] = ((unsigned)(n0 + lrow + RPT * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc4)) * 4u;
     };
 
     f32x16 acc[MT][NT];
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
-    const int sw = (fr >> 1) & 7;                                        // (row>>1)&7 of every fragment row of this lane
+    const int sw = (fr >> SWS) & (CPR - 1);                              // swizzle of every fragment row of this lane
     int rci0 = 0;                                                        // read-side channel base of the k-tile being consumed
 
     // one function, two __restrict__ stages (+ the prologue operands): alias scopes tell the wait-count pass that the
@@ -633,18 +639,18 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
             float* const Vs = Bs + C::B_FLOATS;
             if (lci0 == 0) setup_tap(lt);                                // block-uniform
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < AR; ++j) {
                 const bool ok = (tapok >> j) & 1u;
                 uem_raw_buffer_load_lds(rs_x, (lds_u32p)(As + (j * 4 + wave) * 256), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
-                aoff[j] += BK * 4;
-                if (AFFINE && PADDED && (tid & 7) == 0) Vs[lrow + 32 * j] = ok ? 1.f : 0.f;
+                aoff[j] += KB * 4;
+                if (AFFINE && PADDED && (tid % CPR) == 0) Vs[lrow + RPT * j] = ok ? 1.f : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < BROWS; ++j) {
+            for (int j = 0; j < BR; ++j) {
                 uem_raw_buffer_load_lds(rs_w, (lds_u32p)(Bs + (j * 4 + wave) * 256), 16, (int)boff[j], 0, 0, 0);
-                boff[j] += BK * 4;
+                boff[j] += KB * 4;
             }
-            lci0 += BK;
+            lci0 += KB;
             if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
         }
         if (!do_phase) return;
@@ -664,9 +670,9 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
             const int q = ks * 2 + fh;                                   // 16-B chunk (4 channels) of this lane half
             const int qs = (q ^ sw) * 4;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * BK + qs]);
+            for (int i = 0; i < MT; ++i) fa[buf][i] = *reinterpret_cast<const float4*>(&As[(wm + i * 32 + fr) * KB + qs]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * BK + qs]);
+            for (int j = 0; j < NT; ++j) fb[buf][j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 32 + fr) * KB + qs]);
             if (AFFINE) {
                 fs[buf] = *reinterpret_cast<const float4*>(&ssc[rci0 + q * 4]);
                 fh4[buf] = *reinterpret_cast<const float4*>(&ssc[p.Cin + rci0 + q * 4]);
@@ -691,9 +697,9 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
         fetch(0, 0);
         xform(0);
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
+        for (int ks = 0; ks < KB / 8; ++ks) {
             const int cb = ks & 1, nb = cb ^ 1;
-            const bool more = ks + 1 < BK / 8;
+            const bool more = ks + 1 < KB / 8;
             if (more) fetch(ks + 1, nb);
             MFMA_STEP(x, cb) MFMA_STEP(y, cb)
             if (more) xform(nb);
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN>::BPC)) void conv_dma_kernel(co
             }
         }
 #undef MFMA_STEP
-        rci0 += BK;
+        rci0 += KB;
         if (rci0 >= p.Cin) rci0 = 0;
     };
 #define CONV_SYNC()                                                 \
@@ -771,14 +777,14 @@ static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
 }
 
 // tuning overrides (scripts/sweep_conv.py): LDS-DMA main loop on/off (-1 = rule), its N tile (0 = rule)
-static int g_conv_dma = -1, g_conv_dma_bn = 0;
-extern "C" void uemdbg_conv_config(int dma, int bn) { g_conv_dma = dma; g_conv_dma_bn = bn; }
+static int g_conv_dma = -1, g_conv_dma_bn = 0, g_conv_dma_kb = 0;
+extern "C" void uemdbg_conv_config(int dma, int bn) { g_conv_dma = dma; g_conv_dma_bn = bn % 1000; g_conv_dma_kb = bn / 1000; }
 static int g_conv_dbg = 0;      // diagnostic: 1 = the LDS-DMA loop issues no DMA after its first tile (results wrong)
 extern "C" void uemdbg_conv_dbg(int v) { g_conv_dbg = v; }
 
-template <int BN_, int MODE>
+template <int BN_, int KB_, int MODE>
 static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, hipStream_t st) {
-    using C = ConvDmaCfg<BN_>;
+    using C = ConvDmaCfg<BN_, KB_>;
     const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
     const size_t lds = ((size_t)C::BASE_FLOATS + (affine ? 2 * (size_t)p.Cin : 0)) * sizeof(float);
     const bool padded = p.KH * p.KW > 1;
@@ -788,9 +794,9 @@ static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, h
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         k<<<grid, 256, lds, st>>>(q, xb, wb);
     };
-    if (MODE == 0 && affine && padded) go(conv_dma_kernel<BN_, MODE, MODE == 0, MODE == 0>);
-    else if (MODE == 0 && affine) go(conv_dma_kernel<BN_, MODE, MODE == 0, false>);
-    else go(conv_dma_kernel<BN_, MODE, false, false>);
+    if (MODE == 0 && affine && padded) go(conv_dma_kernel<BN_, KB_, MODE, MODE == 0, MODE == 0>);
+    else if (MODE == 0 && affine) go(conv_dma_kernel<BN_, KB_, MODE, MODE == 0, false>);
+    else go(conv_dma_kernel<BN_, KB_, MODE, false, false>);
 }
 
 // The LDS-DMA main loop takes exact-fp32 forward / data-gradient launches with 32-multiple input and 64-multiple output
@@ -807,8 +813,13 @@ static int conv_dma_try(const ConvP& p, bool affine, hipStream_t st) {
     if (xb >= 4294967280.0 || wb >= 4294967280.0) return 0;
     const bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64;
     if constexpr (MODE != 2) {
-        if (bn128) conv_dma_go<128, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
-        else conv_dma_go<64, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
+        // 16-channel k-steps (34 KB of LDS: a third resident block) pay on the forward 1x1 layers, whose short k-loops leave
+        // the most prologue / epilogue time to cover (+2-4 %); with padding words or the data gradient's epilogues they lose
+        // (profiles/r02_h_conv_sweep_k16.txt)
+        const bool k16 = g_conv_dma_kb == 16 || (g_conv_dma_kb == 0 && MODE == 0 && p.ntaps == 1);
+        if (k16 && bn128) conv_dma_go<128, 16, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
+        else if (bn128) conv_dma_go<128, 32, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
+        else conv_dma_go<64, 32, MODE>(p, affine, (unsigned)xb, (unsigned)wb, st);
     }
     return 1;
 }
