@@ -292,6 +292,18 @@ int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n,
                       float max_norm, float lr, float momentum, float weight_decay, int first_step,
                       float grad_prescale, void* stream);
 
+/* ---- bf16 STORAGE (BASELINE config 5: "bf16 weights, CDNA4 bf16 MFMA") -------------------------------------------
+ * Activations and weights bf16 in HBM (uint16_t = the raw bf16 bits, NHWC / OHWI as above), fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, outputs rounded to nearest-even.  There is no operand prologue on this path: BatchNorm +
+ * ReLU are materialised by uem_bn_apply_bf16 (same HBM bytes per activation as fp32 storage + prologue).  Replaces the
+ * same cuDNN call sites as uem_conv2d_fwd.
+ * uem_conv2d_bf16: forward, or with UEM_CONV_TRANSPOSED the data gradient (x = dY, w = transposed weights, y = dX, shape =
+ *   the FORWARD conv); UEM_CONV_ACCUMULATE: y += result.  tile_stats (forward, may be NULL): [2][Cout][M/128] per-tile
+ *   column sums of the STORED (rounded) y and y*y for uem_bn_stats_from_tiles.  Needs reduction channels % 64 == 0,
+ *   output channels % 64 == 0.                                                                                     */
+int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags,
+                    float* tile_stats, void* stream);
+
 /* ---- data parallel (new relative to the reference, which is single-GPU: SURVEY 2a, 8e) --------------------------
  * all-reduce(sum, in place) of a flat fp32 buffer -- the gradient arena, 98 MB for R50-ASPP -- over RCCL on `stream`:
  * one process per GPU, xGMI inside the node.  Rank 0 draws an id with uem_comm_unique_id, the host ships those 128

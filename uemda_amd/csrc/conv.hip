@@ -737,6 +737,239 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kerne
     conv_epilogue<BN, WM, WN, MODE>(p, acc, smem, m0, n0);
 }
 
+// =========================================================================================================
+// bf16-STORAGE convolution (BASELINE config 5: "bf16 weights, CDNA4 bf16 MFMA"): activations and weights are bf16 in
+// HBM, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, bf16 out.  Same LDS-DMA skeleton as conv_dma_kernel: a staged
+// row is 64 channels = 128 bytes, its eight 16-byte chunks (8 bf16 = exactly one MFMA operand fragment) XOR-swizzled by
+// (row>>1)&7, two stages, one barrier per 64-channel k-step.  No operand prologue: with matrix instructions 16x faster
+// than the f32 ones a BatchNorm transform at the fetch would be the bottleneck, so this path materialises relu(bn(z))
+// (uem_bn_apply_bf16) -- the same HBM bytes per activation as fp32 + prologue.  Epilogue: fp32 accumulators through LDS,
+// rounded to bf16 (RNE), 16-byte stores; optional accumulate (y += ...) and per-tile BatchNorm statistics of the ROUNDED
+// values (what the next layer will read).
+// =========================================================================================================
+#define KBH 64                                                             // bf16 channels per k-step
+template <int BN>
+struct ConvBf16Cfg {
+    static constexpr int A_ELEMS = BM * KBH, B_ELEMS = BN * KBH;          // bf16 elements per stage
+    static constexpr int STAGE_BYTES = (A_ELEMS + B_ELEMS) * 2;
+    static constexpr int EPI_BYTES = 64 * (BN + 4) * 4;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+};
+__device__ __forceinline__ unsigned short f2bf(float f) {                  // RNE, NaN stays NaN (hipcc: v_cvt_pk_bf16_f32)
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
+    using C = ConvBf16Cfg<BN>;
+    constexpr int WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32, BR = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
+    const unsigned short* const xh = reinterpret_cast<const unsigned short*>(p.x);
+    unsigned short* const yh = reinterpret_cast<unsigned short*>(p.y);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = p.Cout / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + 32*j
+    const int lc8 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 8;                 // swizzled source chunk (elements) of this lane
+    const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
+    (void)xh;
+
+    int gy[4], gx[4], gpix[4];
+    {
+        const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
+        const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + lrow + 32 * j;
+            if (m < p.M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / Wrow, ox = rem - oy * Wrow;
+                if (MODE == 1) { gy[j] = oy * p.sub + p.py + p.pad; gx[j] = ox * p.sub + p.px + p.pad; }
+                else { gy[j] = oy * p.stride - p.pad; gx[j] = ox * p.stride - p.pad; }
+                gpix[j] = n * p.H * p.W;
+            } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
+        }
+    }
+    const int cpb = p.Cin / KBH, KT = p.ntaps * cpb, Ktot = p.KH * p.KW * p.Cin;
+    int lt = 0, lci0 = 0;
+    unsigned tapok = 0, aoff[4], boff[BR];
+    auto setup_tap = [&](int t) {
+        const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
+        const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);
+        const int kx = tap - ky * p.KW;
+        tapok = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = gpix[j] >= 0;
+            int iy, ix;
+            if (MODE == 1) {
+                const int ty = gy[j] - ky * p.dil, tx = gx[j] - kx * p.dil;
+                if (p.stride == 1) { iy = ty; ix = tx; }
+                else { iy = ty / p.stride; ix = tx / p.stride; ok = ok && (iy * p.stride == ty) && (ix * p.stride == tx); }
+                ok = ok && ty >= 0 && tx >= 0 && iy < p.H && ix < p.W;
+            } else {
+                iy = gy[j] + ky * p.dil; ix = gx[j] + kx * p.dil;
+                ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            }
+            aoff[j] = ((unsigned)(gpix[j] + iy * p.W + ix) * (unsigned)p.x_ld + (unsigned)lc8) * 2u;
+            tapok |= (ok ? 1u : 0u) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            boff[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc8)) * 2u;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+
+    auto step = [&](unsigned short* __restrict__ fill, const unsigned short* __restrict__ use, const bool do_issue, const bool do_phase) {
+        if (do_issue) {
+            unsigned short* const As = fill;
+            unsigned short* const Bs = fill + C::A_ELEMS;
+            if (lci0 == 0) setup_tap(lt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (tapok >> j) & 1u;
+                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(As + (j * 4 + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
+                aoff[j] += KBH * 2;
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(Bs + (j * 4 + wave) * 512), 16, (int)boff[j], 0, 0, 0);
+                boff[j] += KBH * 2;
+            }
+            lci0 += KBH;
+            if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
+        }
+        if (!do_phase) return;
+        const unsigned short* const As = use;
+        const unsigned short* const Bs = use + C::A_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < KBH / 16; ++ks) {
+            const int qs = (((ks * 2 + fh) ^ sw)) * 8;                   // this lane half's 16-B chunk = its 8 k of the MFMA step
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm + i * 32 + fr) * KBH + qs]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn + j * 32 + fr) * KBH + qs]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+#define CONV_SYNC()                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                   \
+    asm volatile("" ::: "memory")
+    if (KT > 0) {
+        unsigned short* const st0 = lds16;
+        unsigned short* const st1 = lds16 + C::STAGE_BYTES / 2;
+        step(st0, st1, true, false);
+        for (int kt = 0; kt < KT; kt += 2) {
+            CONV_SYNC();
+            step(st1, st0, kt + 1 < KT, true);
+            if (kt + 1 >= KT) break;
+            CONV_SYNC();
+            step(st0, st1, kt + 2 < KT, true);
+        }
+    }
+    __syncthreads();
+#undef CONV_SYNC
+
+    // ---- epilogue -----------------------------------------------------------------------------------------
+    const bool dense_rows = !(MODE == 1 && p.sub > 1);
+    auto row_off = [&](const int m) -> size_t {
+        if (dense_rows) return (size_t)m * p.y_ld;
+        const int hw = p.Hs * p.Ws;
+        const int ni = m / hw, rem = m - ni * hw;
+        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
+        return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
+    };
+    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = 256 / TPR, NRP = 64 / RPP;
+    float* const stg = smem;
+    const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
+    float cs1 = 0.f, cs2 = 0.f;
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {
+        if (wm / 64 == hm) {
+            const int rbase = wm % 64;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+        uint4 o[NRP];
+        bool rok[NRP];
+#pragma unroll
+        for (int u = 0; u < NRP; ++u) {
+            const int m = m0 + hm * 64 + srow + u * RPP;
+            rok[u] = m < p.M;
+            if (p.accumulate && rok[u]) o[u] = *reinterpret_cast<const uint4*>(yh + row_off(m) + n0 + sc8);
+        }
+#pragma unroll
+        for (int u = 0; u < NRP; ++u) {
+            const int row = srow + u * RPP;
+            if (!rok[u]) continue;
+            float v[8];
+            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8]);
+            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8 + 4]);
+            if (p.accumulate) {
+                const unsigned w4[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w4[e] << 16); v[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+            }
+            unsigned pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = f2bf(v[2 * e]), hi = f2bf(v[2 * e + 1]);
+                pk[e] = lo | (hi << 16);
+                v[2 * e] = bf2f((unsigned short)lo); v[2 * e + 1] = bf2f((unsigned short)hi);
+            }
+            *reinterpret_cast<uint4*>(yh + row_off(m0 + hm * 64 + row) + n0 + sc8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (p.tile_stats != nullptr) {                               // statistics of what was stored
+                *reinterpret_cast<float4*>(&stg[row * LDW + sc8]) = *reinterpret_cast<const float4*>(&v[0]);
+                *reinterpret_cast<float4*>(&stg[row * LDW + sc8 + 4]) = *reinterpret_cast<const float4*>(&v[4]);
+            }
+        }
+        if (p.tile_stats != nullptr) {
+            __syncthreads();
+            if (tid < BN) {
+#pragma unroll 8
+                for (int row = 0; row < 64; ++row) {
+                    const float v = stg[row * LDW + tid];
+                    cs1 += v;
+                    cs2 += v * v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (p.tile_stats != nullptr && tid < BN) {
+        const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
+        float* ts = p.tile_stats + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
+        ts[0] = cs1;
+        ts[(size_t)p.Cout * tiles_m] = cs2;
+    }
+}
+
 static int conv_check(const uem_conv_shape* s) {
     if (!s) return uem_fail(UEM_ERR_INVALID, "conv: null shape");
     if (s->N <= 0 || s->H <= 0 || s->W <= 0 || s->Cin <= 0 || s->Cout <= 0 || s->KH <= 0 || s->KW <= 0 || s->stride <= 0 || s->dil <= 0 || s->pad < 0)
@@ -1484,4 +1717,75 @@ extern "C" int uem_aspp_gather_bwd(const float* dout, float* dG, int N, int h, i
     if (rc) return rc;
     aspp_gather_bwd_kernel<<<uem_stream_grid((int64_t)N * h * w * R, 256), 256, 0, (hipStream_t)stream>>>(dout, dG, p);
     return uem_check_launch("aspp_gather_bwd");
+}
+
+// =========================================================================================================
+// bf16-storage entry points (BASELINE config 5)
+// =========================================================================================================
+template <int BN_, int MODE>
+static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+    using C = ConvBf16Cfg<BN_>;
+    const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
+    auto k = conv_bf16_kernel<BN_, MODE>;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)attr;
+    k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
+}
+extern "C" int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags,
+                               float* tile_stats, void* stream) {
+    UEM_REQUIRE(x && w && y, "conv2d_bf16: null pointer");
+    int rc = conv_check(s);
+    if (rc) return rc;
+    const bool transposed = (flags & UEM_CONV_TRANSPOSED) != 0;
+    UEM_REQUIRE((flags & ~(UEM_CONV_TRANSPOSED | UEM_CONV_ACCUMULATE)) == 0, "conv2d_bf16: only TRANSPOSED / ACCUMULATE flags");
+    const int kin = transposed ? s->Cout : s->Cin, kout = transposed ? s->Cin : s->Cout;
+    if (kin % KBH != 0 || kout % 64 != 0 || s->x_ld % 8 != 0 || s->y_ld % 8 != 0 || (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15))
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: needs reduction channels %% 64 == 0, output channels %% 64 == 0, 16-byte rows");
+    ConvP p;
+    p.x = (const float*)x; p.w = (const float*)w; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = (float*)y;
+    p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
+    p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0; p.relu = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0;
+    p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (!transposed) {
+        UEM_REQUIRE(!tile_stats || ((int64_t)s->N * s->Ho * s->Wo) % 128 == 0, "conv2d_bf16: tile statistics need M %% 128 == 0");
+        p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
+        p.x_ld = s->x_ld; p.y_ld = s->y_ld; p.M = s->N * s->Ho * s->Wo;
+        const double xb = (double)p.N * p.H * p.W * p.x_ld * 2.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 2.0;
+        if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
+        if (p.Cout % 128 == 0) conv_bf16_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        else conv_bf16_go<64, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        return uem_check_launch("conv2d_bf16");
+    }
+    UEM_REQUIRE(!tile_stats, "conv2d_bf16: no statistics on the data gradient");
+    UEM_REQUIRE(s->KH * s->KW <= 16, "conv2d_bf16 dgrad: at most 16 taps");
+    p.N = s->N; p.H = s->Ho; p.W = s->Wo; p.Cin = s->Cout;
+    p.Ho = s->H; p.Wo = s->W; p.Cout = s->Cin;
+    p.x_ld = s->y_ld; p.y_ld = s->x_ld;
+    p.sub = s->stride;
+    const double xb = (double)p.N * p.H * p.W * p.x_ld * 2.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 2.0;
+    if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
+    for (int py = 0; py < s->stride; ++py) {
+        for (int px = 0; px < s->stride; ++px) {
+            p.py = py; p.px = px;
+            p.Hs = (s->H - py + s->stride - 1) / s->stride;
+            p.Ws = (s->W - px + s->stride - 1) / s->stride;
+            if (p.Hs <= 0 || p.Ws <= 0) continue;
+            p.ntaps = 0; p.tapmask = 0;
+            for (int ky = 0; ky < s->KH; ++ky) {
+                if ((py + s->pad - ky * s->dil) % s->stride != 0) continue;
+                for (int kx = 0; kx < s->KW; ++kx) {
+                    if ((px + s->pad - kx * s->dil) % s->stride != 0) continue;
+                    p.tapmask |= (unsigned long long)(ky * s->KW + kx) << (4 * p.ntaps);
+                    ++p.ntaps;
+                }
+            }
+            if (p.ntaps == 0 && p.accumulate) continue;
+            p.M = s->N * p.Hs * p.Ws;
+            if (p.Cout % 128 == 0) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            else conv_bf16_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);
+        }
+    }
+    return uem_check_launch("conv2d_bf16 (dgrad)");
 }
