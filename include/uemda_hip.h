@@ -303,6 +303,10 @@ int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n,
  *   output channels % 64 == 0.                                                                                     */
 int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags,
                     float* tile_stats, void* stream);
+/* dw[o][tap][i] (fp32, the gradient arena) += sum_m dY[m][o] * x[m'(m,tap)][i] with bf16 x and dY: 1x1 layers (stride 1; stride
+ * 2 on output rows that are a multiple of 32 pixels) and 3x3 layers (stride 1 dilation 1 / 2, stride 2) on such rows;
+ * channel counts % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise).                                                          */
+int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, const uem_conv_shape* s, void* stream);
 
 /* ---- data parallel (new relative to the reference, which is single-GPU: SURVEY 2a, 8e) --------------------------
  * all-reduce(sum, in place) of a flat fp32 buffer -- the gradient arena, 98 MB for R50-ASPP -- over RCCL on `stream`:

@@ -66,3 +66,36 @@ def test_conv_bf16_forward_and_data_gradient(case):
     wt = w.permute(1, 2, 3, 0).contiguous().cuda()                     # (Cin, KH, KW, Cout)
     dx = ops_bf16.conv2d_dgrad(_nhwc(gy), wt, (N, H, W, Cin), stride=s, pad=p, dil=d)
     _close_bf16(dx.permute(0, 3, 1, 2), x64.grad, "data gradient")
+
+
+WGRAD_CASES = [
+    # N, H, W, Cin, Cout, k, stride, dil
+    (2, 16, 32, 128, 128, 3, 1, 1),
+    (2, 16, 64, 64, 64, 3, 1, 1),
+    (1, 20, 32, 128, 64, 3, 1, 2),
+    (2, 24, 64, 64, 128, 3, 2, 1),
+    (3, 7, 9, 256, 128, 1, 1, 1),            # ragged last step
+    (2, 16, 16, 64, 256, 1, 1, 1),
+    (2, 16, 64, 128, 256, 1, 2, 1),
+    (8, 32, 32, 128, 128, 3, 1, 1),          # several pixel slices per tile (split-K), both stages
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_bf16_vs_fp64(case):
+    from uemda_amd import ops_bf16
+    N, H, W, Cin, Cout, k, s, d = case
+    pad = d * (k - 1) // 2
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, stride=s, padding=pad, dilation=d)
+    gy = _bf(torch.randn(y.shape, generator=g))
+    y.backward(gy.double())
+    dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+    ops_bf16.conv2d_wgrad(_nhwc(x), _nhwc(gy), dw, stride=s, pad=pad, dil=d)
+    ref = w.grad.permute(0, 2, 3, 1)
+    err = float((dw.double().cpu() - ref).norm() / ref.norm())
+    assert err < 2e-6, err                                             # exact bf16 products, fp32 accumulation order only
+    ops_bf16.conv2d_wgrad(_nhwc(x), _nhwc(gy), dw, stride=s, pad=pad, dil=d)       # accumulates
+    assert float((dw.double().cpu() - 2 * ref).norm() / ref.norm()) < 4e-6

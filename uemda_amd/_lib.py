@@ -97,6 +97,7 @@ SIGNATURES = {
     "uem_coral_finish": [P, P, P, P, I, I, I, P, P, P, P, P],
     "uem_negate": [P, P, I, P],
     "uem_conv2d_bf16": [P, P, P, POINTER(ConvShape), I, P, P],
+    "uem_conv2d_wgrad_bf16": [P, P, P, POINTER(ConvShape), P],
     "uem_comm_unique_id": [P],
     "uem_comm_init": [POINTER(c_void_p), P, I, I],
     "uem_allreduce_flat": [P, P, L, P],

@@ -260,6 +260,213 @@ __global__ __launch_bounds__(256, (WgCfg<BK, TM, TN, NTAP, S, D, AFFINE, LINEAR>
     }
 }
 
+// =========================================================================================================
+// bf16-STORAGE weight gradient (BASELINE config 5): x and dY are bf16 in HBM, dW accumulates in fp32 (split-K atomics into
+// the fp32 gradient arena, as above).  Same step structure (LDS-DMA, two stages, one barrier per 32-pixel step, three taps
+// of a filter row per block on 3x3 layers); there is no operand prologue on the bf16 path (activations are materialised).
+// The reduction index is the pixel while a staged row is a pixel's channels, so the MFMA operands -- 8 consecutive pixels
+// of one channel per lane -- come out of the k-major image by the hardware transposing read ds_read_b64_tr_b16.  Rows are
+// unpadded (the DMA writes linearly): the 16-byte chunks of a row are XOR-swizzled on the SOURCE address and on the read
+// so that the 32 eight-byte pieces of one read instruction (4 pixel rows x 2 channel halves x 4 pieces) fall on 32
+// different 8-byte slots of the 256-byte bank row.
+// =========================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int T>                                                            // T = channels per staged row
+__device__ __forceinline__ int wgb_swz(const int row) {
+    constexpr int RPB = 128 / T > 1 ? 128 / T : 1;                          // rows per 256-byte bank row (T=128: 1, T=64: 2)
+    return ((row / RPB) & (4 / RPB - 1)) << 2;                              // XOR on the 16-byte chunk index
+}
+// operand fragment of v_mfma_f32_32x32x16_bf16 for the 32 channels at ch0 and the 8 pixels whose staged rows are
+// row0, row0 + rs, ..., row0 + 7*rs (row0 already carries the lane half's +8 pixels)
+template <int T>
+__device__ __forceinline__ bf16x8 wgb_frag(const unsigned short* img, const int row0, const int rs, const int ch0, const int lane) {
+    const int q = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
+    const int chunk = (ch0 >> 3) + 2 * g16 + (pp >> 1);
+    const int r0 = row0 + q * rs, r1 = r0 + 4 * rs;
+    const unsigned short* a0 = img + r0 * T + ((chunk ^ wgb_swz<T>(r0)) << 3) + ((pp & 1) << 2);
+    const unsigned short* a1 = img + r1 * T + ((chunk ^ wgb_swz<T>(r1)) << 3) + ((pp & 1) << 2);
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int TM, int TN, int NTAP, int S, int D>
+struct WgbCfg {
+    static constexpr int BK = 32;
+    static constexpr int MT = TM / 64, NT = TN / 64;
+    static constexpr int XR = NTAP == 1 ? BK : (BK - 1) * S + 2 * D + 1;
+    static constexpr int RPI_D = 512 / TM, RPI_X = 512 / TN;               // rows per 1-KiB wave instruction
+    static constexpr int XROWS = (XR + 4 * RPI_X - 1) / (4 * RPI_X) * (4 * RPI_X);
+    static constexpr int D_IPW = BK / (4 * RPI_D) > 0 ? BK / (4 * RPI_D) : 1;
+    static constexpr int X_IPW = XROWS / (4 * RPI_X);
+    static constexpr int D_ELEMS = (BK > 4 * RPI_D ? BK : 4 * RPI_D) * TM, X_ELEMS = XROWS * TN;
+    static constexpr int STAGE_ELEMS = D_ELEMS + X_ELEMS + 8;              // + the row flag
+    static constexpr int LDS_BYTES = 2 * STAGE_ELEMS * 2;
+    static constexpr int ACC = NTAP * MT * NT * 16;
+    static constexpr int BPC = ACC <= 64 ? 3 : 2;
+};
+
+template <int TM, int TN, int NTAP, int S, int D, bool LINEAR>
+__global__ __launch_bounds__(256, (WgbCfg<TM, TN, NTAP, S, D>::BPC)) void wgrad_bf16_kernel(const WgP p) {
+    using C = WgbCfg<TM, TN, NTAP, S, D>;
+    constexpr int MT = C::MT, NT = C::NT, BK = C::BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rows_k = NTAP == 3 ? p.KH : 1;
+    const int ntiles = p.tiles_co * p.tiles_ci * rows_k;
+    const int nwg = gridDim.x;
+    int lin;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int split = lin / ntiles;
+    int t_ = lin - split * ntiles;
+    const int ci_t = t_ % p.tiles_ci; t_ /= p.tiles_ci;
+    const int ky = t_ % rows_k;
+    const int co_t = t_ / rows_k;
+    const int co0 = co_t * TM, ci0 = ci_t * TN;
+    const int q_beg = split * p.steps_per_split;
+    const int q_end = min(p.steps_total, q_beg + p.steps_per_split);
+    const int T = q_end - q_beg;
+    const i32x4 rs_d = wg_rsrc(p.dy, p.dy_bytes), rs_x = wg_rsrc(p.x, p.x_bytes);
+
+    // per-lane constants of the DMA pattern: lane -> (staged row, 16-byte chunk); the SOURCE chunk is the swizzled one
+    unsigned dconst[C::D_IPW], xconst[C::X_IPW];
+    int drow[C::D_IPW], xrow[C::X_IPW];
+#pragma unroll
+    for (int j = 0; j < C::D_IPW; ++j) {
+        const int e = ((j * 4 + wave) * 64 + lane) * 8;
+        drow[j] = e / TM;
+        const int chunk = (e % TM) >> 3;
+        dconst[j] = (unsigned)((drow[j] * p.dy_ld + co0 + ((chunk ^ wgb_swz<TM>(drow[j])) << 3)) * 2);
+    }
+    constexpr int SX = NTAP == 3 ? 1 : S;
+#pragma unroll
+    for (int j = 0; j < C::X_IPW; ++j) {
+        const int e = ((j * 4 + wave) * 64 + lane) * 8;
+        xrow[j] = e / TN;
+        const int chunk = (e % TN) >> 3;
+        xconst[j] = (unsigned)((xrow[j] * SX * p.x_ld + ci0 + ((chunk ^ wgb_swz<TN>(xrow[j])) << 3)) * 2);
+    }
+    const int chunks = LINEAR ? 1 : p.Wo / BK;
+    int qi = q_beg, in_ = 0, ioy = 0, ixc = 0;
+    if (!LINEAR) {
+        const int rowid = q_beg / chunks;
+        ixc = q_beg - rowid * chunks;
+        in_ = rowid / p.Ho;
+        ioy = rowid - in_ * p.Ho;
+    }
+    f32x16 acc[NTAP][MT][NT];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    auto step = [&](unsigned short* __restrict__ fill, const unsigned short* __restrict__ use, const bool do_issue, const bool do_phase) {
+        if (do_issue) {
+            unsigned short* const Ds = fill;
+            unsigned short* const Xs = fill + C::D_ELEMS;
+            unsigned short* const Fl = Xs + C::X_ELEMS;
+            const unsigned dbase = (unsigned)qi * (unsigned)(BK * 2) * (unsigned)p.dy_ld;
+#pragma unroll
+            for (int j = 0; j < C::D_IPW; ++j)
+                uem_raw_buffer_load_lds(rs_d, (lds_u32p)(Ds + (j * 4 + wave) * 512), 16,
+                                        (int)(drow[j] < BK ? dconst[j] + dbase : WG_OOB), 0, 0, 0);
+            if (LINEAR) {
+                const unsigned xbase = (unsigned)qi * (unsigned)(BK * 2) * (unsigned)p.x_ld;
+#pragma unroll
+                for (int j = 0; j < C::X_IPW; ++j)
+                    uem_raw_buffer_load_lds(rs_x, (lds_u32p)(Xs + (j * 4 + wave) * 512), 16,
+                                            (int)(xrow[j] < C::XR ? xconst[j] + xbase : WG_OOB), 0, 0, 0);
+            } else {
+                const int iy = ioy * S - p.pad + ky * D;
+                const int ix0 = ixc * (BK * S) - p.pad;
+                const bool rowok = iy >= 0 && iy < p.H && in_ < p.N;
+                const unsigned xbase = (unsigned)(((in_ * p.H + iy) * p.W + ix0) * p.x_ld) * 2u;
+#pragma unroll
+                for (int j = 0; j < C::X_IPW; ++j) {
+                    const int ix = ix0 + xrow[j] * SX;
+                    const bool ok = rowok && ix >= 0 && ix < p.W && xrow[j] < C::XR;
+                    uem_raw_buffer_load_lds(rs_x, (lds_u32p)(Xs + (j * 4 + wave) * 512), 16, (int)(ok ? xconst[j] + xbase : WG_OOB), 0, 0, 0);
+                }
+                if (NTAP == 3 && tid == 0) Fl[0] = rowok ? 1 : 0;
+                if (++ixc == chunks) { ixc = 0; if (++ioy == p.Ho) { ioy = 0; ++in_; } }
+            }
+            ++qi;
+        }
+        if (!do_phase) return;
+        const unsigned short* const Ds = use;
+        const unsigned short* const Xs = use + C::D_ELEMS;
+        const unsigned short* const Fl = Xs + C::X_ELEMS;
+        if (NTAP == 3) {
+            if (__builtin_amdgcn_readfirstlane((int)Fl[0]) == 0) return;  // filter row in the padding for this output row
+        }
+        constexpr int RS = NTAP == 3 ? S : 1;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int k0 = ks * 16 + 8 * fh;                               // this lane half's 8 pixels of the MFMA step
+            bf16x8 a[MT], b[NTAP][NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = wgb_frag<TM>(Ds, k0, 1, wm + i * 32, lane);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[t][j] = wgb_frag<TN>(Xs, k0 * RS + t * D, RS, wn + j * 32, lane);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[t][j], acc[t][i][j], 0, 0, 0);
+        }
+    };
+#define WG_SYNC()                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                   \
+    asm volatile("" ::: "memory")
+    if (T > 0) {
+        unsigned short* const st0 = lds16;
+        unsigned short* const st1 = lds16 + C::STAGE_ELEMS;
+        step(st0, st1, true, false);
+        for (int t = 0; t < T; t += 2) {
+            WG_SYNC();
+            step(st1, st0, t + 1 < T, true);
+            if (t + 1 >= T) break;
+            WG_SYNC();
+            step(st0, st1, t + 2 < T, true);
+        }
+    }
+#undef WG_SYNC
+    const size_t row_ld = (size_t)p.KH * p.KW * p.Cin;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int tap = NTAP == 3 ? ky * p.KW + t : 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float* base = p.dw + (size_t)tap * p.Cin + (ci0 + wn + j * 32 + fr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    atomicAdd(base + (size_t)co * row_ld, acc[t][i][j][r]);
+                }
+            }
+    }
+}
+
 // tuning overrides (scripts/sweep_wgrad.py): tile TM x TN (0 = rule below), split-K rounds (0 = rule)
 static int g_tm = 0, g_tn = 0, g_rounds = 0, g_bk = 0;
 extern "C" void uemdbg_wgrad_config(int tm, int tn, int rounds, int bk) { g_tm = tm; g_tn = tn; g_rounds = rounds; g_bk = bk; }
@@ -359,4 +566,62 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
     else if (n128) ok = wg_dispatch<32, 64, 128>(p, s, affine, st);
     else ok = wg_dispatch<32, 64, 64>(p, s, affine, st);
     return ok ? 1 : 0;
+}
+
+// ---- bf16-storage weight gradient: launcher ------------------------------------------------------------------
+template <int TM, int TN, int NTAP, int S, int D, bool LINEAR>
+static void wgb_go(WgP p, hipStream_t st) {
+    using C = WgbCfg<TM, TN, NTAP, S, D>;
+    p.tiles_co = p.Cout / TM;
+    p.tiles_ci = p.Cin / TN;
+    const int tiles = p.tiles_co * p.tiles_ci * (NTAP == 3 ? p.KH : 1);
+    p.steps_total = (int)uem_cdiv(p.M, C::BK);
+    const int slots = 256 * C::BPC;
+    const int max_splits = (int)uem_cdiv(p.steps_total, 8);
+    int splits = 1;
+    double best_fill = -1.0;
+    for (int r = 1; r <= 3; ++r) {
+        int sp = slots * r / tiles;
+        if (sp > max_splits) sp = max_splits;
+        if (sp < 1) sp = 1;
+        const double fill = (double)tiles * sp / ((double)slots * uem_cdiv((int64_t)tiles * sp, slots));
+        if (fill > best_fill + 1e-9) { best_fill = fill; splits = sp; }
+        if (fill >= 0.97) break;
+    }
+    p.steps_per_split = (int)uem_cdiv(p.steps_total, splits);
+    splits = (int)uem_cdiv(p.steps_total, p.steps_per_split);
+    const unsigned grid = (unsigned)tiles * (unsigned)splits;
+    auto k = wgrad_bf16_kernel<TM, TN, NTAP, S, D, LINEAR>;
+    static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
+    (void)attr;
+    k<<<grid, 256, C::LDS_BYTES, st>>>(p);
+}
+template <int TM, int TN>
+static bool wgb_dispatch(const WgP& p, const uem_conv_shape* s, hipStream_t st) {
+    if (s->KH == 1 && s->KW == 1 && s->pad == 0) {
+        if (s->stride == 1) { wgb_go<TM, TN, 1, 1, 0, true>(p, st); return true; }
+        if (s->stride == 2 && s->Wo % 32 == 0) { wgb_go<TM, TN, 1, 2, 0, false>(p, st); return true; }
+        return false;
+    }
+    if (s->KH == 3 && s->KW == 3 && s->Wo % 32 == 0) {
+        if (s->stride == 1 && s->dil == 1) { wgb_go<TM, TN, 3, 1, 1, false>(p, st); return true; }
+        if (s->stride == 1 && s->dil == 2) { wgb_go<TM, TN, 3, 1, 2, false>(p, st); return true; }
+        if (s->stride == 2 && s->dil == 1) { wgb_go<TM, TN, 3, 2, 1, false>(p, st); return true; }
+    }
+    return false;
+}
+extern "C" int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, const uem_conv_shape* s, void* stream) {
+    UEM_REQUIRE(x && dy && dw && s, "conv2d_wgrad_bf16: null pointer");
+    if (s->Cout % 64 != 0 || s->Cin % 64 != 0 || s->x_ld % 8 != 0 || s->y_ld % 8 != 0 || (((uintptr_t)x | (uintptr_t)dy) & 15))
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_wgrad_bf16: needs channel counts %% 64 == 0 and 16-byte rows");
+    const double xb = (double)s->N * s->H * s->W * s->x_ld * 2.0, db = (double)s->N * s->Ho * s->Wo * s->y_ld * 2.0;
+    if (xb >= 4294967280.0 || db >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_wgrad_bf16: tensor beyond 32-bit buffer offsets");
+    WgP p;
+    p.x = (const float*)x; p.dy = (const float*)dy; p.in_scale = p.in_shift = nullptr; p.dw = dw;
+    p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
+    p.KH = s->KH; p.KW = s->KW; p.pad = s->pad; p.x_ld = s->x_ld; p.dy_ld = s->y_ld;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    const bool ok = s->Cout % 128 == 0 ? wgb_dispatch<128, 64>(p, s, (hipStream_t)stream) : wgb_dispatch<64, 64>(p, s, (hipStream_t)stream);
+    if (!ok) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_wgrad_bf16: 1x1 (stride 1, or 2 with rows of 32 pixels) and 3x3 on rows of 32 pixels only");
+    return uem_check_launch("conv2d_wgrad_bf16");
 }

@@ -55,3 +55,20 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     ops.PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_bf16", ptr(dy), ptr(w_t), ptr(out), ctypes.byref(s),
                                                    CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0), None, stream()))
     return out
+
+
+def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1):
+    """dw (Cout,KH,KW,Cin) fp32 += dy^T * im2col(x) with bf16 x (N,H,W,Cin) and dy (N,Ho,Wo,Cout)."""
+    need_gpu(x, dy, dw_ohwi)
+    _bf16c(x, "wgrad_bf16 x"), _bf16c(dy, "wgrad_bf16 dy")
+    if dw_ohwi.dtype != torch.float32 or not dw_ohwi.is_contiguous():
+        raise UemError("wgrad_bf16: dw must be a contiguous float32 tensor")
+    cout, kh, kw, cin = dw_ohwi.shape
+    n, h, w, _ = x.shape
+    s = ConvShape()
+    s.N, s.H, s.W, s.Cin = n, h, w, cin
+    s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], cout
+    s.KH, s.KW, s.stride, s.pad, s.dil = kh, kw, stride, pad, dil
+    s.x_ld, s.y_ld = cin, cout
+    flops = 2.0 * n * s.Ho * s.Wo * cout * kh * kw * cin
+    ops.PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad_bf16", ptr(x), ptr(dy), ptr(dw_ohwi), ctypes.byref(s), stream()))
