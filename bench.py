@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--conv-prec", default="fp32", choices=["fp32", "mixed", "bf16x3", "bf16"],
                     help="matrix-core operand precision of the convolutions (fp32 = exact f32 MFMA, the parity default)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: activations / weight copies of the encoder stored in bf16, bf16 matrix cores (BASELINE config 5)")
     ap.add_argument("--no-other-precisions", action="store_true",
                     help="skip the short extra legs that time the same step in the two opt-in precisions (N=1 only)")
     args = ap.parse_args()
@@ -128,7 +130,7 @@ def main():
     cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
                cascade=False, use_ppm=(args.head == "ppm"), ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
                inchannels=2048, num_classes=C, is_ins_norm=True)
-    model = Deeplabv2(cfg).cuda()                 # random init of the reference's architecture (no checkpoints)
+    model = Deeplabv2(cfg).cuda().set_storage(args.storage)   # random init of the reference's architecture (no checkpoints)
     wrapper = udp.DataParallel(model, overlap=not args.no_overlap) if (world > 1 or udp.FORCE) else None
     # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
     data_rank = rank if args.data_rank is None else args.data_rank
@@ -217,7 +219,7 @@ def main():
     value = tiles_per_step * args.steps / elapsed
 
     others = None
-    if world == 1 and not args.no_other_precisions:
+    if world == 1 and not args.no_other_precisions and args.storage == "fp32":
         # the same step in the other matrix-core precisions (2 untimed + 3 timed steps each); `value` above is untouched
         others = {}
         for prec in ("fp32", "mixed", "bf16x3", "bf16"):
@@ -238,7 +240,7 @@ def main():
                 others[prec] = dict(error=repr(e)[:200])
         ops.set_conv_precision(args.conv_prec)
 
-    peak = BF16_MATRIX_PEAK_TFLOPS if args.conv_prec == "bf16" else F32_MATRIX_PEAK_TFLOPS
+    peak = BF16_MATRIX_PEAK_TFLOPS if (args.conv_prec == "bf16" or args.storage == "bf16") else F32_MATRIX_PEAK_TFLOPS
     prec_text = {"fp32": "fp32 (f32 MFMA)", "bf16x3": "fp32 storage, 3xbf16 split MFMA with fp32 accumulate",
                  "mixed": "fp32 (f32 MFMA) forward, 3xbf16 split MFMA data/weight gradients",
                  "bf16": "fp32 storage, bf16 MFMA operands with fp32 accumulate"}[args.conv_prec]
@@ -252,7 +254,7 @@ def main():
             # configuration they were collected on: any other run reports null
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}"
+            key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}" + ("" if args.storage == "fp32" else " storage=bf16")
             if os.path.exists(tfile):
                 tj = json.load(open(tfile))
                 if tj.get("config") == key:
@@ -273,10 +275,10 @@ def main():
             "metric": metric,
             "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "mixed": "f32 fwd / 3xbf16 split bwd", "bf16x3": "f32 (3xbf16 split)", "bf16": "bf16"}[args.conv_prec],
+            "vs_baseline": None, "dtype": "bf16 storage (fp32 accumulate / statistics / master weights)" if args.storage == "bf16" else {"fp32": "f32", "mixed": "f32 fwd / 3xbf16 split bwd", "bf16x3": "f32 (3xbf16 split)", "bf16": "bf16"}[args.conv_prec],
             "data": "synthetic",
             "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
-                                   f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text}, "
+                                   f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text if args.storage == 'fp32' else 'bf16 storage in the encoder (bf16 MFMA, fp32 accumulate)'}, "
                                    f"random init; tiles counted = source + target; the batch repeats {min(B, 4)} unique seeded "
                                    f"tiles x{rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
                                    f"events (660 event records: about 1 ms of command-processor bubbles)",

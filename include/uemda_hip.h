@@ -307,6 +307,25 @@ int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem
  * 2 on output rows that are a multiple of 32 pixels) and 3x3 layers (stride 1 dilation 1 / 2, stride 2) on such rows;
  * channel counts % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise).                                                          */
 int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, float* dw, const uem_conv_shape* s, void* stream);
+/* BatchNorm / residual passes on bf16 tensors (statistics, scale / shift, gradients of gamma / beta stay fp32):
+ * the bf16 twins of uem_affine_act (relu(bn(z)) materialised for the next conv; with `res` the block output and its packed
+ * ReLU bits), uem_bn_bwd_reduce and uem_bn_bwd_apply.  relu: 0 = none, 1 = mask recomputed from x*scale+shift > 0 (pass no
+ * bits), UEM_RELU_BITS = packed output mask of uem_affine_act_bf16.                        _resnets.py:96-112          */
+int uem_affine_act_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* res /* may be NULL */,
+                        const float* res_scale, const float* res_shift, uint16_t* y, int64_t M, int C, int relu,
+                        uint32_t* relu_bits /* may be NULL */, void* stream);
+int uem_bn_bwd_reduce_bf16(const uint16_t* x, const uint16_t* dy, const uint32_t* relu_bits, const float* scale,
+                           const float* shift, const float* save_mean, const float* save_invstd, int M, int C, int relu,
+                           float* dgamma, float* dbeta, float* grad_gamma /* += */, float* grad_beta /* += */,
+                           float* workspace /* uem_bn_workspace_floats(M,C) */, void* stream);
+int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, const uint32_t* relu_bits, const float* scale,
+                          const float* shift, const float* save_mean, const float* save_invstd, const float* dgamma,
+                          const float* dbeta, int M, int C, int relu, uint16_t* dx, uint16_t* dres /* dy*mask, may be NULL */,
+                          void* stream);
+/* fp32 <-> bf16 (round to nearest even): the bf16 copy of the fp32 master weights after every optimizer step, and the two
+ * ends of the bf16-storage region of the network (max-pool output in, layer4 output out).                             */
+int uem_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream);
 
 /* ---- data parallel (new relative to the reference, which is single-GPU: SURVEY 2a, 8e) --------------------------
  * all-reduce(sum, in place) of a flat fp32 buffer -- the gradient arena, 98 MB for R50-ASPP -- over RCCL on `stream`:

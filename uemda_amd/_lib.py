@@ -98,6 +98,11 @@ SIGNATURES = {
     "uem_negate": [P, P, I, P],
     "uem_conv2d_bf16": [P, P, P, POINTER(ConvShape), I, P, P],
     "uem_conv2d_wgrad_bf16": [P, P, P, POINTER(ConvShape), P],
+    "uem_affine_act_bf16": [P, P, P, P, P, P, P, L, I, I, P, P],
+    "uem_bn_bwd_reduce_bf16": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
+    "uem_bn_bwd_apply_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, P, P, P],
+    "uem_cast_f32_bf16": [P, P, L, P],
+    "uem_cast_bf16_f32": [P, P, L, P],
     "uem_comm_unique_id": [P],
     "uem_comm_init": [POINTER(c_void_p), P, I, I],
     "uem_allreduce_flat": [P, P, L, P],

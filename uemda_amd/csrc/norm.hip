@@ -40,6 +40,28 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// storage types: float (default) or bf16 bits (unsigned short; BASELINE config 5's bf16-storage path).  4 channels
+// per access either way; arithmetic is always fp32.
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned short bf16_t;
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned f2bf_bits(float f) {                   // round to nearest even; NaN stays NaN
+    const __bf16 b = (__bf16)f;
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f2bf_bits(v.x) | (f2bf_bits(v.y) << 16), f2bf_bits(v.z) | (f2bf_bits(v.w) << 16));
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // BatchNorm statistics (training mode)
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int M, int C, int ld,
@@ -237,22 +259,23 @@ extern "C" int uem_bn_eval_affine(const float* gamma, const float* beta, const f
 // ---------------------------------------------------------------------------------------------------------
 // y = act(x*scale + shift (+ res))
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const float* __restrict__ res,
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res,
                                                          const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                         float* __restrict__ y, int64_t nvec, int C, int relu,
+                                                         T* __restrict__ y, int64_t nvec, int C, int relu,
                                                          uint32_t* __restrict__ bits) {
     // `bits` (optional; needs nvec % 8 == 0): one bit per element, bit (e & 31) of word e >> 5 = [y_e > 0].  The
     // backward passes read these 1/32-size words instead of the materialised output.
     const int64_t nloop = bits ? (nvec + 7) / 8 * 8 : nvec;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nloop; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
-        float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 v = ld4<T>(x + i * 4);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
         const float4 sh = *reinterpret_cast<const float4*>(shift + c);
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         if (res) {
-            float4 r = reinterpret_cast<const float4*>(res)[i];
+            float4 r = ld4<T>(res + i * 4);
             if (rscale) {
                 const float4 rs = *reinterpret_cast<const float4*>(rscale + c);
                 const float4 rt = *reinterpret_cast<const float4*>(rshift + c);
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        reinterpret_cast<float4*>(y)[i] = v;
+        st4<T>(y + i * 4, v);
         if (bits) {
             // 8 consecutive lanes hold the 32 elements of one word (i is lane-aligned: grid stride is a multiple of 256)
             uint32_t m = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
@@ -280,8 +303,18 @@ extern "C" int uem_affine_act(const float* x, const float* scale, const float* s
     UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act: relu_bits needs C %% 32 == 0 (C=%d)", C);
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act: bad residual affine");
     const int64_t nvec = M * C / 4;
-    affine_act_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    affine_act_kernel<float><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     return uem_check_launch("affine_act");
+}
+extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* res,
+                                   const float* res_scale, const float* res_shift, uint16_t* y, int64_t M, int C, int relu,
+                                   uint32_t* relu_bits, void* stream) {
+    UEM_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && (C % 4) == 0, "affine_act_bf16: bad arguments");
+    UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act_bf16: relu_bits needs C %% 32 == 0 (C=%d)", C);
+    UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act_bf16: bad residual affine");
+    const int64_t nvec = M * C / 4;
+    affine_act_kernel<bf16_t><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    return uem_check_launch("affine_act_bf16");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -303,7 +336,8 @@ __device__ __forceinline__ float4 relu_mask4(float4 dy, float4 x, float4 sc, flo
     dy.z = pre.z > 0.f ? dy.z : 0.f; dy.w = pre.w > 0.f ? dy.w : 0.f;
     return dy;
 }
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                              const float* __restrict__ res, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ smean,
                                                              const float* __restrict__ sinv, int M, int C, int relu,
@@ -318,8 +352,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
     for (int r = r0 + cm.rg; r < r1; r += cm.rpp) {
         const size_t off = (size_t)r * C + cm.c0;
-        const float4 xv = *reinterpret_cast<const float4*>(x + off);
-        float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 xv = ld4<T>(x + off);
+        float4 d = ld4<T>(dy + off);
         if (relu) d = relu_mask4(d, xv, sc, sh, res, off, relu);
         sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
         sg.x += d.x * ((xv.x - mu.x) * is.x); sg.y += d.y * ((xv.y - mu.y) * is.y);
@@ -391,24 +425,40 @@ extern "C" int uem_bn_bwd_reduce(const float* x, const float* dy, const void* ym
     int chunks, rpc;
     col_chunks(M, C, &chunks, &rpc);
     dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
-    bn_bwd_partial_kernel<<<grid, 256, 0, st>>>(x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
+    bn_bwd_partial_kernel<float><<<grid, 256, 0, st>>>(x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
     bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta, grad_gamma, grad_beta);
     return uem_check_launch("bn_bwd_reduce");
 }
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+extern "C" int uem_bn_bwd_reduce_bf16(const uint16_t* x, const uint16_t* dy, const uint32_t* relu_bits, const float* scale,
+                                      const float* shift, const float* save_mean, const float* save_invstd, int M, int C, int relu,
+                                      float* dgamma, float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
+    UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce_bf16: null pointer");
+    UEM_REQUIRE(M > 0 && col_shape_ok(C), "bn_bwd_reduce_bf16: unsupported shape M=%d C=%d", M, C);
+    UEM_REQUIRE(relu == 0 || relu == 1 || (relu == UEM_RELU_BITS && relu_bits && C % 32 == 0), "bn_bwd_reduce_bf16: relu is 0, 1 (mask recomputed from x) or UEM_RELU_BITS");
+    UEM_REQUIRE(relu != 1 || relu_bits == nullptr, "bn_bwd_reduce_bf16: relu = 1 recomputes the mask, pass no bits");
+    hipStream_t st = (hipStream_t)stream;
+    int chunks, rpc;
+    col_chunks(M, C, &chunks, &rpc);
+    dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
+    bn_bwd_partial_kernel<bf16_t><<<grid, 256, 0, st>>>(x, dy, (const float*)relu_bits, scale, shift, save_mean, save_invstd, M, C, relu, rpc, workspace);
+    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta, grad_gamma, grad_beta);
+    return uem_check_launch("bn_bwd_reduce_bf16");
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const float* __restrict__ res, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ smean,
                                                            const float* __restrict__ sinv, const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, int64_t nvec, int C, float invM,
-                                                           int relu, float* __restrict__ dx, float* __restrict__ dres) {
+                                                           int relu, T* __restrict__ dx, T* __restrict__ dres) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
         const size_t off = (size_t)i * 4;
-        const float4 xv = *reinterpret_cast<const float4*>(x + off);
-        float4 d = *reinterpret_cast<const float4*>(dy + off);
+        const float4 xv = ld4<T>(x + off);
+        float4 d = ld4<T>(dy + off);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
         if (relu) d = relu_mask4(d, xv, sc, *reinterpret_cast<const float4*>(shift + c), res, off, relu);
-        if (dres) *reinterpret_cast<float4*>(dres + off) = d;
+        if (dres) st4<T>(dres + off, d);
         const float4 mu = *reinterpret_cast<const float4*>(smean + c);
         const float4 is = *reinterpret_cast<const float4*>(sinv + c);
         const float4 dg = *reinterpret_cast<const float4*>(dgamma + c);
@@ -418,7 +468,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         o.y = sc.y * (d.y - db.y * invM - ((xv.y - mu.y) * is.y) * (dg.y * invM));
         o.z = sc.z * (d.z - db.z * invM - ((xv.z - mu.z) * is.z) * (dg.z * invM));
         o.w = sc.w * (d.w - db.w * invM - ((xv.w - mu.w) * is.w) * (dg.w * invM));
-        *reinterpret_cast<float4*>(dx + off) = o;
+        st4<T>(dx + off, o);
     }
 }
 extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
@@ -428,9 +478,42 @@ extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* yma
     UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad shape");
     UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "bn_bwd_apply: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = (int64_t)M * C / 4;
-    bn_bwd_apply_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
+    bn_bwd_apply_kernel<float><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
         x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
     return uem_check_launch("bn_bwd_apply");
+}
+extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, const uint32_t* relu_bits, const float* scale,
+                                     const float* shift, const float* save_mean, const float* save_invstd, const float* dgamma,
+                                     const float* dbeta, int M, int C, int relu, uint16_t* dx, uint16_t* dres, void* stream) {
+    UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && dx, "bn_bwd_apply_bf16: null pointer");
+    UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply_bf16: bad shape");
+    UEM_REQUIRE(relu == 0 || (relu == 1 && !relu_bits) || (relu == UEM_RELU_BITS && relu_bits && C % 32 == 0), "bn_bwd_apply_bf16: bad relu mode");
+    const int64_t nvec = (int64_t)M * C / 4;
+    bn_bwd_apply_kernel<bf16_t><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
+        x, dy, (const float*)relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
+    return uem_check_launch("bn_bwd_apply_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 <-> bf16 (round to nearest even): the weight arena's bf16 copy, and the two ends of the bf16-storage region
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t nvec, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) st4<bf16_t>(y + i * 4, ld4<float>(x + i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const int64_t i = (n & ~(int64_t)3) + threadIdx.x; y[i] = (bf16_t)f2bf_bits(x[i]); }
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t nvec, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) st4<float>(y + i * 4, ld4<bf16_t>(x + i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const int64_t i = (n & ~(int64_t)3) + threadIdx.x; y[i] = __uint_as_float((unsigned)x[i] << 16); }
+}
+extern "C" int uem_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
+    UEM_REQUIRE(x && y && n > 0 && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 7) == 0), "cast_f32_bf16: bad arguments");
+    cast_f32_bf16_kernel<<<uem_stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, n);
+    return uem_check_launch("cast_f32_bf16");
+}
+extern "C" int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream) {
+    UEM_REQUIRE(x && y && n > 0 && (((uintptr_t)x & 7) == 0) && (((uintptr_t)y & 15) == 0), "cast_bf16_f32: bad arguments");
+    cast_bf16_f32_kernel<<<uem_stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, n);
+    return uem_check_launch("cast_bf16_f32");
 }
 __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ res, const float* __restrict__ scale,

@@ -142,6 +142,14 @@ class Deeplabv2(nn.Module):
     def flat_parameters(self):
         return self._arena, self._grad_arena, self._n_params
 
+    def set_storage(self, storage):
+        """"fp32" (default: the reference's arithmetic, every parity statement) or "bf16" (BASELINE config 5: bf16
+        activations + bf16 copies of the fp32 master weights inside the encoder, bf16 matrix cores; training mode)."""
+        if storage not in ("fp32", "bf16"):
+            raise UemError(f"storage must be 'fp32' or 'bf16', got {storage!r}")
+        self.encoder.storage = storage
+        return self
+
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient arena (one memset) and keep every .grad attached to it."""
         if self._grad_arena is None:

@@ -47,6 +47,9 @@ class Bottleneck(nn.Module):
             ops.nbt_inc(bn)
 
     def forward(self, x):                      # x: (N,H,W,C) dense NHWC
+        if x.dtype == torch.bfloat16:           # bf16-storage region (ResNetEncoder.storage = "bf16", BASELINE config 5)
+            from .models.blocks_bf16 import BottleneckBf16Fn
+            return BottleneckBf16Fn.apply(x, self, *list(self.parameters()))
         return blocks.BottleneckFn.apply(x, self, *list(self.parameters()))
 
 
@@ -123,15 +126,25 @@ class ResNetEncoder(nn.Module):
                 m.dilation = (dilate, dilate)
                 m.padding = (dilate, dilate)
 
+    # "fp32" (default, the parity path) or "bf16": activations between the max-pool and the layer4 output stored in bf16,
+    # bf16 matrix cores with fp32 accumulation, fp32 master weights (BASELINE config 5; training mode only)
+    storage = "fp32"
+
     def forward_nhwc(self, x):
         r = self.resnet
         params = [r.conv1.weight, r.bn1.weight, r.bn1.bias]
         y = blocks.StemFn.apply(x, r, *params)
+        bf16 = self.storage == "bf16" and self.training
+        if bf16:
+            from .models.blocks_bf16 import CastFn
+            y = CastFn.apply(y, True)
         outs = []
         for layer in (r.layer1, r.layer2, r.layer3, r.layer4):
             for blk in layer:
                 y = blk(y)
             outs.append(y)
+        if bf16:
+            outs[-1] = CastFn.apply(outs[-1], False)       # InstanceNorm and the heads stay fp32
         return outs
 
     def forward(self, inputs):                                                  # resnet.py:140-166
