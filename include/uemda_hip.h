@@ -324,6 +324,8 @@ int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, const uint32_t*
                           void* stream);
 /* fp32 <-> bf16 (round to nearest even): the bf16 copy of the fp32 master weights after every optimizer step, and the two
  * ends of the bf16-storage region of the network (max-pool output in, layer4 output out).                             */
+int uem_weight_transpose_bf16(const float* w /* [Cout][KH][KW][Cin] fp32 master */, uint16_t* wt /* [Cin][KH][KW][Cout] bf16 */,
+                              int Cout, int KH, int KW, int Cin, void* stream);
 int uem_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream);
 

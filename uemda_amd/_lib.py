@@ -101,6 +101,7 @@ SIGNATURES = {
     "uem_affine_act_bf16": [P, P, P, P, P, P, P, L, I, I, P, P],
     "uem_bn_bwd_reduce_bf16": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
     "uem_bn_bwd_apply_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, P, P, P],
+    "uem_weight_transpose_bf16": [P, P, I, I, I, I, P],
     "uem_cast_f32_bf16": [P, P, L, P],
     "uem_cast_bf16_f32": [P, P, L, P],
     "uem_comm_unique_id": [P],

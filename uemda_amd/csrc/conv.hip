@@ -1586,6 +1586,23 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
         wt[idx] = w[((size_t)o * T + t) * Cin + i];
     }
 }
+__global__ void weight_transpose_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wt, int Cout, int T, int Cin) {
+    // w[o][t][i] (fp32 master) -> wt[i][t][o] (bf16, round to nearest even): the data gradient's filter bank on the bf16 path
+    const int64_t total = (int64_t)Cout * T * Cin;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % Cout);
+        int64_t r = idx / Cout;
+        const int t = (int)(r % T);
+        const int i = (int)(r / T);
+        wt[idx] = f2bf(w[((size_t)o * T + t) * Cin + i]);
+    }
+}
+extern "C" int uem_weight_transpose_bf16(const float* w, uint16_t* wt, int Cout, int KH, int KW, int Cin, void* stream) {
+    UEM_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "weight_transpose_bf16: bad arguments");
+    const int64_t total = (int64_t)Cout * KH * KW * Cin;
+    weight_transpose_bf16_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w, wt, Cout, KH * KW, Cin);
+    return uem_check_launch("weight_transpose_bf16");
+}
 extern "C" int uem_weight_transpose(const float* w, float* wt, int Cout, int KH, int KW, int Cin, void* stream) {
     UEM_REQUIRE(w && wt && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "weight_transpose: bad arguments");
     const int64_t total = (int64_t)Cout * KH * KW * Cin;

@@ -118,6 +118,7 @@ class Deeplabv2(nn.Module):
                 p.grad = gv
             p._uem_grad_view = (lambda vo=view_of, ga=garena: vo(ga))
             p._uem_owner = self
+            p._uem_off = off
             off += n
         self._arena, self._grad_arena, self._n_params = arena, garena, total
         # one int64 arena for every BatchNorm's num_batches_tracked: a training forward bumps all of them with ONE

@@ -100,7 +100,18 @@ def to_f32(x):
 
 
 def weight(param):
-    """bf16 OHWI copy of a conv weight, refreshed when the fp32 master changes (optimizer step / load_state_dict)."""
+    """bf16 OHWI copy of a conv weight: a view into the model's bf16 copy of the whole fp32 parameter arena, which is
+    refreshed by ONE cast after every optimizer step (fp32 masters stay in the arena the optimizer and the all-reduce use)."""
+    owner = getattr(param, "_uem_owner", None)
+    off = getattr(param, "_uem_off", None)
+    if owner is not None and off is not None and owner._arena is not None and param.data_ptr() == owner._arena.data_ptr() + 4 * off:
+        key = (ops.WEIGHT_EPOCH, owner._arena._version)
+        hit = getattr(owner, "_uem_arena_bf16", None)
+        if hit is None or hit[0] != key:
+            hit = (key, to_bf16(owner._arena))
+            owner._uem_arena_bf16 = hit
+        o, i, kh, kw = param.shape
+        return hit[1][off:off + param.numel()].view(o, kh, kw, i)
     key = (ops.WEIGHT_EPOCH, param._version, param.data_ptr())
     hit = getattr(param, "_uem_wb", None)
     if hit is None or hit[0] != key:
@@ -110,11 +121,16 @@ def weight(param):
 
 
 def weight_t(param):
-    """bf16 (Cin,KH,KW,Cout) copy for the data gradient (transposed in fp32, then rounded: the same bf16 values as weight())."""
+    """bf16 (Cin,KH,KW,Cout) copy for the data gradient: transposed and rounded from the fp32 master in one kernel, once
+    per optimizer step (the same bf16 values as weight())."""
     key = (ops.WEIGHT_EPOCH, param._version, param.data_ptr())
     hit = getattr(param, "_uem_wbt", None)
     if hit is None or hit[0] != key:
-        hit = (key, to_bf16(ops.weight_transpose(ops.weight_ohwi(param))))
+        w = ops.weight_ohwi(param)
+        cout, kh, kw, cin = w.shape
+        wt = torch.empty((cin, kh, kw, cout), device=w.device, dtype=torch.bfloat16)
+        call("uem_weight_transpose_bf16", ptr(w), ptr(wt), cout, kh, kw, cin, stream())
+        hit = (key, wt)
         param._uem_wbt = hit
     return hit[1]
 
