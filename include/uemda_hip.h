@@ -118,8 +118,11 @@ int64_t uem_bn_workspace_floats(int M, int C); /* also covers uem_bn_bwd_reduce'
 int uem_bn_stats_from_tiles(const float* tile_stats, int tiles, int M, int C, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
                             float* save_invstd, float* scale, float* shift, void* stream);
-int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
+/* eval-mode BatchNorm as an affine map: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale; mean /
+ * invstd (may be NULL) = running_mean, 1 / sqrt(running_var + eps), what uem_bn_bwd_reduce needs for the gamma / beta
+ * gradients of a BatchNorm that runs in eval mode inside a training graph (reference resnet.py:112-117,183-190)        */
+int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
 /* y = act(x*scale + shift (+ r)); r = res, or res*res_scale + res_shift (downsample branch BN) when
  * res_scale != NULL; act = relu if relu != 0.  In place allowed (y == x).  relu_bits (optional, C % 32 == 0,
  * M*C/32 words): bit (e & 31) of word e >> 5 = [y_e > 0], e = row*C + c -- the 1/32-size ReLU mask the backward
@@ -142,7 +145,7 @@ int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* d
 int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
-/* eval-mode / frozen-stat backward: dx = dp * scale                                              */
+/* eval-mode / frozen-statistics backward: dx = dp * scale, dp = dy masked as in uem_bn_bwd_apply (relu 0 / 1 / UEM_RELU_BITS) */
 int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, const float* scale,
                        const float* shift, int64_t M, int C, int relu, float* dx, float* dres, void* stream);
 
@@ -303,6 +306,13 @@ int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n,
  *   output channels % 64 == 0.                                                                                     */
 int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags,
                     float* tile_stats, void* stream);
+/* bf16 twin of uem_conv2d_dgrad_bnbwd / uem_conv2d_dgrad_tail (same argument meaning and restrictions: stride 1,
+ * N*H*W % 128 == 0, Cin % 64 == 0): dx = dgrad(dy) [+ acc_src * [acc_bits]] (or dx += with UEM_CONV_ACCUMULATE), and with
+ * bn_z / bn_vec (4, Cin) / tile_partials [2][Cin][M/128] the per-tile sums of dp and dp*xhat over the ROUNDED dx, dp = dx
+ * masked by bn_bits (packed) or by [bn_z*scale + shift > 0].  Tensors bf16; vectors, partial sums fp32.             */
+int uem_conv2d_dgrad_tail_bf16(const uint16_t* dy, const uint16_t* w_t, uint16_t* dx, const uem_conv_shape* s,
+                               const uint16_t* acc_src, const uint32_t* acc_bits, const uint16_t* bn_z, const float* bn_vec,
+                               const uint32_t* bn_bits, float* tile_partials, int flags, void* stream);
 /* dw[o][tap][i] (fp32, the gradient arena) += sum_m dY[m][o] * x[m'(m,tap)][i] with bf16 x and dY: 1x1 layers (stride 1; stride
  * 2 on output rows that are a multiple of 32 pixels) and 3x3 layers (stride 1 dilation 1 / 2, stride 2) on such rows;
  * channel counts % 64 == 0 (UEM_ERR_UNSUPPORTED otherwise).                                                          */

@@ -93,7 +93,11 @@ class OracleDeeplabv2:
     """Functional Deeplabv2 over a state_dict-keyed tensor mapping (CPU, fp32)."""
 
     def __init__(self, state, resnet_type="resnet50", num_classes=6, use_ppm=False,
-                 is_ins_norm=True, requires_grad=True):
+                 is_ins_norm=True, requires_grad=True, freeze_at=0, batchnorm_trainable=True,
+                 with_cp=(False, False, False, False)):
+        """freeze_at / batchnorm_trainable / with_cp: the ResNetEncoder options of reference uemda/resnet.py:57-60 (ctor),
+        :112-130 (_frozen_res_bn, _freeze_at), :146-165 (torch.utils.checkpoint per layer), :183-190 (train())."""
+        self.freeze_at, self.batchnorm_trainable, self.with_cp = int(freeze_at), bool(batchnorm_trainable), tuple(with_cp)
         self.resnet_type = resnet_type
         self.num_classes = num_classes
         self.use_ppm = use_ppm
@@ -108,6 +112,16 @@ class OracleDeeplabv2:
                     t.requires_grad_(True)
             self.p[k] = t
         self.plan = layer_plan(resnet_type)
+        # resnet.py:119-130: freeze_params(conv1, bn1) at >= 1, layer1..layer4 at >= 2..5; :112-117: every encoder BatchNorm
+        frozen = ["encoder.resnet.conv1.", "encoder.resnet.bn1.", "encoder.resnet.layer1.", "encoder.resnet.layer2.",
+                  "encoder.resnet.layer3.", "encoder.resnet.layer4."][:max(0, min(self.freeze_at, 5)) + (1 if self.freeze_at >= 1 else 0)]
+        for k, t in self.p.items():
+            if not t.requires_grad:
+                continue
+            if any(k.startswith(f) for f in frozen):
+                t.requires_grad_(False)
+            if not self.batchnorm_trainable and k.startswith("encoder.resnet.") and (".bn" in k or ".downsample.1." in k):
+                t.requires_grad_(False)
 
     # -- nn.Module-like helpers -------------------------------------------------------------
     def train(self, mode=True):
@@ -129,7 +143,8 @@ class OracleDeeplabv2:
     # -- building blocks -----------------------------------------------------------------------
     def _bn(self, x, prefix):
         p = self.p
-        if self.training:
+        frozen_stats = not self.batchnorm_trainable and prefix.startswith("encoder.resnet.")   # resnet.py:186-190: eval() while training
+        if self.training and not frozen_stats:
             # torch BatchNorm2d training semantics (_resnets.py:151 etc.): normalise with biased
             # batch variance, update running stats with momentum 0.1 and the unbiased variance.
             y = F.batch_norm(x, p[prefix + ".running_mean"], p[prefix + ".running_var"],
@@ -160,8 +175,18 @@ class OracleDeeplabv2:
         x = F.conv2d(x, p["encoder.resnet.conv1.weight"], stride=2, padding=3)
         x = F.relu(self._bn(x, "encoder.resnet.bn1"))
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        for prefix, _inpl, _planes, stride, dilation, has_ds in self.plan:
-            x = self._bottleneck(x, prefix, stride, dilation, has_ds)
+        for li in range(4):
+            blocks = [b for b in self.plan if b[0].startswith(f"encoder.resnet.layer{li + 1}.")]
+
+            def run(t, blocks=blocks):
+                for prefix, _inpl, _planes, stride, dilation, has_ds in blocks:
+                    t = self._bottleneck(t, prefix, stride, dilation, has_ds)
+                return t
+            if self.with_cp[li] and x.requires_grad:                   # resnet.py:146-165
+                import torch.utils.checkpoint as cp
+                x = cp.checkpoint(run, x, use_reentrant=True)
+            else:
+                x = run(x)
         return x
 
     def aspp_head(self, feat, head):

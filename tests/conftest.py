@@ -29,6 +29,18 @@ def load_golden(name):
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}      # name lists stay numpy
 
 
+def golden_initial_state(g, sd):
+    """State dict a model-level fixture's step started from: `sd` with the running statistics the fixture stores (calibrated
+    ones for the frozen-BatchNorm step, tests/golden/make_golden.py calibrated_state_dict) written over the defaults."""
+    if "init_stat_names" not in g:
+        return sd
+    sd = {k: v.clone() for k, v in sd.items()}
+    off, vals = g["init_stat_offsets"], g["init_stat_values"]
+    for i, k in enumerate(str(n) for n in g["init_stat_names"]):
+        sd[k] = vals[int(off[i]):int(off[i + 1])].reshape(sd[k].shape).clone()
+    return sd
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

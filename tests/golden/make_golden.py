@@ -344,12 +344,15 @@ def main():
     run_layer("layer_stem", stem, torch.randn(2, 3, 32, 32, generator=g))
 
     # ---------------- G-model / G-step ---------------------------------------------------------
-    def ssl_step_reference(use_ppm, mkldnn=True, ulp_noise=False):
+    def ssl_step_reference(use_ppm, mkldnn=True, ulp_noise=False, backbone=None, sd=None):
         """One train_ssl_uem.py iteration of the REFERENCE on the seeded batch; returns everything the fixture stores.
-        ulp_noise: the two image batches are perturbed by one unit in the last place (x * (1 +- 2^-23), seeded)."""
+        ulp_noise: the two image batches are perturbed by one unit in the last place (x * (1 +- 2^-23), seeded).
+        backbone: extra ResNetEncoder options (freeze_at, batchnorm_trainable, with_cp; reference resnet.py:170-181)."""
         torch.backends.mkldnn.enabled = mkldnn
-        sd = det_state_dict("resnet50", C, use_ppm, seed=2333)
-        model = ref.Encoder.Deeplabv2(model_cfg(use_ppm, C))
+        sd = det_state_dict("resnet50", C, use_ppm, seed=2333) if sd is None else sd
+        cfg = model_cfg(use_ppm, C)
+        cfg["backbone"].update(backbone or {})
+        model = ref.Encoder.Deeplabv2(cfg)
         model.load_state_dict(sd, strict=True)
         assert list(model.state_dict().keys()) == list(sd.keys()), "state_dict key order mismatch"
         if use_ppm:
@@ -392,17 +395,23 @@ def main():
         grads = {}          # NB: views of .grad -> they hold the POST-clip values once clip ran
         for n in gnames:
             gr = named[n].grad
+            if gr is None:                                   # frozen parameter
+                continue
             grads["grad:" + n] = gr if gr.numel() <= 8192 else gr.reshape(-1)[:: max(1, gr.numel() // 4096)][:4096]
+        frozen = [n for n, p in named.items() if p.grad is None]
+        for n in frozen:
+            assert not named[n].requires_grad, n
         gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=32, norm_type=2)
         # the UPDATE of every parameter tensor, 256 strided samples each: -lr * (clipped grad + wd * w), what SGD's first
         # step applies (momentum buffer = gradient), evaluated in float64 from the reference's own fp32 gradients -- the
         # difference w_post - w_pre itself is quantised to the weights' last place (8 % of a BatchNorm gamma's update)
-        upd = {n: (-lr * (p.grad.detach().double() + 5e-4 * p.detach().double())).reshape(-1)[:: max(1, p.numel() // 256)][:256]
-               .clone() for n, p in named.items()}
+        upd = {n: ((-lr * (p.grad.detach().double() + 5e-4 * p.detach().double())) if p.grad is not None else
+                   torch.zeros_like(p, dtype=torch.float64)).reshape(-1)[:: max(1, p.numel() // 256)][:256].clone()
+               for n, p in named.items()}              # a frozen parameter (grad None) is skipped by SGD: update 0
         opt.step()
         torch.backends.mkldnn.enabled = True
         return dict(model=model, prob=prob, ps1=ps1, ps2=ps2, pt1=pt1, pt2=pt2, feat_s=feat_s, feat_t=feat_t, soft=soft, hard=hard,
-                    loss_s=loss_s, loss_t=loss_t, al=al, gnorm=gnorm, lr=lr, grads=grads, upd=upd)
+                    loss_s=loss_s, loss_t=loss_t, al=al, gnorm=gnorm, lr=lr, grads=grads, upd=upd, frozen=frozen, pre=sd)
 
     for use_ppm in (False, True):
         tag = "ppm" if use_ppm else "aspp"
@@ -437,6 +446,60 @@ def main():
              post_conv1_sample=post["encoder.resnet.conv1.weight"].reshape(-1)[::7],
              nbt=post["encoder.resnet.bn1.num_batches_tracked"],
              upd_names=np.array(names), upd_offsets=upd_off, upd_samples=upd_flat, upd_noise_floor=noise, **r["grads"])
+    # ---------------- G-step with the encoder's optional modes (resnet.py:112-130,146-165,183-190) ---------------
+    # the same seeded step with (a) the stem and layer1 frozen and every encoder BatchNorm frozen in eval mode, (b) every
+    # residual layer under torch.utils.checkpoint.  Stored: outputs, losses, gradient norm, per-tensor update samples with
+    # their fp32 noise floor (as above), which tensors were frozen, and the BatchNorm buffers that tell the modes apart.
+    bn_keys = ["encoder.resnet.bn1", "encoder.resnet.layer1.0.bn1", "encoder.resnet.layer2.0.downsample.1", "encoder.resnet.layer4.2.bn3"]
+    def calibrated_state_dict():
+        """Frozen BatchNorm needs running statistics that normalise (with the initial mean 0 / variance 1 an eval-mode
+        ResNet lets its activations collapse and its backward pass cancels to 1e-4 of the incoming gradient, so every fp32
+        summation order gives another answer).  Like pretrained weights would, the state dict for the frozen step carries
+        the statistics of the data: the plain reference model, training mode, momentum=None (cumulative average), one forward
+        over the source and the target batch."""
+        sd0 = det_state_dict("resnet50", C, False, seed=2333)
+        m = ref.Encoder.Deeplabv2(model_cfg(False, C))
+        m.load_state_dict(sd0, strict=True)
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.momentum = None
+        b = synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333)
+        with torch.no_grad():
+            m(b["images_s"])
+            m(b["images_t"])
+        out = {k: v.clone() for k, v in m.state_dict().items()}
+        for k in out:
+            if k.endswith("num_batches_tracked"):
+                out[k].zero_()
+        return out
+
+    for tag, bb in (("frozen", dict(freeze_at=2, batchnorm_trainable=False)), ("cp", dict(with_cp=(True, True, True, True)))):
+        print("G-step encoder options", tag, bb)
+        sd_in = calibrated_state_dict() if tag == "frozen" else None
+        r = ssl_step_reference(False, backbone=bb, sd=sd_in)
+        r2 = ssl_step_reference(False, mkldnn=False, backbone=bb, sd=sd_in)
+        r3 = ssl_step_reference(False, ulp_noise=True, backbone=bb, sd=sd_in)
+        names = list(r["upd"].keys())
+        noise = np.array([max(float((r["upd"][n] - q["upd"][n]).norm() / (r["upd"][n].norm() + 1e-30)) for q in (r2, r3))
+                          for n in names])
+        post = r["model"].state_dict()
+        bufs = {}
+        for k in bn_keys:
+            for b in ("running_mean", "running_var", "num_batches_tracked"):
+                bufs[f"post:{k}.{b}"] = post[f"{k}.{b}"]
+        unchanged = all(torch.equal(post[n], r["pre"][n]) for n in r["frozen"])
+        if sd_in is not None:                              # the calibrated running statistics the step started from
+            rs = [k for k in sd_in if k.endswith("running_mean") or k.endswith("running_var")]
+            bufs["init_stat_names"] = np.array(rs)
+            bufs["init_stat_offsets"] = np.cumsum([0] + [sd_in[k].numel() for k in rs])
+            bufs["init_stat_values"] = torch.cat([sd_in[k].reshape(-1) for k in rs])
+        save(f"model_aspp_r50_b2_256_{tag}", pred_s1=r["ps1"], pred_s2=r["ps2"], pred_t1=r["pt1"], pred_t2=r["pt2"],
+             hard=r["hard"].to(torch.int8), loss_source=r["loss_s"], loss_target=r["loss_t"], prototypes=r["al"].prototypes,
+             grad_norm=r["gnorm"], lr=r["lr"], upd_names=np.array(names), upd_offsets=np.cumsum([0] + [r["upd"][n].numel() for n in names]),
+             upd_samples=torch.cat([r["upd"][n] for n in names]), upd_noise_floor=noise,
+             frozen_names=np.array(r["frozen"] if r["frozen"] else [""]), frozen_unchanged=np.array(unchanged),
+             options=np.array(repr(bb)), **bufs)
     print("done")
 
 

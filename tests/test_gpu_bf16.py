@@ -101,6 +101,234 @@ def test_wgrad_bf16_vs_fp64(case):
     assert float((dw.double().cpu() - 2 * ref).norm() / ref.norm()) < 4e-6
 
 
+TAIL_CASES = [
+    # N, H, W, Cin, Cout, k, dil, acc ("none" | "bits" | "accumulate"), bn ("none" | "z" | "bits")
+    (2, 16, 16, 64, 256, 1, 1, "none", "z"),           # conv3's data gradient + bn2's reduction
+    (2, 16, 16, 128, 128, 3, 2, "none", "z"),          # dilated conv2's data gradient + bn1's reduction
+    (2, 16, 16, 256, 64, 1, 1, "bits", "bits"),        # conv1's: identity gradient through the packed mask + previous bn3
+    (2, 16, 16, 256, 64, 1, 1, "bits", "none"),
+    (4, 8, 8, 512, 128, 1, 1, "accumulate", "bits"),   # after a stride-1 downsample's data gradient
+    (1, 16, 24, 64, 64, 3, 1, "none", "z"),            # 64-wide column tiles
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES)
+def test_dgrad_tail_bf16_epilogue(case):
+    """uem_conv2d_dgrad_tail_bf16: the data gradient with the residual tail and the BatchNorm-backward reduction in its epilogue
+    against fp64 built from the same bf16 values; the partial sums against sums over the dx the kernel stored."""
+    from uemda_amd import ops_bf16
+    N, H, W, Cin, Cout, k, d, acc, bn = case
+    g = torch.Generator().manual_seed(sum(case[:7]) + len(acc) + 7 * len(bn))
+    pad = d * (k - 1) // 2
+    w = _bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5)
+    x64 = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    y64 = F.conv2d(x64, w.double(), None, padding=pad, dilation=d)
+    gy = _bf(torch.randn(y64.shape, generator=g))
+    y64.backward(gy.double())
+    ref = x64.grad.clone()                                              # (N, Cin, H, W)
+    M = N * H * W
+    kw = {}
+    if acc != "none":
+        prev = _bf(torch.randn(N, Cin, H, W, generator=g))
+        if acc == "bits":
+            keep = torch.rand(N, H, W, Cin, generator=g) > 0.4
+            kw.update(acc_src=_nhwc(prev), acc_bits=_pack_bits(keep).cuda())
+            ref = ref + prev.double() * keep.permute(0, 3, 1, 2)
+        else:
+            kw.update(out=_nhwc(prev), accumulate=True)
+            ref = ref + prev.double()
+    if bn != "none":
+        z = _bf(torch.randn(N, H, W, Cin, generator=g))
+        vec = torch.stack([torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3, torch.randn(Cin, generator=g) * 0.1,
+                           torch.rand(Cin, generator=g) + 0.5])       # scale, shift, mean, invstd
+        kw.update(bn_z=z.cuda(), bn_vec=vec.cuda())
+        if bn == "bits":
+            on = torch.rand(N, H, W, Cin, generator=g) > 0.5
+            kw.update(bn_bits=_pack_bits(on).cuda())
+        else:
+            on = (z.float() * vec[0] + vec[1]) > 0
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda()
+    dx, tp = ops_bf16.conv2d_dgrad_tail(_nhwc(gy), wt, (N, H, W, Cin), pad=pad, dil=d, **kw)
+    _close_bf16(dx.permute(0, 3, 1, 2), ref, "data gradient + tail")
+    if bn == "none":
+        assert tp is None
+        return
+    tiles = M // 128
+    tp = tp.reshape(-1).double().cpu().view(2, Cin, tiles)
+    dp = dx.double().cpu() * on
+    xhat = (z.double() - vec[2].double()) * vec[3].double()
+    torch.testing.assert_close(tp[0].sum(1), dp.reshape(M, Cin).sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(tp[1].sum(1), (dp * xhat).reshape(M, Cin).sum(0), rtol=1e-4, atol=1e-3)
+    # per tile, not only in total
+    torch.testing.assert_close(tp[0].t(), dp.reshape(tiles, 128, Cin).sum(1), rtol=1e-4, atol=1e-3)
+
+
+def _pack_bits(mask):
+    """bool (..., C) -> int32 words, bit i of word j = element 32*j + i of the flattened tensor (the layout of the packed ReLU masks)."""
+    m = mask.reshape(-1, 32).to(torch.int64)
+    words = (m << torch.arange(32, dtype=torch.int64)).sum(1)
+    return (words & 0xFFFFFFFF).to(torch.int64).where(words < 2 ** 31, words - 2 ** 32).to(torch.int32)
+
+
+def _block_stack():
+    import torch.nn as nn
+    from uemda_amd.resnet import Bottleneck
+    torch.manual_seed(77)
+
+    def ds(cin, cout, s):
+        return nn.Sequential(nn.Conv2d(cin, cout, 1, s, bias=False), nn.BatchNorm2d(cout))
+    net = nn.Sequential(Bottleneck(64, 64, downsample=ds(64, 256, 1)), Bottleneck(256, 64), Bottleneck(256, 64),
+                        Bottleneck(256, 128, stride=2, downsample=ds(256, 512, 2)), Bottleneck(512, 128),
+                        Bottleneck(512, 128, dilation=2, downsample=ds(512, 512, 1)), Bottleneck(512, 128, dilation=2))
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    return net
+
+
+def _run_stack(sd, x, gy, storage, fuse, lo=0, hi=7):
+    from uemda_amd import ops
+    from uemda_amd.models.blocks_bf16 import CastFn
+    from uemda_amd.models.Encoder import Deeplabv2
+
+    class Holder(torch.nn.Module):
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+    net = _block_stack()
+    net.load_state_dict(sd)
+    h = Holder(net).cuda()
+    Deeplabv2._flatten_parameters(h)
+    net.train()
+    xi = x.clone().requires_grad_(True)
+    old = ops.FUSE_BN_BACKWARD
+    ops.FUSE_BN_BACKWARD = fuse
+    try:
+        t = CastFn.apply(xi, True) if storage == "bf16" else xi
+        for blk in list(net)[lo:hi]:
+            t = blk(t)
+        y = CastFn.apply(t, False) if storage == "bf16" else t
+        y.backward(gy)
+        torch.cuda.synchronize()
+    finally:
+        ops.FUSE_BN_BACKWARD = old
+    return y.detach().double(), xi.grad.double(), h._grad_arena[:h._n_params].double().clone(), \
+        {n: (p_._uem_off, p_.numel()) for n, p_ in net.named_parameters()}
+
+
+class _Rnd(torch.autograd.Function):
+    """bf16 storage of an activation: the value is rounded on the way up, its gradient on the way down."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+class _RndW(torch.autograd.Function):
+    """bf16 copy of an fp32 master weight: rounded value, full-precision gradient."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.bfloat16().to(w.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _emulated_stack(sd, x, gy, lo=0, hi=7):
+    """The same seven blocks in float64 torch on the CPU with a bf16 rounding wherever the storage path keeps a bf16 tensor
+    (conv outputs z, relu(bn(z)), block outputs, weight copies, and every activation gradient): the arithmetic the bf16
+    path implements, with none of its kernels."""
+    net = _block_stack().double()
+    net.load_state_dict({k: v.double() for k, v in sd.items()})
+    net.train()
+    R, RW = _Rnd.apply, _RndW.apply
+
+    def cbn(t, conv, bn):
+        z = R(F.conv2d(t, RW(conv.weight), None, conv.stride, conv.padding, conv.dilation))
+        return z, lambda z_: F.batch_norm(z_, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
+    xi = x.detach().cpu().double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    t = R(xi)
+    for blk in list(net)[lo:hi]:
+        z1, bn1 = cbn(t, blk.conv1, blk.bn1)
+        a1 = R(F.relu(bn1(z1)))
+        z2, bn2 = cbn(a1, blk.conv2, blk.bn2)
+        a2 = R(F.relu(bn2(z2)))
+        z3, bn3 = cbn(a2, blk.conv3, blk.bn3)
+        if blk.downsample is not None:
+            zd, bnd = cbn(t, blk.downsample[0], blk.downsample[1])
+            res = bnd(zd)
+        else:
+            res = t
+        t = R(F.relu(bn3(z3) + res))
+    t.backward(gy.detach().cpu().double().permute(0, 3, 1, 2))
+    grads = {n: p_.grad for n, p_ in net.named_parameters() if p_.grad is not None}
+    return t.detach().permute(0, 2, 3, 1), xi.grad.permute(0, 2, 3, 1), grads
+
+
+_CIN = [64, 256, 256, 256, 512, 512, 512]
+STACK_SLICES = [(0, 1), (1, 2), (3, 4), (4, 5), (5, 6), (6, 7), (0, 3), (2, 5), (4, 7), (0, 7)]
+
+
+@pytest.mark.parametrize("lo,hi", STACK_SLICES)
+def test_bf16_bottleneck_backward_vs_emulation_and_unfused(lo, hi):
+    """Bottleneck blocks (every block shape of the encoder: stride-1 / stride-2 / dilated downsample, identity; alone and in
+    chains, where a block's bn3 reduction rides in the NEXT block's tail epilogue) forward and backward in bf16 storage against a
+    float64 torch emulation of the SAME arithmetic (a bf16 rounding wherever the path stores a bf16 tensor, _emulated_stack).
+    What is left between the two: fp32 accumulation order, which flips a rounding here and there (one flip = 2^-8 relative
+    on that element, and downstream every ReLU whose sign it changes), and the downsample blocks adding their two data
+    gradients with one more rounding.  The flips cascade: training-mode BatchNorm blocks with branches as large as their
+    trunk amplify a perturbation by ~2 per block forward and, through the ReLU masks it moves, far more backward -- the same
+    float64 emulation sits 4e-2 (y) / 4e-1 (dx) from exact fp32 blocks after seven blocks, so the bounds below widen with the
+    chain length and the seven-block chain is printed, not asserted.  Also: the fused backward (BatchNorm reductions and the
+    residual tail in the data-gradient epilogues, gradient buffers reused in place) against the plain
+    one-pass-per-operation backward of the same path on the same forward (a linear map of gy: no cascade)."""
+    sd = {k: v.clone() for k, v in _block_stack().state_dict().items()}
+    g = torch.Generator().manual_seed(5 + 10 * lo + hi)
+    hw_in, hw_out = (32 if lo <= 3 else 16), (32 if hi <= 3 else 16)
+    x = torch.randn(2, hw_in, hw_in, _CIN[lo], generator=g).bfloat16().float().cuda()
+    gy = torch.randn(2, hw_out, hw_out, 256 if hi <= 3 else 512, generator=g).bfloat16().float().cuda()
+    y16, dx16, g16, offs = _run_stack(sd, x, gy, "bf16", True, lo, hi)
+    y16u, dx16u, g16u, _ = _run_stack(sd, x, gy, "bf16", False, lo, hi)
+    ye, dxe, ge = _emulated_stack(sd, x, gy, lo, hi)
+
+    def rel(a, b):
+        return float((a.cpu() - b.cpu()).norm() / b.cpu().norm())
+
+    def layer_grad(arena, n):
+        o, c = offs[n]
+        t = arena[o:o + c].cpu()
+        if ge[n].dim() == 4:                                           # the arena keeps conv weights OHWI
+            co, ci, kh, kw = ge[n].shape
+            t = t.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return t.reshape(ge[n].shape)
+    per_layer = {n: rel(layer_grad(g16, n), ge[n]) for n in ge}
+    worst = max(per_layer.items(), key=lambda kv: kv[1])
+    ry, rdx, rfu = rel(y16, ye), rel(dx16, dxe), max(rel(dx16, dx16u), rel(g16, g16u))
+    print(f"blocks [{lo}:{hi}) bf16 path vs float64 emulation of bf16 storage: y {ry:.2e}, dx {rdx:.2e}, worst parameter gradient {worst}; "
+          f"fused vs plain backward {rfu:.2e}")
+    assert torch.equal(y16, y16u)                                      # the forward does not depend on the backward's fusion
+    has_ds = any(b in (0, 3, 5) for b in range(lo, hi))              # downsample blocks: two data gradients, rounded in another order
+    assert rfu < (FUSED_TOL if has_ds else FUSED_TOL_IDENTITY), rfu
+    n = hi - lo
+    if n in CHAIN_TOL:
+        ty, tdx, tdw = CHAIN_TOL[n]
+        assert ry < ty and rdx < tdx and worst[1] < tdw, (ry, rdx, worst)
+
+
+# measured (profiles/README.md, round 2): one block y 2-7e-4, dx 2e-3..1.2e-2, parameter gradients <= 1.5e-2; three blocks y 4-7e-3,
+# dx 6e-2..1.1e-1, parameter gradients <= 1.4e-1; fused vs plain 4-6e-5 on identity blocks, 3e-3..1e-2 with downsample blocks.
+# A wrong mask, a missing term or a mis-indexed partial sum is an O(1) error at the one-block level.
+FUSED_TOL, FUSED_TOL_IDENTITY = 2e-2, 1e-3
+CHAIN_TOL = {1: (2e-3, 3e-2, 4e-2), 3: (2e-2, 2.5e-1, 3e-1)}      # blocks in the chain -> relative L2 bounds on y, dx, parameter gradients
+
+
 def _damped_sd(rtype, damp=0.2):
     from oracle.weights import det_state_dict
     sd = det_state_dict(rtype, 6, False, seed=2333)
@@ -134,7 +362,7 @@ def test_bf16_storage_ssl_step_vs_oracle(rtype, size):
     ref = oracle_ssl(om, SGDState(om.parameters(), 0.9, 5e-4), bc["prototypes"], bc, 2e-3, OH)
     cfg = dict(backbone=dict(resnet_type=rtype, output_stride=16, pretrained=False), multi_layer=True, cascade=False,
                use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
-    res = {}
+    res, grads = {}, {}
     for storage in ("fp32", "bf16"):
         model = Deeplabv2(cfg)
         model.load_state_dict(sd)
@@ -150,6 +378,7 @@ def test_bf16_storage_ssl_step_vs_oracle(rtype, size):
         lt = abs(float(out["loss_target"]) / float(ref["loss_target"]) - 1.0)
         gn = abs(float(out["grad_norm"]) / float(ref["grad_norm"]) - 1.0)
         res[storage] = (rel, agree, ls, lt, gn)
+        grads[storage] = model._grad_arena[:model._n_params].clone()
         print(f"{rtype} {size}x{size} storage={storage}: logit relative L2 {rel:.3e}, hard-label agreement {agree:.5f}, "
               f"losses off by {ls:.2e} / {lt:.2e}, grad norm off by {gn:.2e}")
         del model
@@ -160,3 +389,10 @@ def test_bf16_storage_ssl_step_vs_oracle(rtype, size):
     assert agree >= 0.99, agree
     assert ls < 1e-2 and lt < 1e-2, (ls, lt)
     assert gn < 0.1, gn
+    # whole-step gradients, bf16 against fp32 storage: a coarse check only (through ~50 / ~100 layers the forward already
+    # differs by `rel` and the ReLU masks with it; measured cosine 0.94 on ResNet-50, 0.82 on ResNet-101).  The backward kernels themselves are
+    # pinned on short chains by test_bf16_bottleneck_backward_vs_emulation_and_unfused.
+    g32, g16 = grads["fp32"].double(), grads["bf16"].double()
+    cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
+    print(f"{rtype} {size}x{size}: gradient arena bf16 vs fp32 storage: cosine {cos:.5f}, relative L2 {float((g32 - g16).norm() / g32.norm()):.3e}")
+    assert cos > 0.7, cos

@@ -122,6 +122,12 @@ WGRAD_DMA_CASES = [
     (2, 16, 64, 128, 256, 1, 2, 1, False),      # downsample 1x1 stride 2
     (2, 16, 64, 128, 64, 1, 2, 1, True),
     (8, 32, 32, 128, 128, 3, 1, 1, True),       # enough rows for several pixel slices per tile (split-K) and both stages
+    (2, 16, 16, 512, 512, 3, 1, 1, True),       # 16-pixel rows (256^2 tiles at stride 16): the 16-pixel-step variant; layer4.0.conv2
+    (2, 16, 16, 256, 256, 3, 1, 1, True),       # layer3 at 256^2
+    (2, 16, 16, 512, 512, 3, 1, 2, True),       # layer4 dilated at 256^2
+    (2, 32, 32, 128, 128, 3, 2, 1, True),       # stride 2 onto 16-pixel rows
+    (2, 16, 16, 1024, 512, 1, 1, 1, False),     # layer4.0.conv1 at 256^2
+    (2, 16, 16, 512, 2048, 1, 1, 1, True),
 ]
 
 
@@ -317,14 +323,14 @@ def test_layer_stem_golden():
 
 
 # ---------------- full network + one SSL step against the reference golden (BASELINE config 1) ------------------
-def _model(use_ppm=False):
+def _model(use_ppm=False, sd=None, **backbone):
     from oracle.weights import det_state_dict
     from uemda_amd.models.Encoder import Deeplabv2
-    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True,
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False, **backbone), multi_layer=True,
                cascade=False, use_ppm=use_ppm, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
                inchannels=2048, num_classes=C, is_ins_norm=True)
     m = Deeplabv2(cfg)
-    sd = det_state_dict("resnet50", C, use_ppm, seed=2333)
+    sd = det_state_dict("resnet50", C, use_ppm, seed=2333) if sd is None else sd
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict(sd)
     return m.cuda()
@@ -411,9 +417,16 @@ def _check_updates(model, g, use_ppm):
     names, off, ref, floor = [str(n) for n in g["upd_names"]], g["upd_offsets"], g["upd_samples"], g["upd_noise_floor"]
     named = dict(model.named_parameters())
     assert set(names) == set(named), "the fixture covers every parameter tensor"
+    frozen = set(str(n) for n in g["frozen_names"] if str(n)) if "frozen_names" in g else set()
     ratios, report = [], []
     for i, n in enumerate(names):
         p = named[n]
+        if n in frozen:                                  # freeze_at / frozen BatchNorm: no gradient, not a bit of the weight moves
+            assert not p.requires_grad and p.grad is None, n
+            assert torch.equal(p.detach().cpu(), w0[n].float()), n
+            assert float(ref[int(off[i]):int(off[i + 1])].abs().max()) == 0.0
+            continue
+        assert p.requires_grad, n
         st = max(1, p.numel() // 256)
         w_pre = w0[n].reshape(-1)[::st][:256].double()
         grad = p.grad.detach().cpu().reshape(-1)[::st][:256].double()            # post-clip (the fused step scales .grad)
@@ -432,11 +445,124 @@ def _check_updates(model, g, use_ppm):
         ulp = torch.maximum(w_pre.abs(), w_post.abs()).float().clamp_min(1e-30)
         ulp = (torch.nextafter(ulp, torch.full_like(ulp, float("inf"))) - ulp).double()
         assert ((w_post - (w_pre + upd)).abs() <= 1.5 * ulp + 2e-6 * upd.abs()).all(), n
+    if not ratios:                                       # every trainable tensor sits at rounding level (frozen BatchNorm statistics)
+        return
     ratios.sort()
     median = ratios[len(ratios) // 2]
     print(f"update error / reference noise floor over {len(ratios)} encoder tensors: median {median:.2f}, max {ratios[-1]:.2f}; "
           f"worst absolute {max(report)[:2]} {max(report)[2]}")
     assert median < 1.5, median
+
+
+@pytest.mark.parametrize("affine_trainable", [True, False])
+@pytest.mark.parametrize("shape", ["stride2_downsample", "stride1_downsample", "identity_dilated"])
+def test_bottleneck_eval_mode_batchnorm_backward_vs_torch(shape, affine_trainable):
+    """A bottleneck whose BatchNorms run in eval mode inside a training graph (ResNetEncoder batchnorm_trainable=False,
+    reference resnet.py:112-117,183-190): y, dx and every parameter gradient against torch autograd in float64 on the same
+    weights and running statistics.  With constant statistics nothing amplifies rounding: 1e-5 relative."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from uemda_amd.resnet import Bottleneck
+    torch.manual_seed(11)
+    if shape.endswith("downsample"):
+        sd_ = 2 if shape.startswith("stride2") else 1
+        blk = Bottleneck(64, 32, stride=sd_, downsample=nn.Sequential(nn.Conv2d(64, 128, 1, sd_, bias=False), nn.BatchNorm2d(128)))
+        cin = 64
+    else:
+        blk = Bottleneck(128, 32, dilation=2)
+        cin = 128
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.3)
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2.0)
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = affine_trainable
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, cin, 16, 16, generator=g)
+    holder = _Holder(blk).cuda().flatten()
+    xg = nhwc(x).requires_grad_(True)
+    y = blk(xg)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.cuda())
+    # float64 torch
+    ref = Bottleneck(cin, 32, stride=blk.stride, dilation=blk.dilation,
+                     downsample=None if blk.downsample is None else nn.Sequential(nn.Conv2d(64, 128, 1, blk.stride, bias=False), nn.BatchNorm2d(128))).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    ref.eval()
+    x64 = x.double().requires_grad_(True)
+
+    def bn(t, m):
+        return F.batch_norm(t, m.running_mean, m.running_var, m.weight, m.bias, False, 0.1, m.eps)
+    o = F.relu(bn(F.conv2d(x64, ref.conv1.weight), ref.bn1))
+    o = F.relu(bn(F.conv2d(o, ref.conv2.weight, None, ref.conv2.stride, ref.conv2.padding, ref.conv2.dilation), ref.bn2))
+    o = bn(F.conv2d(o, ref.conv3.weight), ref.bn3)
+    idn = x64 if ref.downsample is None else bn(F.conv2d(x64, ref.downsample[0].weight, None, ref.downsample[0].stride), ref.downsample[1])
+    y64 = F.relu(o + idn)
+    y64.backward(gy.permute(0, 3, 1, 2).double())
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(nchw(y.detach()), y64.detach()) < 1e-5
+    assert rel(nchw(xg.grad), x64.grad) < 1e-5
+    named, rnamed = dict(blk.named_parameters()), dict(ref.named_parameters())
+    for n, p in named.items():
+        if "bn" in n or "downsample.1" in n:
+            if not affine_trainable:
+                assert p.grad is None, n
+                continue
+        assert rel(p.grad, rnamed[n].grad) < 2e-5, (n, rel(p.grad, rnamed[n].grad))
+    for n, b in blk.named_buffers():                                   # eval mode: statistics and counters untouched
+        assert torch.equal(b.cpu(), sd[n]), n
+    del holder
+
+
+ENCODER_OPTIONS = {"frozen": dict(freeze_at=2, batchnorm_trainable=False), "cp": dict(with_cp=(True, True, True, True))}
+
+
+@pytest.mark.parametrize("tag", ["frozen", "cp"])
+def test_ssl_step_encoder_options_match_reference_golden(tag):
+    """The ResNetEncoder modes the config exposes but no UemDA script switches on (reference uemda/resnet.py:112-130,146-165,
+    183-190), one train_ssl_uem step each against the reference's own step:
+      frozen: freeze_at=2 + batchnorm_trainable=False -- stem and layer1 frozen, every encoder BatchNorm in eval mode with frozen
+              gamma / beta (backward through running statistics; no gradient, no weight decay, no momentum on frozen tensors;
+              running statistics and num_batches_tracked untouched);
+      cp:     every residual layer under torch.utils.checkpoint (its forward runs again inside backward, so its BatchNorm
+              running statistics move twice per forward and num_batches_tracked counts 4 for the step's two forwards)."""
+    from oracle import synth
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    g = load_golden(f"model_aspp_r50_b2_256_{tag}")
+    assert str(g["options"]) == repr(ENCODER_OPTIONS[tag])
+    from oracle.weights import det_state_dict
+    from conftest import golden_initial_state
+    model = _model(False, sd=golden_initial_state(g, det_state_dict("resnet50", C, False, seed=2333)), **ENCODER_OPTIONS[tag])
+    model.train()
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    al.prototypes = batch["prototypes"].clone()
+    opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    out = ssl_step(model, al, opt, StepState(C), batch, float(g["lr"]))
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        err = (out[k].cpu() - g[k]).abs().max() / g[k].abs().max()
+        assert err < 1e-3, (k, float(err))
+    assert (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item() >= 0.9995
+    torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(al.prototypes.cpu(), g["prototypes"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=5e-3, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("post:"):
+            if k.endswith("num_batches_tracked"):
+                assert int(sd[k[5:]]) == int(v), (k, int(sd[k[5:]]), int(v))
+            else:
+                torch.testing.assert_close(sd[k[5:]].cpu(), v, rtol=1e-3, atol=1e-5)
+    _check_updates(model, g, False)
 
 
 def test_fused_sgd_matches_torch_sgd_with_clipping():

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import golden_initial_state, load_golden
 from oracle import gast, synth
 from oracle.model import OracleDeeplabv2, param_shapes
 from oracle.step import HYPER, SGDState, ssl_step
@@ -252,6 +252,40 @@ def test_full_model_ssl_step(tag):
     torch.testing.assert_close(model.p["encoder.resnet.bn1.running_mean"], g["post_bn1_running_mean"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(model.p["encoder.resnet.layer4.2.bn3.running_var"], g["post_l4_bn3_running_var"], rtol=1e-4, atol=1e-6)
     assert int(model.p["encoder.resnet.bn1.num_batches_tracked"]) == int(g["nbt"]) == 2
+
+
+ENCODER_OPTIONS = {"frozen": dict(freeze_at=2, batchnorm_trainable=False), "cp": dict(with_cp=(True, True, True, True))}
+
+
+@pytest.mark.parametrize("tag", ["frozen", "cp"])
+def test_ssl_step_encoder_options(tag):
+    """The ResNetEncoder modes no UemDA script switches on but its config exposes (reference uemda/resnet.py:112-130
+    freeze_at / frozen BatchNorm, :146-165 checkpointed layers): the oracle's restatement against the reference's own step."""
+    g = load_golden(f"model_aspp_r50_b2_256_{tag}")
+    assert str(g["options"]) == repr(ENCODER_OPTIONS[tag])
+    sd = golden_initial_state(g, det_state_dict("resnet50", C, False, seed=2333))
+    model = OracleDeeplabv2(sd, "resnet50", C, False, **ENCODER_OPTIONS[tag])
+    batch = synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333)
+    frozen = [str(n) for n in g["frozen_names"] if str(n)]
+    assert sorted(k for k, t in model.p.items() if t.is_floating_point() and "running_" not in k and not t.requires_grad) == sorted(frozen)
+    opt = SGDState(model.parameters(), HYPER["momentum"], HYPER["weight_decay"])
+    out = ssl_step(model, opt, batch["prototypes"], batch, float(g["lr"]), HYPER, dropout=False)
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        torch.testing.assert_close(out[k], g[k], rtol=1e-3, atol=1e-4)
+    assert (out["label_t_hard"] == g["hard"].long()).float().mean().item() >= 0.9999
+    torch.testing.assert_close(out["loss_source"], g["loss_source"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["loss_target"], g["loss_target"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["grad_norm"], g["grad_norm"], rtol=1e-3, atol=1e-5)
+    for k in frozen:                                                   # untouched: no gradient, no weight decay
+        assert torch.equal(model.p[k], sd[k].float()), k
+        assert model.p[k].grad is None
+    for k, v in g.items():
+        if k.startswith("post:"):
+            got = model.p[k[5:]]
+            if k.endswith("num_batches_tracked"):
+                assert int(got) == int(v), (k, int(got), int(v))
+            else:
+                torch.testing.assert_close(got, v, rtol=1e-4, atol=1e-6)
 
 
 def test_pre_slide_windowing_golden():

@@ -48,7 +48,7 @@ SIGNATURES = {
     "uem_bn_stats": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P, P],
     "uem_bn_workspace_floats": [I, I],
     "uem_bn_stats_from_tiles": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P],
-    "uem_bn_eval_affine": [P, P, P, P, F, P, P, I, P],
+    "uem_bn_eval_affine": [P, P, P, P, F, P, P, P, P, I, P],
     "uem_affine_act": [P, P, P, P, P, P, P, L, I, I, P, P],
     "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
     "uem_bn_bwd_from_tiles": [P, I, I, P, P, P, P, P],
@@ -97,6 +97,7 @@ SIGNATURES = {
     "uem_coral_finish": [P, P, P, P, I, I, I, P, P, P, P, P],
     "uem_negate": [P, P, I, P],
     "uem_conv2d_bf16": [P, P, P, POINTER(ConvShape), I, P, P],
+    "uem_conv2d_dgrad_tail_bf16": [P, P, P, POINTER(ConvShape), P, P, P, P, P, P, I, P],
     "uem_conv2d_wgrad_bf16": [P, P, P, POINTER(ConvShape), P],
     "uem_affine_act_bf16": [P, P, P, P, P, P, P, L, I, I, P, P],
     "uem_bn_bwd_reduce_bf16": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],

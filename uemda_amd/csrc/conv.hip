@@ -871,6 +871,53 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
+    const bool dense_rows = !(MODE == 1 && p.sub > 1);
+    auto row_off = [&](const int m) -> size_t {
+        if (dense_rows) return (size_t)m * p.y_ld;
+        const int hw = p.Hs * p.Ws;
+        const int ni = m / hw, rem = m - ni * hw;
+        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
+        return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
+    };
+    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = 256 / TPR, NRP = 64 / RPP;
+    float* const stg = smem;
+    const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
+    float cs1 = 0.f, cs2 = 0.f;
+    // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
+    // backward over the rounded dx (same contract as the fp32 kernel's epilogue, bf16 tensors)
+    const bool fuse_bn = MODE == 1 && p.tile_bnbwd != nullptr;
+    const unsigned short* const zh = reinterpret_cast<const unsigned short*>(p.bn_z);
+    const unsigned short* const ah = p.acc_src != nullptr ? reinterpret_cast<const unsigned short*>(p.acc_src) : yh;
+    float pb[8], pg[8], bsc[8], bsh[8], bmu[8], bis[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pb[e] = pg[e] = 0.f; bsc[e] = bsh[e] = bmu[e] = bis[e] = 0.f; }
+    if (fuse_bn) {
+        const float* v4 = p.bn_vec + n0 + sc8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bsc[e] = v4[e]; bsh[e] = v4[p.Cout + e]; bmu[e] = v4[2 * p.Cout + e]; bis[e] = v4[3 * p.Cout + e]; }
+    }
+    // what the epilogue reads besides the accumulators -- the tensor accumulated into, its gate bits, the BatchNorm input and
+    // its mask bits -- is fetched one 64-row half ahead: half 0 before the main loop, half 1 while half 0 is written out
+    uint4 eo[2][NRP], ez[2][NRP];
+    unsigned eab[2][NRP], ebb[2][NRP];
+    auto epi_fetch = [&](const int hm) {
+#pragma unroll
+        for (int u = 0; u < NRP; ++u) {
+            const int m = m0 + hm * 64 + srow + u * RPP;
+            eab[hm][u] = 0xffu; ebb[hm][u] = 0u;
+            if (m >= p.M) continue;
+            if (p.accumulate) eo[hm][u] = *reinterpret_cast<const uint4*>(ah + row_off(m) + n0 + sc8);
+            if (MODE == 1) {
+                const size_t e0 = (size_t)m * p.Cout + n0 + sc8;           // dense rows whenever bits / bn_z are given
+                if (p.acc_bits != nullptr) eab[hm][u] = (p.acc_bits[e0 >> 5] >> (e0 & 31)) & 0xffu;
+                if (fuse_bn) {
+                    ez[hm][u] = *reinterpret_cast<const uint4*>(zh + e0);
+                    if (p.bn_bits != nullptr) ebb[hm][u] = (p.bn_bits[e0 >> 5] >> (e0 & 31)) & 0xffu;
+                }
+            }
+        }
+    };
+    epi_fetch(0);
 #define CONV_SYNC()                                                 \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
     __builtin_amdgcn_s_barrier();                                   \
@@ -890,19 +937,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     __syncthreads();
 #undef CONV_SYNC
 
-    // ---- epilogue -----------------------------------------------------------------------------------------
-    const bool dense_rows = !(MODE == 1 && p.sub > 1);
-    auto row_off = [&](const int m) -> size_t {
-        if (dense_rows) return (size_t)m * p.y_ld;
-        const int hw = p.Hs * p.Ws;
-        const int ni = m / hw, rem = m - ni * hw;
-        const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
-        return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
-    };
-    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = 256 / TPR, NRP = 64 / RPP;
-    float* const stg = smem;
-    const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
-    float cs1 = 0.f, cs2 = 0.f;
+    // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {
         if (wm / 64 == hm) {
@@ -916,14 +951,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                         stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
         }
         __syncthreads();
-        uint4 o[NRP];
+        if (hm == 0) epi_fetch(1);
         bool rok[NRP];
 #pragma unroll
-        for (int u = 0; u < NRP; ++u) {
-            const int m = m0 + hm * 64 + srow + u * RPP;
-            rok[u] = m < p.M;
-            if (p.accumulate && rok[u]) o[u] = *reinterpret_cast<const uint4*>(yh + row_off(m) + n0 + sc8);
-        }
+        for (int u = 0; u < NRP; ++u) rok[u] = m0 + hm * 64 + srow + u * RPP < p.M;
+        const uint4 (&o)[NRP] = eo[hm];
+        const uint4 (&zq)[NRP] = ez[hm];
+        const unsigned (&abyte)[NRP] = eab[hm];
+        const unsigned (&bbyte)[NRP] = ebb[hm];
 #pragma unroll
         for (int u = 0; u < NRP; ++u) {
             const int row = srow + u * RPP;
@@ -934,7 +969,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             if (p.accumulate) {
                 const unsigned w4[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w4[e] << 16); v[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
+                    v[2 * e] += ((abyte[u] >> (2 * e)) & 1u) ? lo : 0.f;
+                    v[2 * e + 1] += ((abyte[u] >> (2 * e + 1)) & 1u) ? hi : 0.f;
+                }
             }
             unsigned pk[4];
 #pragma unroll
@@ -947,6 +986,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             if (p.tile_stats != nullptr) {                               // statistics of what was stored
                 *reinterpret_cast<float4*>(&stg[row * LDW + sc8]) = *reinterpret_cast<const float4*>(&v[0]);
                 *reinterpret_cast<float4*>(&stg[row * LDW + sc8 + 4]) = *reinterpret_cast<const float4*>(&v[4]);
+            }
+            if (fuse_bn) {
+                const unsigned z4[4] = {zq[u].x, zq[u].y, zq[u].z, zq[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float z = (e & 1) ? __uint_as_float(z4[e >> 1] & 0xffff0000u) : __uint_as_float(z4[e >> 1] << 16);
+                    const bool on = p.bn_bits != nullptr ? ((bbyte[u] >> e) & 1u) != 0u : (z * bsc[e] + bsh[e] > 0.f);
+                    const float dp = on ? v[e] : 0.f;
+                    pb[e] += dp;
+                    pg[e] = fmaf(dp, (z - bmu[e]) * bis[e], pg[e]);
+                }
             }
         }
         if (p.tile_stats != nullptr) {
@@ -961,6 +1011,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             }
         }
         __syncthreads();
+    }
+    if (fuse_bn) {                                                       // column sums over the tile's 128 rows
+        float* const red = stg;                                          // [2][RPP][BN]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, col = tid % BN;
+            float a = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + col];
+            const size_t tiles_m = (size_t)(p.M / BM);
+            p.tile_bnbwd[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
+        }
     }
     if (p.tile_stats != nullptr && tid < BN) {
         const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
@@ -1748,8 +1812,31 @@ static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t s
     (void)attr;
     k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
 }
+struct BnBwdFuseH { const uint16_t* z; const float* vec; float* tiles; const uint16_t* acc_src; const uint32_t* acc_bits; const uint32_t* bn_bits; };
+static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags, float* tile_stats,
+                            const BnBwdFuseH* fuse, void* stream);
 extern "C" int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags,
                                float* tile_stats, void* stream) {
+    return conv2d_bf16_impl(x, w, y, s, flags, tile_stats, nullptr, stream);
+}
+// bf16 twin of uem_conv2d_dgrad_bnbwd / uem_conv2d_dgrad_tail (same argument meaning; tensors are bf16, vectors and partial
+// sums fp32; the partial sums are taken over the ROUNDED dx, the values the apply pass reads back)
+extern "C" int uem_conv2d_dgrad_tail_bf16(const uint16_t* dy, const uint16_t* w_t, uint16_t* dx, const uem_conv_shape* s,
+                                          const uint16_t* acc_src, const uint32_t* acc_bits, const uint16_t* bn_z, const float* bn_vec,
+                                          const uint32_t* bn_bits, float* tile_partials, int flags, void* stream) {
+    UEM_REQUIRE(s && dx, "conv2d_dgrad_tail_bf16: null pointer");
+    UEM_REQUIRE((acc_bits == nullptr) == (acc_src == nullptr), "conv2d_dgrad_tail_bf16: acc_src and acc_bits go together");
+    UEM_REQUIRE((bn_z == nullptr) == (tile_partials == nullptr) && (bn_z == nullptr) == (bn_vec == nullptr) && (bn_z || !bn_bits),
+                "conv2d_dgrad_tail_bf16: bn_z, bn_vec and tile_partials go together");
+    if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_tail_bf16: needs stride 1, M %% 128 == 0, Cin %% 64 == 0, dense rows");
+    UEM_REQUIRE((flags & ~UEM_CONV_ACCUMULATE) == 0, "conv2d_dgrad_tail_bf16: bad flags");
+    UEM_REQUIRE(!(acc_src && (flags & UEM_CONV_ACCUMULATE)), "conv2d_dgrad_tail_bf16: acc_src already names the tensor accumulated into");
+    BnBwdFuseH f{bn_z, bn_vec, tile_partials, acc_src, acc_bits, bn_bits};
+    return conv2d_bf16_impl(dy, w_t, dx, s, UEM_CONV_TRANSPOSED | flags | (acc_src ? UEM_CONV_ACCUMULATE : 0), nullptr, &f, stream);
+}
+static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags, float* tile_stats,
+                            const BnBwdFuseH* fuse, void* stream) {
     UEM_REQUIRE(x && w && y, "conv2d_bf16: null pointer");
     int rc = conv_check(s);
     if (rc) return rc;
@@ -1764,6 +1851,10 @@ extern "C" int uem_conv2d_bf16(const uint16_t* x, const uint16_t* w, uint16_t* y
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0; p.relu = 0;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0;
     p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
+    if (fuse != nullptr) {
+        p.bn_z = (const float*)fuse->z; p.bn_vec = fuse->vec; p.tile_bnbwd = fuse->tiles;
+        p.acc_src = (const float*)fuse->acc_src; p.acc_bits = fuse->acc_bits; p.bn_bits = fuse->bn_bits;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (!transposed) {
         UEM_REQUIRE(!tile_stats || ((int64_t)s->N * s->Ho * s->Wo) % 128 == 0, "conv2d_bf16: tile statistics need M %% 128 == 0");

@@ -61,6 +61,24 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, float4 v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(f2bf_bits(v.x) | (f2bf_bits(v.y) << 16), f2bf_bits(v.z) | (f2bf_bits(v.w) << 16));
 }
 
+// 8 bf16 channels per access (16 bytes): what the elementwise bf16 passes use when C % 8 == 0
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(w[e] << 16); v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = f2bf_bits(v[2 * e]) | (f2bf_bits(v[2 * e + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void ldv8(const float* p, float (&v)[8]) {
+    *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(p);
+    *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(p + 4);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm statistics (training mode)
 // ---------------------------------------------------------------------------------------------------------
@@ -242,17 +260,22 @@ extern "C" int uem_bn_stats(const float* x, int M, int C, int ld, const float* g
 
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
-                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+                                      float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean,
+                                      float* __restrict__ invstd, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
     const float sc = (gamma ? gamma[c] : 1.f) / sqrtf(rv[c] + eps);
     scale[c] = sc;
     shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+    if (mean) mean[c] = rm[c];
+    if (invstd) invstd[c] = is;
 }
-extern "C" int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
-                                  const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+extern "C" int uem_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  float eps, float* scale, float* shift, float* mean, float* invstd, int C, void* stream) {
     UEM_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_affine: bad arguments");
-    bn_eval_affine_kernel<<<(int)uem_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, scale, shift, C);
+    bn_eval_affine_kernel<<<(int)uem_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, scale, shift,
+                                                                                mean, invstd, C);
     return uem_check_launch("bn_eval_affine");
 }
 
@@ -296,6 +319,48 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
         }
     }
 }
+__global__ __launch_bounds__(256) void affine_act_bf16x8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const bf16_t* __restrict__ res,
+                                                                const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                                bf16_t* __restrict__ y, int64_t nvec, int C, int relu,
+                                                                uint32_t* __restrict__ bits) {
+    // same arithmetic as affine_act_kernel<bf16_t>, 8 channels (16 bytes) per lane; with `bits` 4 consecutive lanes hold one word
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 8) % C);
+        float v[8], sc[8], sh[8];
+        ld8(x + i * 8, v);
+        ldv8(scale + c, sc);
+        ldv8(shift + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res) {
+            float r[8];
+            ld8(res + i * 8, r);
+            if (rscale) {
+                ldv8(rscale + c, sc);
+                ldv8(rshift + c, sh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = r[e] * sc[e] + sh[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        st8(y + i * 8, v);
+        if (bits) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m |= (v[e] > 0.f ? 1u : 0u) << e;
+            m <<= 8 * (threadIdx.x & 3);
+            m |= __shfl_xor(m, 1);
+            m |= __shfl_xor(m, 2);
+            if ((threadIdx.x & 3) == 0) bits[i >> 2] = m;
+        }
+    }
+}
 extern "C" int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
                               const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
                               uint32_t* relu_bits, void* stream) {
@@ -312,6 +377,12 @@ extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const 
     UEM_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && (C % 4) == 0, "affine_act_bf16: bad arguments");
     UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act_bf16: relu_bits needs C %% 32 == 0 (C=%d)", C);
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act_bf16: bad residual affine");
+    if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {       // with bits: C % 32 == 0, whole lane quads
+        const int64_t nvec8 = M * C / 8;
+        affine_act_bf16x8_kernel<<<uem_stream_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y,
+                                                                                               nvec8, C, relu, relu_bits);
+        return uem_check_launch("affine_act_bf16");
+    }
     const int64_t nvec = M * C / 4;
     affine_act_kernel<bf16_t><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     return uem_check_launch("affine_act_bf16");
@@ -471,6 +542,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         st4<T>(dx + off, o);
     }
 }
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                  const uint32_t* __restrict__ rbits, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ smean,
+                                                                  const float* __restrict__ sinv, const float* __restrict__ dgamma,
+                                                                  const float* __restrict__ dbeta, int64_t nvec, int C, float invM,
+                                                                  int relu, bf16_t* dx, bf16_t* __restrict__ dres) {
+    // same arithmetic as bn_bwd_apply_kernel<bf16_t>, 8 channels (16 bytes) per lane; dx may alias dy (element-wise in place)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 8) % C);
+        const size_t off = (size_t)i * 8;
+        float xv[8], d[8], sc[8], t[8];
+        ld8(x + off, xv);
+        ld8(dy + off, d);
+        ldv8(scale + c, sc);
+        if (relu == 2) {
+            const uint32_t m = rbits[off >> 5] >> (off & 31);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = ((m >> e) & 1u) ? d[e] : 0.f;
+        } else if (relu) {
+            ldv8(shift + c, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = (xv[e] * sc[e] + t[e] > 0.f) ? d[e] : 0.f;
+        }
+        if (dres) st8(dres + off, d);
+        float mu[8], is[8], dg[8], db[8], o[8];
+        ldv8(smean + c, mu);
+        ldv8(sinv + c, is);
+        ldv8(dgamma + c, dg);
+        ldv8(dbeta + c, db);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sc[e] * (d[e] - db[e] * invM - ((xv[e] - mu[e]) * is[e]) * (dg[e] * invM));
+        st8(dx + off, o);
+    }
+}
 extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                                 const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
                                 int M, int C, int relu, float* dx, float* dres, void* stream) {
@@ -488,6 +593,12 @@ extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, cons
     UEM_REQUIRE(x && dy && scale && shift && save_mean && save_invstd && dgamma && dbeta && dx, "bn_bwd_apply_bf16: null pointer");
     UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply_bf16: bad shape");
     UEM_REQUIRE(relu == 0 || (relu == 1 && !relu_bits) || (relu == UEM_RELU_BITS && relu_bits && C % 32 == 0), "bn_bwd_apply_bf16: bad relu mode");
+    if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0) {
+        const int64_t nvec8 = (int64_t)M * C / 8;
+        bn_bwd_apply_bf16x8_kernel<<<uem_stream_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(
+            x, dy, relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec8, C, 1.0f / (float)M, relu, dx, dres);
+        return uem_check_launch("bn_bwd_apply_bf16");
+    }
     const int64_t nvec = (int64_t)M * C / 4;
     bn_bwd_apply_kernel<bf16_t><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
         x, dy, (const float*)relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
@@ -524,7 +635,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
         const size_t off = (size_t)i * 4;
         float4 d = *reinterpret_cast<const float4*>(dy + off);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-        if (relu) d = relu_mask4(d, *reinterpret_cast<const float4*>(x + off), sc, *reinterpret_cast<const float4*>(shift + c), res, off);
+        if (relu) d = relu_mask4(d, *reinterpret_cast<const float4*>(x + off), sc, *reinterpret_cast<const float4*>(shift + c), res, off, relu);
         if (dres) *reinterpret_cast<float4*>(dres + off) = d;
         d.x *= sc.x; d.y *= sc.y; d.z *= sc.z; d.w *= sc.w;
         *reinterpret_cast<float4*>(dx + off) = d;
@@ -533,6 +644,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
 extern "C" int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, const float* scale, const float* shift,
                                   int64_t M, int C, int relu, float* dx, float* dres, void* stream) {
     UEM_REQUIRE(x && dy && scale && shift && dx && M > 0 && C > 0 && (C % 4) == 0, "affine_act_bwd: bad arguments");
+    UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "affine_act_bwd: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = M * C / 4;
     affine_act_bwd_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, dy, ymask, scale, shift, nvec, C, relu, dx, dres);
     return uem_check_launch("affine_act_bwd");

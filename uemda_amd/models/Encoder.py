@@ -157,7 +157,7 @@ class Deeplabv2(nn.Module):
             return super().zero_grad(set_to_none)
         self._grad_arena.zero_()
         for p in self.parameters():
-            if p.grad is None:
+            if p.grad is None and p.requires_grad:           # a frozen parameter keeps .grad = None, as under torch autograd
                 p.grad = p._uem_grad_view()
 
     # ---- forward ----------------------------------------------------------------------------------------

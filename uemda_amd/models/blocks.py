@@ -18,7 +18,11 @@ from ..ops import UemError
 
 
 def grad_buffer(p):
-    """The tensor wgrad kernels accumulate into: p.grad, (re)attached to the flat arena when None."""
+    """The tensor wgrad kernels accumulate into: p.grad, (re)attached to the flat arena when None.  None for a frozen
+    parameter (requires_grad False: ResNetEncoder freeze_at / batchnorm_trainable, reference resnet.py:112-130): the kernels
+    skip its gradient and its .grad stays None, as under torch autograd."""
+    if not p.requires_grad:
+        return None
     if p.grad is None:
         maker = getattr(p, "_uem_grad_view", None)
         g = maker() if maker is not None else torch.zeros_like(p)
@@ -29,7 +33,10 @@ def grad_buffer(p):
 
 
 def grad_ohwi(p):
-    g = grad_buffer(p).permute(0, 2, 3, 1)
+    g = grad_buffer(p)
+    if g is None:
+        return None
+    g = g.permute(0, 2, 3, 1)
     if not g.is_contiguous():
         raise UemError("conv weight .grad is not channels_last; let the model own its gradient arena")
     return g

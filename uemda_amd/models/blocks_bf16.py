@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from .. import ops, ops_bf16 as ob
-from .blocks import _st_from, _st_tensor, grad_buffer, grad_ohwi
+from .blocks import _Link, _st_from, _st_tensor, grad_buffer, grad_ohwi
 
 
 class CastFn(Function):
@@ -49,6 +49,11 @@ class BottleneckBf16Fn(Function):
             if has_ds:
                 saved += [zd, _st_tensor(std)]
             ctx.save_for_backward(*saved)
+            # bn3's reduction pass rides in the next block's last data-gradient epilogue, the previous block's in ours
+            # (blocks._Link, same protocol as the fp32 node)
+            ctx.link_in = getattr(x, "_uem_link", None)
+            ctx.link_out = _Link(z3, bits, _st_tensor(st3))
+            y._uem_link = ctx.link_out
         return y
 
     @staticmethod
@@ -60,29 +65,53 @@ class BottleneckBf16Fn(Function):
         s, d = blk.stride, blk.dilation
         G, gb = grad_ohwi, grad_buffer
         dy = dy.contiguous()
-        # BN3 + residual + ReLU (mask = packed bits of the block output); dp = dy*mask feeds the identity / downsample path
-        dz3, dp = ob.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits, want_dres=True)
+        # BN3 + residual + ReLU.  dp = dy*[y > 0] is not materialised when the tail epilogue takes the identity gradient: bn3's
+        # backward, the downsample BatchNorm's backward and the identity path all read dy through the packed mask.
+        tail_ok = ob.dgrad_tail_ok(x.shape, x.shape[-1])
+        need_dp = not ctx.has_ds and not tail_ok
+        lo = ctx.link_out
+        # dy may be overwritten in place only when it is the buffer the next block's backward allocated for us
+        own = lo is not None and lo.dx_ptr == dy.data_ptr()
+        dp = None
+        if own and lo.tiles is not None:
+            dz3 = ob.bn_backward_from_partials(z3, dy, st3, lo.tiles, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits)
+            lo.tiles = None
+        elif need_dp:
+            dz3, dp = ob.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits, want_dres=True)
+        else:
+            dz3 = ob.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits)
         ob.conv2d_wgrad(a2, dz3, G(blk.conv3.weight))
-        da2 = ob.conv2d_dgrad(dz3, ob.weight_t(blk.conv3.weight), a2.shape)
+        dz2 = ob.conv2d_dgrad_bn_backward(dz3, ob.weight_t(blk.conv3.weight), z2, st2, gb(blk.bn2.weight), gb(blk.bn2.bias))
         del dz3
-        dz2 = ob.bn_backward(z2, da2, st2, gb(blk.bn2.weight), gb(blk.bn2.bias), relu=1)
-        del da2
         ob.conv2d_wgrad(a1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d)
-        da1 = ob.conv2d_dgrad(dz2, ob.weight_t(blk.conv2.weight), a1.shape, stride=s, pad=d, dil=d)
+        dz1 = ob.conv2d_dgrad_bn_backward(dz2, ob.weight_t(blk.conv2.weight), z1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias),
+                                          stride=s, pad=d, dil=d)
         del dz2
-        dz1 = ob.bn_backward(z1, da1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), relu=1)
-        del da1
         ob.conv2d_wgrad(x, dz1, G(blk.conv1.weight))
         wt1 = ob.weight_t(blk.conv1.weight)
+        li = ctx.link_in
+        fuse = li is not None and li.z3.shape == x.shape and tail_ok
+        bn_args = dict(bn_z=li.z3, bn_vec=li.vec, bn_bits=li.bits) if fuse else {}
+        tp = None
         if ctx.has_ds:
             zd, std = sv[10], _st_from(sv[11])
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
-            dzd = ob.bn_backward(zd, dp, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=0)
+            dzd = ob.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=2, bits=bits, dx=dy if own else None)
             ob.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s)
-            dx = ob.conv2d_dgrad(dz1, wt1, x.shape)
-            ob.conv2d_dgrad(dzd, ob.weight_t(ds_conv.weight), x.shape, stride=s, out=dx, accumulate=True)
+            wtd = ob.weight_t(ds_conv.weight)
+            if s == 1 and tail_ok:
+                dx = ob.conv2d_dgrad(dzd, wtd, x.shape)
+                dx, tp = ob.conv2d_dgrad_tail(dz1, wt1, x.shape, out=dx, accumulate=True, **bn_args)
+            else:
+                # strided downsample: its data gradient reaches one pixel in four, so it goes second (accumulating)
+                dx = ob.conv2d_dgrad(dz1, wt1, x.shape)
+                ob.conv2d_dgrad(dzd, wtd, x.shape, stride=s, out=dx, accumulate=True)
+        elif tail_ok:
+            dx, tp = ob.conv2d_dgrad_tail(dz1, wt1, x.shape, acc_src=dy, acc_bits=bits, out=dy if own else None, **bn_args)
         else:
             dx = ob.conv2d_dgrad(dz1, wt1, x.shape, out=dp, accumulate=True)      # identity gradient + conv1's
+        if li is not None:
+            li.tiles, li.dx_ptr = tp, dx.data_ptr()
         cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
         if cb is not None:
             cb()

@@ -297,7 +297,10 @@ def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, ymask_bits, 
 
 def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
                  algo_cout=None):
-    """dw (Cout,KH,KW,Cin) += dy^T * im2col(prologue(x)).  dw must be contiguous (atomics land in it)."""
+    """dw (Cout,KH,KW,Cin) += dy^T * im2col(prologue(x)).  dw must be contiguous (atomics land in it); None (a frozen
+    weight, blocks.grad_ohwi) skips the launch."""
+    if dw_ohwi is None:
+        return
     need_gpu(x, dy, dw_ohwi)
     _f32c(x, "wgrad x"), _f32c(dy, "wgrad dy"), _f32c(dw_ohwi, "wgrad dw")
     cout, kh, kw, cin = dw_ohwi.shape
@@ -360,6 +363,8 @@ def stem_conv(x4, w_ohwi):
 
 
 def stem_wgrad(x4, dy, dw_ohwi):
+    if dw_ohwi is None:                      # frozen stem (freeze_at >= 1)
+        return
     n, h, w, _ = x4.shape
     dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
     PROF.run("conv_wgrad", 2.0 * dy.numel() * 147,
@@ -395,7 +400,7 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=BN_EPS, mo
              ptr(running_var), ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), ptr(ws), stream())
     else:
         call("uem_bn_eval_affine", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps,
-             ptr(st.scale), ptr(st.shift), C, stream())
+             ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), C, stream())
     return st
 
 
@@ -427,8 +432,17 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None
         call("uem_bn_bwd_apply", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
              ptr(st.invstd), ptr(tmp[0]), ptr(tmp[1]), M, C, int(relu), ptr(dx), ptr(dres), stream())
     else:
-        # frozen statistics (eval-mode BN inside a graph): dx = dp * scale; dgamma/dbeta via the reduce
-        raise UemError("backward through eval-mode BatchNorm is not supported (reference never does it)")
+        # frozen statistics (eval-mode BatchNorm inside a training graph: ResNetEncoder batchnorm_trainable=False, reference
+        # resnet.py:112-117,183-190): y = x*scale + shift with constant scale / shift, so dx = dp*scale; gamma / beta, when they
+        # are still trainable, get sum dp*xhat / sum dp with xhat taken from the running statistics
+        if gamma_grad is not None or beta_grad is not None:
+            tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
+            ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+            call("uem_bn_bwd_reduce", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), ptr(st.mean),
+                 ptr(st.invstd), M, C, int(relu), ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws),
+                 stream())
+        call("uem_affine_act_bwd", ptr(x), ptr(dy), ptr(ymask), ptr(st.scale), ptr(st.shift), M, C, int(relu), ptr(dx),
+             ptr(dres), stream())
     return dx
 
 

@@ -57,8 +57,53 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     return out
 
 
+def dgrad_tail_ok(x_shape, cin):
+    n, h, w, _ = x_shape
+    return (n * h * w) % 128 == 0 and cin % 64 == 0 and ops.FUSE_BN_BACKWARD
+
+
+def conv2d_dgrad_tail(dy, w_t, x_shape, acc_src=None, acc_bits=None, out=None, accumulate=False, bn_z=None, bn_vec=None, bn_bits=None,
+                      pad=None, dil=1):
+    """ops.conv2d_dgrad_tail on bf16 tensors (stride-1 data gradient with the residual bookkeeping and / or the first pass of
+    a BatchNorm backward in its epilogue) -> (dx, per-tile partial sums or None)."""
+    need_gpu(dy, w_t)
+    _bf16c(dy, "dgrad_bf16 dy"), _bf16c(w_t, "dgrad_bf16 w_t")
+    cin, kh, kw, cout = w_t.shape
+    n, h, w, _ = x_shape
+    s = ConvShape()
+    s.N, s.H, s.W, s.Cin = n, h, w, cin
+    s.Ho, s.Wo, s.Cout = dy.shape[1], dy.shape[2], cout
+    s.KH, s.KW, s.stride, s.pad, s.dil = kh, kw, 1, (dil * (kh - 1) // 2 if pad is None else pad), dil
+    s.x_ld, s.y_ld = cin, cout
+    if out is None:
+        out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.bfloat16)
+    M = n * h * w
+    tp = torch.empty((M // 128, 2, cin), device=dy.device, dtype=torch.float32) if bn_z is not None else None
+    flops = 2.0 * n * dy.shape[1] * dy.shape[2] * cout * kh * kw * cin
+    ops.PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_dgrad_tail_bf16", ptr(dy), ptr(w_t), ptr(out), ctypes.byref(s), ptr(acc_src),
+                                                   ptr(acc_bits), ptr(bn_z), ptr(bn_vec), ptr(bn_bits), ptr(tp),
+                                                   CONV_ACCUMULATE if accumulate else 0, stream()))
+    return out, tp
+
+
+def conv2d_dgrad_bn_backward(dy, w_t, z, st, gamma_grad, beta_grad, stride=1, pad=0, dil=1):
+    """dA = dgrad(dy) for the conv that consumed relu(bn(z)), then that BatchNorm+ReLU's backward -> dz (in dA's buffer); the
+    reduction pass rides in the data-gradient epilogue when the conv has stride 1 and full tiles."""
+    cin, kh, kw, cout = w_t.shape
+    if stride != 1 or not dgrad_tail_ok(z.shape, cin):
+        da = conv2d_dgrad(dy, w_t, z.shape, stride=stride, pad=pad, dil=dil)
+        return bn_backward(z, da, st, gamma_grad, beta_grad, relu=1, dx=da)
+    vec = st.scale._base
+    if vec is None or vec.shape != (4, cin):
+        raise UemError("conv2d_dgrad_bn_backward: BNState vectors must live in one (4, C) buffer")
+    da, tp = conv2d_dgrad_tail(dy, w_t, z.shape, bn_z=z, bn_vec=vec, pad=pad, dil=dil)
+    return bn_backward_from_partials(z, da, st, tp, gamma_grad, beta_grad, relu=1, dx=da)
+
+
 def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1):
     """dw (Cout,KH,KW,Cin) fp32 += dy^T * im2col(x) with bf16 x (N,H,W,Cin) and dy (N,Ho,Wo,Cout)."""
+    if dw_ohwi is None:                      # frozen weight (blocks.grad_ohwi)
+        return
     need_gpu(x, dy, dw_ohwi)
     _bf16c(x, "wgrad_bf16 x"), _bf16c(dy, "wgrad_bf16 dy")
     if dw_ohwi.dtype != torch.float32 or not dw_ohwi.is_contiguous():
@@ -167,17 +212,29 @@ def affine_act(x, st, res=None, res_st=None, relu=True, want_bits=False):
     return (out, bits) if want_bits else out
 
 
-def bn_backward(x, dy, st, gamma_grad, beta_grad, relu, bits=None, want_dres=False):
+def bn_backward(x, dy, st, gamma_grad, beta_grad, relu, bits=None, want_dres=False, dx=None):
     """BatchNorm(+ReLU) backward on bf16 tensors.  relu: 0 none, 1 mask recomputed from x, 2 packed bits.
-    Returns dx (new bf16 tensor) [, dres = dy*mask]."""
+    Returns dx (a new bf16 tensor unless given; may alias dy) [, dres = dy*mask]."""
     C = x.shape[-1]
     M = x.numel() // C
     tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
     ws = torch.empty(ops._lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
     call("uem_bn_bwd_reduce_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), M, C,
          int(relu), ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws), stream())
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if dx is None else dx
     dres = torch.empty_like(x) if want_dres else None
     call("uem_bn_bwd_apply_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
          ptr(tmp[0]), ptr(tmp[1]), M, C, int(relu), ptr(dx), ptr(dres), stream())
     return (dx, dres) if want_dres else dx
+
+
+def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, relu, bits=None, dx=None):
+    """BatchNorm backward whose reduction pass already ran in a data-gradient epilogue (tp = its per-tile partial sums)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
+    call("uem_bn_bwd_from_tiles", ptr(tp), tp.shape[0], C, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
+    dx = torch.empty_like(x) if dx is None else dx
+    call("uem_bn_bwd_apply_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         ptr(tmp[0]), ptr(tmp[1]), M, C, int(relu), ptr(dx), None, stream())
+    return dx

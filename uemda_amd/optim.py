@@ -52,6 +52,22 @@ class FusedSGD(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.model.zero_grad()
 
+    def _trainable_ranges(self, n):
+        """[(offset, count)] runs of the flat arena that belong to trainable parameters: the whole arena unless something is frozen."""
+        params = self.param_groups[0]["params"]
+        if all(p.requires_grad for p in params):
+            return [(0, n)]
+        runs = []
+        for p in params:
+            if not p.requires_grad:
+                continue
+            off, cnt = p._uem_off, p.numel()
+            if runs and runs[-1][0] + runs[-1][1] == off:
+                runs[-1] = (runs[-1][0], runs[-1][1] + cnt)
+            else:
+                runs.append((off, cnt))
+        return runs
+
     @torch.no_grad()
     def step(self, closure=None, max_norm=None, grad_prescale=1.0):
         g = self.param_groups[0]
@@ -60,8 +76,11 @@ class FusedSGD(torch.optim.Optimizer):
         if max_norm is not None:
             norm = grad_norm(self.model)
             self.last_grad_norm = norm
-        call("uem_sgd_clip_step", ptr(arena), ptr(garena), ptr(self.momentum_buffer), n, ptr(norm),
-             float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(g["momentum"]),
-             float(g["weight_decay"]), 1 if self._steps == 0 else 0, float(grad_prescale), stream())
+        for off, cnt in self._trainable_ranges(n):
+            # frozen parameters (requires_grad False: ResNetEncoder freeze_at / batchnorm_trainable) are skipped altogether, as
+            # torch.optim.SGD skips a parameter whose .grad is None -- no weight decay, no momentum
+            call("uem_sgd_clip_step", ptr(arena) + 4 * off, ptr(garena) + 4 * off, ptr(self.momentum_buffer) + 4 * off, cnt, ptr(norm),
+                 float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(g["momentum"]),
+                 float(g["weight_decay"]), 1 if self._steps == 0 else 0, float(grad_prescale), stream())
         self._steps += 1
         ops.weights_changed()

@@ -100,14 +100,17 @@ class ResNetEncoder(nn.Module):
             raise ValueError('output_stride must be 8, 16 or 32.')               # resnet.py:48-51
         if cfg.resnet_type not in _LAYERS:
             raise UemError(f"resnet_type {cfg.resnet_type!r} not supported (resnet50 / resnet101)")
-        if cfg.freeze_at != 0 or not cfg.batchnorm_trainable or any(cfg.with_cp):
-            raise UemError("freeze_at / frozen BN / checkpointing are not used by the UemDA scripts; not implemented")
+        if len(tuple(cfg.with_cp)) != 4:
+            raise UemError("with_cp takes four flags, one per residual layer")
         self.resnet = ResNet(_LAYERS[cfg.resnet_type])
         if isinstance(cfg.pretrained, str):
             # no network on the box: a local torchvision-format checkpoint path may be given instead of True
             sd = torch.load(cfg.pretrained, map_location="cpu")
             sd = sd.get("state_dict", sd)
             self.resnet.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+        if not cfg.batchnorm_trainable:                                          # resnet.py:57-58
+            self._frozen_res_bn()
+        self._freeze_at(cfg.freeze_at)                                           # resnet.py:60
         if cfg.output_stride == 16:                                              # resnet.py:62-63
             self.resnet.layer4.apply(partial(self._nostride_dilate, dilate=2))
         elif cfg.output_stride == 8:
@@ -126,6 +129,56 @@ class ResNetEncoder(nn.Module):
                 m.dilation = (dilate, dilate)
                 m.padding = (dilate, dilate)
 
+    def _frozen_res_bn(self):                                                   # resnet.py:112-117
+        """Every BatchNorm of the encoder: parameters frozen, running statistics used (eval mode) also while training."""
+        for m in self.resnet.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                for p in m.parameters():
+                    p.requires_grad = False
+                m.eval()
+
+    def _freeze_at(self, at=2):                                                 # resnet.py:119-130
+        """Freeze the parameters of the stem (at >= 1) and of layer1 .. layer4 (at >= 2 .. 5): no gradient is computed for
+        them (blocks.grad_buffer), the optimizer leaves them alone (FusedSGD._trainable_ranges), and the backward pass stops at
+        the first trainable layer.  Their BatchNorms still normalise with batch statistics and update the running ones,
+        as in the reference (freeze_params touches requires_grad only)."""
+        r = self.resnet
+        frozen = [[r.conv1, r.bn1], [r.layer1], [r.layer2], [r.layer3], [r.layer4]][:max(0, min(int(at), 5))]
+        for group in frozen:
+            for m in group:
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def train(self, mode=True):                                                 # resnet.py:183-190
+        super().train(mode)
+        self._freeze_at(self.config.freeze_at)
+        if mode and not self.config.batchnorm_trainable:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def _run_layer(self, layer, y, with_cp):
+        """One residual layer; with_cp: under torch.utils.checkpoint as the reference does (resnet.py:146-165) -- only the
+        layer input is kept, the layer's forward runs again inside backward.  As there, the second run updates the
+        BatchNorm running statistics (and num_batches_tracked) a second time."""
+        def run(t):
+            if torch.is_grad_enabled():                   # the re-run inside backward: torch's BatchNorm would count it
+                for m in layer.modules():
+                    if isinstance(m, nn.BatchNorm2d) and m.training and getattr(m, "_uem_nbt_arena", False):
+                        m.num_batches_tracked.add_(1)
+            for blk in layer:
+                t = blk(t)
+            return t
+        if with_cp and y.requires_grad:
+            if y.dtype != torch.float32:
+                raise UemError("with_cp runs on the fp32 storage path")
+            import torch.utils.checkpoint as cp
+            return cp.checkpoint(run, y, use_reentrant=True)
+        for blk in layer:
+            y = blk(y)
+        return y
+
     # "fp32" (default, the parity path) or "bf16": activations between the max-pool and the layer4 output stored in bf16,
     # bf16 matrix cores with fp32 accumulation, fp32 master weights (BASELINE config 5; training mode only)
     storage = "fp32"
@@ -139,9 +192,8 @@ class ResNetEncoder(nn.Module):
             from .models.blocks_bf16 import CastFn
             y = CastFn.apply(y, True)
         outs = []
-        for layer in (r.layer1, r.layer2, r.layer3, r.layer4):
-            for blk in layer:
-                y = blk(y)
+        for layer, with_cp in zip((r.layer1, r.layer2, r.layer3, r.layer4), self.config.with_cp):
+            y = self._run_layer(layer, y, with_cp)
             outs.append(y)
         if bf16:
             outs[-1] = CastFn.apply(outs[-1], False)       # InstanceNorm and the heads stay fp32
