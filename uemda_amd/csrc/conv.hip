@@ -92,8 +92,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) bv4 = *reinterpret_cast<const float4*>(p.bias + n0 + sc4);
-        float cs1 = 0.f, cs2 = 0.f;                     // column tid of the tile (threads < BN)
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;   // fused BN-backward partials (MODE 1)
+        // per-thread column partials over this thread's rows (4 columns): BatchNorm statistics sum y / sum y*y (forward) or
+        // the BatchNorm-backward partials sum dp / sum dp*xhat (data gradient); combined across thread rows at the end
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;
 #pragma unroll
         for (int hm = 0; hm < 2; ++hm) {
             if (wm / 64 == hm) {
@@ -140,6 +141,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                         if (MODE == 1 && p.tile_bnbwd != nullptr) *reinterpret_cast<float4*>(&stg[row * LDW + sc4]) = v;
                     }
                     *reinterpret_cast<float4*>(p.y + row_off(m0 + hm * 64 + row) + n0 + sc4) = v;
+                    if (MODE != 1 && p.tile_stats != nullptr) {
+                        bb.x += v.x; bb.y += v.y; bb.z += v.z; bb.w += v.w;
+                        bg.x = fmaf(v.x, v.x, bg.x); bg.y = fmaf(v.y, v.y, bg.y); bg.z = fmaf(v.z, v.z, bg.z); bg.w = fmaf(v.w, v.w, bg.w);
+                    }
                 }
             }
             if (MODE == 1 && p.tile_bnbwd != nullptr) {
@@ -173,37 +178,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                     }
                 }
             }
-            if (p.tile_stats != nullptr && tid < BN) {
-#pragma unroll 8
-                for (int row = 0; row < 64; ++row) {
-                    const float v = stg[row * LDW + tid];
-                    cs1 += v;
-                    cs2 += v * v;
-                }
-            }
             __syncthreads();
         }
-        if (p.tile_stats != nullptr && tid < BN) {
-            // channel-major [2][Cout][tiles]: the per-channel finalize then streams contiguous rows
-            const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
-            float* ts = p.tile_stats + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
-            ts[0] = cs1;
-            ts[(size_t)p.Cout * tiles_m] = cs2;
-        }
-        if (MODE == 1 && p.tile_bnbwd != nullptr) {
-            // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again)
+        float* const tile_out = (MODE == 1) ? p.tile_bnbwd : p.tile_stats;
+        if (tile_out != nullptr) {
+            // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again); channel-major
+            // [2][Cout][tiles] output, so the per-channel finalize streams contiguous rows
             float* red = stg;                           // [2][RPP][BN]
             *reinterpret_cast<float4*>(&red[(0 * RPP + srow) * BN + sc4]) = bb;
             *reinterpret_cast<float4*>(&red[(1 * RPP + srow) * BN + sc4]) = bg;
             __syncthreads();
-            if (tid < BN) {
-                float b = 0.f, g = 0.f;
+            if (tid < 2 * BN) {
+                const int which = tid / BN, col = tid % BN;
+                float a = 0.f;
 #pragma unroll
-                for (int q = 0; q < RPP; ++q) { b += red[(0 * RPP + q) * BN + tid]; g += red[(1 * RPP + q) * BN + tid]; }
+                for (int q = 0; q < RPP; ++q) a += red[(which * RPP + q) * BN + col];
                 const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
-                float* tb = p.tile_bnbwd + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
-                tb[0] = b;
-                tb[(size_t)p.Cout * tiles_m] = g;
+                tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
             }
         }
         return;
@@ -882,7 +873,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     constexpr int LDW = BN + 4, TPR = BN / 8, RPP = 256 / TPR, NRP = 64 / RPP;
     float* const stg = smem;
     const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
-    float cs1 = 0.f, cs2 = 0.f;
     // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
     // backward over the rounded dx (same contract as the fp32 kernel's epilogue, bf16 tensors)
     const bool fuse_bn = MODE == 1 && p.tile_bnbwd != nullptr;
@@ -983,9 +973,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 v[2 * e] = bf2f((unsigned short)lo); v[2 * e + 1] = bf2f((unsigned short)hi);
             }
             *reinterpret_cast<uint4*>(yh + row_off(m0 + hm * 64 + row) + n0 + sc8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            if (p.tile_stats != nullptr) {                               // statistics of what was stored
-                *reinterpret_cast<float4*>(&stg[row * LDW + sc8]) = *reinterpret_cast<const float4*>(&v[0]);
-                *reinterpret_cast<float4*>(&stg[row * LDW + sc8 + 4]) = *reinterpret_cast<const float4*>(&v[4]);
+            if (MODE == 0 && p.tile_stats != nullptr) {                  // BatchNorm statistics of what was stored (rounded)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pb[e] += v[e]; pg[e] = fmaf(v[e], v[e], pg[e]); }
             }
             if (fuse_bn) {
                 const unsigned z4[4] = {zq[u].x, zq[u].y, zq[u].z, zq[u].w};
@@ -999,20 +989,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 }
             }
         }
-        if (p.tile_stats != nullptr) {
-            __syncthreads();
-            if (tid < BN) {
-#pragma unroll 8
-                for (int row = 0; row < 64; ++row) {
-                    const float v = stg[row * LDW + tid];
-                    cs1 += v;
-                    cs2 += v * v;
-                }
-            }
-        }
         __syncthreads();
     }
-    if (fuse_bn) {                                                       // column sums over the tile's 128 rows
+    float* const tile_out = fuse_bn ? p.tile_bnbwd : (MODE == 0 ? p.tile_stats : nullptr);
+    if (tile_out != nullptr) {                                           // column sums over the tile's 128 rows
+        // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
         float* const red = stg;                                          // [2][RPP][BN]
 #pragma unroll
         for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; }
@@ -1023,14 +1004,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
 #pragma unroll 8
             for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + col];
             const size_t tiles_m = (size_t)(p.M / BM);
-            p.tile_bnbwd[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
+            tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
         }
-    }
-    if (p.tile_stats != nullptr && tid < BN) {
-        const size_t tiles_m = (size_t)((p.M + BM - 1) / BM);
-        float* ts = p.tile_stats + (size_t)(n0 + tid) * tiles_m + (size_t)(m0 / BM);
-        ts[0] = cs1;
-        ts[(size_t)p.Cout * tiles_m] = cs2;
     }
 }
 
