@@ -752,7 +752,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {                  // RN
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-template <int BN, int MODE>
+// EPI: the epilogue the launch needs, fixed at compile time -- on the small-K layers a block's time is instruction issue, and an
+// epilogue that tests its options per row keeps the compiler from batching the LDS reads, conversions and stores:
+//   0  full dense tiles, plain store;  1  full dense tiles + BatchNorm tile statistics (forward) / the residual tail and
+//   BatchNorm-backward options (data gradient);  -1  anything (ragged last tile, strided output rows, accumulate in forward)
+template <int BN, int MODE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
     using C = ConvBf16Cfg<BN>;
     constexpr int WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32, BR = BN / 32;
@@ -770,8 +774,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
     (void)xh;
 
+    // pointwise layers (1x1, stride 1, no padding: two thirds of a ResNet's launches): output pixel m reads input pixel m, no
+    // per-row divisions and no bounds tests besides m < M -- the index arithmetic below is most of a small-K block's instructions
+    const bool pointwise = p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
     int gy[4], gx[4], gpix[4];
-    {
+    if (pointwise) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gy[j] = gx[j] = 0; gpix[j] = (m0 + lrow + 32 * j < p.M) ? m0 + lrow + 32 * j : -1; }
+    } else {
         const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
         const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
@@ -790,6 +800,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     int lt = 0, lci0 = 0;
     unsigned tapok = 0, aoff[4], boff[BR];
     auto setup_tap = [&](int t) {
+        if (pointwise) {
+            tapok = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                aoff[j] = ((unsigned)gpix[j] * (unsigned)p.x_ld + (unsigned)lc8) * 2u;
+                tapok |= (gpix[j] >= 0 ? 1u : 0u) << j;
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) boff[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)lc8) * 2u;
+            return;
+        }
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
         const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);
         const int kx = tap - ky * p.KW;
@@ -827,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const int sw = (fr >> 1) & 7;
 
     auto step = [&](unsigned short* __restrict__ fill, const unsigned short* __restrict__ use, const bool do_issue, const bool do_phase) {
-        if (do_issue) {
+        if (do_issue && !(p.dbg & 4)) {
             unsigned short* const As = fill;
             unsigned short* const Bs = fill + C::A_ELEMS;
             if (lci0 == 0) setup_tap(lt);
@@ -862,7 +883,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    const bool dense_rows = !(MODE == 1 && p.sub > 1);
+    constexpr bool FULL = EPI >= 0;
+    const bool dense_rows = FULL || !(MODE == 1 && p.sub > 1);
     auto row_off = [&](const int m) -> size_t {
         if (dense_rows) return (size_t)m * p.y_ld;
         const int hw = p.Hs * p.Ws;
@@ -875,7 +897,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
     // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
     // backward over the rounded dx (same contract as the fp32 kernel's epilogue, bf16 tensors)
-    const bool fuse_bn = MODE == 1 && p.tile_bnbwd != nullptr;
+    const bool fuse_bn = MODE == 1 && EPI != 0 && p.tile_bnbwd != nullptr;
+    const bool acc_on = (EPI == 0 || (EPI == 1 && MODE == 0)) ? false : p.accumulate != 0;
+    const bool stats_on = MODE == 0 && (EPI == 1 || (EPI < 0 && p.tile_stats != nullptr));
+    const bool ablate_store = EPI < 0 && (p.dbg & 1), ablate_stage = EPI < 0 && (p.dbg & 2);
     const unsigned short* const zh = reinterpret_cast<const unsigned short*>(p.bn_z);
     const unsigned short* const ah = p.acc_src != nullptr ? reinterpret_cast<const unsigned short*>(p.acc_src) : yh;
     float pb[8], pg[8], bsc[8], bsh[8], bmu[8], bis[8];
@@ -895,8 +920,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         for (int u = 0; u < NRP; ++u) {
             const int m = m0 + hm * 64 + srow + u * RPP;
             eab[hm][u] = 0xffu; ebb[hm][u] = 0u;
-            if (m >= p.M) continue;
-            if (p.accumulate) eo[hm][u] = *reinterpret_cast<const uint4*>(ah + row_off(m) + n0 + sc8);
+            if (!FULL && m >= p.M) continue;
+            if (acc_on) eo[hm][u] = *reinterpret_cast<const uint4*>(ah + row_off(m) + n0 + sc8);
             if (MODE == 1) {
                 const size_t e0 = (size_t)m * p.Cout + n0 + sc8;           // dense rows whenever bits / bn_z are given
                 if (p.acc_bits != nullptr) eab[hm][u] = (p.acc_bits[e0 >> 5] >> (e0 & 31)) & 0xffu;
@@ -907,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             }
         }
     };
-    epi_fetch(0);
+    if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
 #define CONV_SYNC()                                                 \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
     __builtin_amdgcn_s_barrier();                                   \
@@ -930,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {
-        if (wm / 64 == hm) {
+        if (wm / 64 == hm && !ablate_stage) {
             const int rbase = wm % 64;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -941,10 +966,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                         stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
         }
         __syncthreads();
-        if (hm == 0) epi_fetch(1);
+        if (hm == 0 && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(1);
         bool rok[NRP];
 #pragma unroll
-        for (int u = 0; u < NRP; ++u) rok[u] = m0 + hm * 64 + srow + u * RPP < p.M;
+        for (int u = 0; u < NRP; ++u) rok[u] = FULL || m0 + hm * 64 + srow + u * RPP < p.M;
         const uint4 (&o)[NRP] = eo[hm];
         const uint4 (&zq)[NRP] = ez[hm];
         const unsigned (&abyte)[NRP] = eab[hm];
@@ -956,7 +981,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             float v[8];
             *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8]);
             *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8 + 4]);
-            if (p.accumulate) {
+            if (acc_on) {
                 const unsigned w4[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -972,8 +997,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 pk[e] = lo | (hi << 16);
                 v[2 * e] = bf2f((unsigned short)lo); v[2 * e + 1] = bf2f((unsigned short)hi);
             }
-            *reinterpret_cast<uint4*>(yh + row_off(m0 + hm * 64 + row) + n0 + sc8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            if (MODE == 0 && p.tile_stats != nullptr) {                  // BatchNorm statistics of what was stored (rounded)
+            if (!ablate_store) *reinterpret_cast<uint4*>(yh + row_off(m0 + hm * 64 + row) + n0 + sc8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (stats_on) {                                              // BatchNorm statistics of what was stored (rounded)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { pb[e] += v[e]; pg[e] = fmaf(v[e], v[e], pg[e]); }
             }
@@ -991,7 +1016,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         }
         __syncthreads();
     }
-    float* const tile_out = fuse_bn ? p.tile_bnbwd : (MODE == 0 ? p.tile_stats : nullptr);
+    float* const tile_out = fuse_bn ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
     if (tile_out != nullptr) {                                           // column sums over the tile's 128 rows
         // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
         float* const red = stg;                                          // [2][RPP][BN]
@@ -1778,14 +1803,22 @@ extern "C" int uem_aspp_gather_bwd(const float* dout, float* dG, int N, int h, i
 // =========================================================================================================
 // bf16-storage entry points (BASELINE config 5)
 // =========================================================================================================
-template <int BN_, int MODE>
-static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+template <int BN_, int MODE, int EPI>
+static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
     using C = ConvBf16Cfg<BN_>;
     const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
-    auto k = conv_bf16_kernel<BN_, MODE>;
+    auto k = conv_bf16_kernel<BN_, MODE, EPI>;
     static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     (void)attr;
     k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
+}
+template <int BN_, int MODE>
+static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+    const bool full = p.M % BM == 0 && (MODE == 0 || p.sub == 1) && p.dbg == 0;
+    const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
+    if (!full || (MODE == 0 && p.accumulate)) conv_bf16_launch<BN_, MODE, -1>(p, xb, wb, st);
+    else if (extras) conv_bf16_launch<BN_, MODE, 1>(p, xb, wb, st);
+    else conv_bf16_launch<BN_, MODE, 0>(p, xb, wb, st);
 }
 struct BnBwdFuseH { const uint16_t* z; const float* vec; float* tiles; const uint16_t* acc_src; const uint32_t* acc_bits; const uint32_t* bn_bits; };
 static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags, float* tile_stats,
@@ -1824,7 +1857,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
     p.x = (const float*)x; p.w = (const float*)w; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = (float*)y;
     p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0; p.relu = 0;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = g_conv_dbg;
     p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     if (fuse != nullptr) {
         p.bn_z = (const float*)fuse->z; p.bn_vec = fuse->vec; p.tile_bnbwd = fuse->tiles;
