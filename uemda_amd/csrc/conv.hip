@@ -12,6 +12,7 @@
 // floats (k contiguous, 16-B pad) read with ds_read_b128 (conflict-free).
 // Replaces cuDNN behind nn.Conv2d: reference _resnets.py:95-110,149,209; Encoder.py:19,35-36,40,74-75.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,14 +64,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // Accumulators -> global memory (shared by the register-staged and the LDS-DMA main loops): C/D layout
 // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `smem` must be free (every wave past its last operand read).
-template <int BN, int WM, int WN, int MODE>
+// EPI fixes the epilogue's options at compile time where the launcher knows them (conv_dma_go): 0 = full dense tiles, plain
+// store; 1 = full dense tiles with BatchNorm tile statistics (forward) / the residual-tail and BatchNorm-backward options
+// (data gradient); -1 = everything tested at run time (bias, ragged tiles, strided rows, forward accumulate).
+template <int BN, int WM, int WN, int MODE, int EPI = -1>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const int m0, const int n0) {
     constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+    constexpr bool FULL = EPI >= 0;
+    const bool acc_on = (EPI == 0 || (EPI == 1 && MODE != 1)) ? false : p.accumulate != 0;
+    const bool stats_on = MODE != 1 && (EPI == 1 || (EPI < 0 && p.tile_stats != nullptr));
+    const bool bnbwd_on = MODE == 1 && EPI != 0 && p.tile_bnbwd != nullptr;
+    const float* const bias = FULL ? nullptr : p.bias;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
-    const bool dense_rows = !(MODE == 1 && p.sub > 1);
+    const bool dense_rows = FULL || !(MODE == 1 && p.sub > 1);
     // strided data gradient (one launch per output-parity class): GEMM row m is pixel (sub*yy + py, sub*xx + px) of its image,
     // so a staged row still leaves as 16-byte stores, only its base offset is computed per row
     auto row_off = [&](const int m) -> size_t {
@@ -80,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
         return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
     };
-    if ((dense_rows || (p.tile_stats == nullptr && p.tile_bnbwd == nullptr)) && m0 + BM <= p.M && n0 + BN <= p.Cout) {
+    if (FULL || ((dense_rows || (p.tile_stats == nullptr && p.tile_bnbwd == nullptr)) && m0 + BM <= p.M && n0 + BN <= p.Cout)) {
         // Full tile: the accumulators go through LDS (the operand stages are dead now) in two 64-row halves and
         // leave as 16-byte stores, 32 lanes per 512-B row segment.  (64 dword stores per lane made the epilogue
         // store-issue bound on the small-K layers.)  The staged half is also where the fused BatchNorm statistics
@@ -91,7 +100,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         float* const stg = smem;                        // 64 x LDW floats <= the A+B stages
         const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
         float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv4 = *reinterpret_cast<const float4*>(p.bias + n0 + sc4);
+        if (bias) bv4 = *reinterpret_cast<const float4*>(bias + n0 + sc4);
         // per-thread column partials over this thread's rows (4 columns): BatchNorm statistics sum y / sum y*y (forward) or
         // the BatchNorm-backward partials sum dp / sum dp*xhat (data gradient); combined across thread rows at the end
         float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;
@@ -116,7 +125,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
             for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
                 float4 o[RB];
                 uint32_t ob[RB];
-                if (p.accumulate) {
+                if (acc_on) {
                     const float* const asrc = p.acc_src ? p.acc_src : p.y;
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
@@ -130,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                     const int row = srow + (rp0 + u) * RPP;
                     float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
                     v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
-                    if (p.accumulate) {
+                    if (acc_on) {
                         if (p.acc_bits) {
                             const uint32_t m = ob[u];
                             o[u].x = (m & 1u) ? o[u].x : 0.f; o[u].y = (m & 2u) ? o[u].y : 0.f;
@@ -138,16 +147,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                         }
                         v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w;
                         // the fused BatchNorm reduction below works on the FINAL gradient
-                        if (MODE == 1 && p.tile_bnbwd != nullptr) *reinterpret_cast<float4*>(&stg[row * LDW + sc4]) = v;
+                        if (bnbwd_on) *reinterpret_cast<float4*>(&stg[row * LDW + sc4]) = v;
                     }
                     *reinterpret_cast<float4*>(p.y + row_off(m0 + hm * 64 + row) + n0 + sc4) = v;
-                    if (MODE != 1 && p.tile_stats != nullptr) {
+                    if (stats_on) {
                         bb.x += v.x; bb.y += v.y; bb.z += v.z; bb.w += v.w;
                         bg.x = fmaf(v.x, v.x, bg.x); bg.y = fmaf(v.y, v.y, bg.y); bg.z = fmaf(v.z, v.z, bg.z); bg.w = fmaf(v.w, v.w, bg.w);
                     }
                 }
             }
-            if (MODE == 1 && p.tile_bnbwd != nullptr) {
+            if (bnbwd_on) {
                 // each thread owns 4 columns x (64/RPP) rows of this half: accumulate dbeta / dgamma partials
                 const float4 sc = *reinterpret_cast<const float4*>(p.bn_vec + n0 + sc4);
                 const float4 sh = *reinterpret_cast<const float4*>(p.bn_vec + p.Cout + n0 + sc4);
@@ -180,7 +189,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
             }
             __syncthreads();
         }
-        float* const tile_out = (MODE == 1) ? p.tile_bnbwd : p.tile_stats;
+        float* const tile_out = bnbwd_on ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
         if (tile_out != nullptr) {
             // RPP thread rows hold partials of the same 4 columns: combine through LDS (stg is free again); channel-major
             // [2][Cout][tiles] output, so the per-channel finalize streams contiguous rows
@@ -539,7 +548,7 @@ struct ConvDmaCfg {
 
 // MODE 0 forward / 1 data gradient; AFFINE: BatchNorm affine + ReLU on the input operand; PADDED: the filter has taps
 // that can fall outside the image (only then does the affine path need the validity words)
-template <int BN, int KB, int MODE, bool AFFINE, bool PADDED>
+template <int BN, int KB, int MODE, bool AFFINE, bool PADDED, int EPI>
 __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
     using C = ConvDmaCfg<BN, KB>;
     constexpr int CPR = C::CPR, RPT = C::RPT, AR = C::AR, BR = C::BR;
@@ -562,8 +571,13 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kerne
     const int lc4 = ((tid % CPR) ^ ((lrow >> SWS) & (CPR - 1))) * 4;     // swizzled source chunk (floats) of this lane
     const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
 
+    // pointwise layers (1x1, stride 1: output pixel m reads input pixel m) skip the per-row divisions and bounds tests
+    const bool pointwise = !PADDED && p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
     int gy[AR], gx[AR], gpix[AR];                                        // gather geometry of this lane's A rows
-    {
+    if (pointwise) {
+#pragma unroll
+        for (int j = 0; j < AR; ++j) { gy[j] = gx[j] = 0; gpix[j] = (m0 + lrow + RPT * j < p.M) ? m0 + lrow + RPT * j : -1; }
+    } else {
         const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
         const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
@@ -583,6 +597,17 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kerne
     int lt = 0, lci0 = 0;
     unsigned tapok = 0, aoff[AR], boff[BR];
     auto setup_tap = [&](int t) {
+        if (pointwise) {
+            tapok = 0;
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                aoff[j] = ((unsigned)gpix[j] * (unsigned)p.x_ld + (unsigned)lc4) * 4u;
+                tapok |= (gpix[j] >= 0 ? 1u : 0u) << j;
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) boff[j] = ((unsigned)(n0 + lrow + RPT * j) * (unsigned)Ktot + (unsigned)lc4) * 4u;
+            return;
+        }
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
         const int ky = (p.KW == 1) ? tap : ((p.KW == 3) ? (tap * 11) >> 5 : tap / p.KW);
         const int kx = tap - ky * p.KW;
@@ -725,7 +750,7 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kerne
     }
     __syncthreads();                                                     // every wave is past its last operand read
 #undef CONV_SYNC
-    conv_epilogue<BN, WM, WN, MODE>(p, acc, smem, m0, n0);
+    conv_epilogue<BN, WM, WN, MODE, EPI>(p, acc, smem, m0, n0);
 }
 
 // =========================================================================================================
@@ -1091,9 +1116,17 @@ static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, h
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         k<<<grid, 256, lds, st>>>(q, xb, wb);
     };
-    if (MODE == 0 && affine && padded) go(conv_dma_kernel<BN_, KB_, MODE, MODE == 0, MODE == 0>);
-    else if (MODE == 0 && affine) go(conv_dma_kernel<BN_, KB_, MODE, MODE == 0, false>);
-    else go(conv_dma_kernel<BN_, KB_, MODE, false, false>);
+    const bool full = p.M % BM == 0 && (MODE == 0 || p.sub == 1) && p.bias == nullptr && !(MODE == 0 && p.accumulate);
+    const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
+    auto pick = [&](auto epi) {
+        constexpr int E = decltype(epi)::value;
+        if (MODE == 0 && affine && padded) go(conv_dma_kernel<BN_, KB_, MODE, MODE == 0, MODE == 0, E>);
+        else if (MODE == 0 && affine) go(conv_dma_kernel<BN_, KB_, MODE, MODE == 0, false, E>);
+        else go(conv_dma_kernel<BN_, KB_, MODE, false, false, E>);
+    };
+    if (!full) pick(std::integral_constant<int, -1>{});
+    else if (extras) pick(std::integral_constant<int, 1>{});
+    else pick(std::integral_constant<int, 0>{});
 }
 
 // The LDS-DMA main loop takes exact-fp32 forward / data-gradient launches with 32-multiple input and 64-multiple output
