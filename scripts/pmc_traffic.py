@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def family(name):
     if "conv_wgrad_kernel" in name or "wgrad_dma_kernel" in name:
         return "conv_wgrad"
-    m = re.search(r"conv_fwd_kernel<\d+, \d+, \d+, (\d)", name) or re.search(r"conv_dma_kernel<\d+, (\d)", name)
+    m = re.search(r"conv_fwd_kernel<\d+, \d+, \d+, (\d)", name) or re.search(r"conv_dma_kernel<\d+, \d+, (\d)", name)   # <BN, KB, MODE, ...>
     if m:
         return "conv_dgrad" if m.group(1) == "1" else "conv_fwd"
     return None

@@ -572,7 +572,10 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB>::BPC)) void conv_dma_kerne
     const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
 
     // pointwise layers (1x1, stride 1: output pixel m reads input pixel m) skip the per-row divisions and bounds tests
-    const bool pointwise = !PADDED && p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
+    // (the AFFINE && !PADDED instantiation is only ever launched pointwise -- conv_dma_go -- so there it is a compile-time fact
+    // and the generic gather, with its registers, drops out of the 16-channel forward kernels that run three blocks per CU)
+    const bool pointwise = (AFFINE && !PADDED) ||
+                           (!PADDED && p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1));
     int gy[AR], gx[AR], gpix[AR];                                        // gather geometry of this lane's A rows
     if (pointwise) {
 #pragma unroll
@@ -1109,7 +1112,9 @@ static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, h
     using C = ConvDmaCfg<BN_, KB_>;
     const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
     const size_t lds = ((size_t)C::BASE_FLOATS + (affine ? 2 * (size_t)p.Cin : 0)) * sizeof(float);
-    const bool padded = p.KH * p.KW > 1;
+    // "padded" variant = the general gather with validity words; besides filters with taps outside the image it takes the
+    // strided 1x1 layers, so that the unpadded affine variant can assume output pixel m reads input pixel m
+    const bool padded = p.KH * p.KW > 1 || p.stride != 1 || p.pad != 0;
     ConvP q = p;
     q.dbg = g_conv_dbg;
     auto go = [&](auto k) {
