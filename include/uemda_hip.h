@@ -85,6 +85,8 @@ int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* dx, const ue
                           float* tile_partials, int flags, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
+/* the same with the per-tile BatchNorm statistics of uem_conv2d_fwd_stats out of the epilogue ([2][64][M/128]; N*Ho*Wo % 128 == 0) */
+int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, void* stream);
 /* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */
 int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift,
                      float* dw, const uem_conv_shape* s, int flags, void* stream);
@@ -145,6 +147,15 @@ int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* d
 int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
+/* BatchNorm(+ReLU, mask recomputed from x) backward of the layer in front of that max-pool, reading the POOLED gradient
+ * dy_pool (N, Ho, Wo, C) and the argmax taps in gather form instead of uem_maxpool3x3s2_bwd's (N, H, W, C) output: same
+ * sums and the same dx as uem_bn_bwd_reduce / uem_bn_bwd_apply on that tensor                                             */
+int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                           const float* save_mean, const float* save_invstd, int N, int H, int W, int C, int relu, float* dgamma,
+                           float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream);
+int uem_bn_bwd_apply_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N, int H,
+                          int W, int C, int relu, float* dx, void* stream);
 /* eval-mode / frozen-statistics backward: dx = dp * scale, dp = dy masked as in uem_bn_bwd_apply (relu 0 / 1 / UEM_RELU_BITS) */
 int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, const float* scale,
                        const float* shift, int64_t M, int C, int relu, float* dx, float* dres, void* stream);
@@ -152,6 +163,10 @@ int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, cons
 /* ---- MaxPool 3x3 s2 p1 (_resnets.py:153), InstanceNorm2d (Encoder.py:123,147) ---------------------- */
 int uem_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx /* argmax tap 0..8, may be NULL */, int N, int H,
                          int W, int C, void* stream);
+/* y = maxpool(relu(x*scale + shift)): the stem's BatchNorm + ReLU (_resnets.py:150-153) applied in the pool's fetch, the
+ * normalised map is never written; same first-max-wins argmax as uem_maxpool3x3s2_fwd on the materialised tensor          */
+int uem_maxpool3x3s2_affine_fwd(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, int N, int H,
+                                int W, int C, void* stream);
 int uem_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx /* = */, int N, int H, int W, int C,
                          void* stream);
 int uem_instnorm_fwd(const float* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,

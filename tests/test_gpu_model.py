@@ -172,6 +172,54 @@ def test_stem_conv_and_wgrad():
     torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), w.grad, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 15, 21, 64), (1, 32, 8, 128), (2, 6, 10, 64)])
+def test_stem_fusions_equal_the_separate_passes(shape):
+    """The stem's fused passes against the passes they replace: max-pool with BatchNorm + ReLU in its fetch == max-pool of the
+    materialised relu(bn(z)), bit for bit (values AND argmax taps, ties between equal zeros included); BatchNorm backward
+    reading the pooled gradient per 2x2 pixel block (even sizes) == max-pool backward followed by the BatchNorm backward, up
+    to the order of the two channel sums (per-pixel gradients are the same numbers, added in the same order)."""
+    from uemda_amd import ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    z = torch.randn(n, h, w, c, generator=g).cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.5).cuda()
+    rm, rv = torch.zeros(c).cuda(), torch.ones(c).cuda()
+    st = ops.bn_stats(z, gamma, beta, rm, rv, True)
+    a = ops.affine_act(z, st, relu=True)
+    y_ref, idx_ref = ops.maxpool_fwd(a, True)
+    y, idx = ops.maxpool_affine_fwd(z, st, True)
+    assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
+    dy = torch.randn(y.shape, generator=g).cuda()
+    gg_ref, gb_ref = torch.zeros(c).cuda(), torch.zeros(c).cuda()
+    da = ops.maxpool_bwd(dy, idx, z.shape)
+    dz_ref = ops.bn_backward(z, da, st, gg_ref, gb_ref, None, True)
+    if h % 2 or w % 2:
+        return                                             # odd sizes keep the two-kernel path (blocks.StemFn)
+    gg, gb = torch.zeros(c).cuda(), torch.zeros(c).cuda()
+    dz = ops.bn_backward_pooled(z, dy, idx, st, gg, gb)
+    torch.testing.assert_close(gg, gg_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gb, gb_ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dz, dz_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_stem_conv_tile_statistics():
+    """uem_conv2d_stem_fwd_stats: the same z as the plain stem conv and BatchNorm statistics equal to the two-pass ones."""
+    import torch.nn as nn
+    from uemda_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 12)
+    x4 = ops.nchw3_to_nhwc4(x.cuda())
+    bn1, bn2 = nn.BatchNorm2d(64).cuda(), nn.BatchNorm2d(64).cuda()
+    z_ref = ops.stem_conv(x4, ohwi(w))
+    st_ref = ops.bn_stats(z_ref, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, True)
+    z, st = ops.stem_conv_bn(x4, ohwi(w), bn2)
+    assert torch.equal(z, z_ref)
+    for a, b in ((st.mean, st_ref.mean), (st.invstd, st_ref.invstd), (st.scale, st_ref.scale), (st.shift, st_ref.shift),
+                 (bn2.running_mean, bn1.running_mean), (bn2.running_var, bn1.running_var)):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("Cn,M", [(64, 1000), (256, 77), (2048, 300), (128, 40000)])
 def test_batchnorm_stats_apply_backward(Cn, M):
     from uemda_amd import ops

@@ -393,6 +393,33 @@ extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const 
 // ---------------------------------------------------------------------------------------------------------
 // relu: 1 = mask from the materialised output `ymask` (float) or, without it, from x*scale+shift recomputed;
 //       2 (UEM_RELU_BITS) = `ymask` points at the packed sign bits written by uem_affine_act
+// Gradient of a 3x3 / stride 2 / pad 1 max-pool read in GATHER form: input pixel (iy, ix) collects from the <= 2x2 windows that
+// contain it the output gradients whose argmax tap (idx, 0..8 row-major) is this pixel.
+__device__ __forceinline__ float4 pool_grad4(const float* __restrict__ dy, const uint8_t* __restrict__ idx, int n, int iy, int ix, int c, int C,
+                                             int Ho, int Wo) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int oy0 = iy / 2, oy1 = (iy + 1) / 2;   // candidates: windows starting at 2*oy-1 covering iy
+    const int ox0 = ix / 2, ox1 = (ix + 1) / 2;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        if (oy >= Ho) continue;
+        const int ky = iy - (oy * 2 - 1);
+        if (ky < 0 || ky > 2) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (ox >= Wo) continue;
+            const int kx = ix - (ox * 2 - 1);
+            if (kx < 0 || kx > 2) continue;
+            const unsigned char k = (unsigned char)(ky * 3 + kx);
+            const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
+            const uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o);
+            const float4 g = *reinterpret_cast<const float4*>(dy + o);
+            if (bi.x == k) acc.x += g.x;
+            if (bi.y == k) acc.y += g.y;
+            if (bi.z == k) acc.z += g.z;
+            if (bi.w == k) acc.w += g.w;
+        }
+    }
+    return acc;
+}
 __device__ __forceinline__ float4 relu_mask4(float4 dy, float4 x, float4 sc, float4 sh, const float* ymask, size_t off,
                                              int relu = 1) {
     float4 pre;
@@ -606,6 +633,154 @@ extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// BatchNorm(+ReLU) backward of the layer in front of a 3x3 / stride 2 / pad 1 max-pool (the stem), reading the POOLED gradient
+// (N, Ho, Wo, C) and the pool's argmax taps instead of a materialised (N, H, W, C) gradient.  Work item = one 2x2 block of
+// input pixels (2k..2k+1, 2j..2j+1): it lies in exactly the four windows (k..k+1, j..j+1), so four (tap, gradient) loads serve
+// four pixels -- pixel (2k, 2j) takes window (k, j) at tap 4; (2k, 2j+1) windows (k, j) / (k, j+1) at taps 5 / 3; (2k+1, 2j)
+// windows (k, j) / (k+1, j) at 7 / 1; (2k+1, 2j+1) all four at 8, 6, 2, 0 -- added in the order uem_maxpool3x3s2_bwd adds them,
+// so sums and dx equal the two-kernel path bit for bit.  H and W even.
+// ---------------------------------------------------------------------------------------------------------
+struct Pool2x2 {
+    float4 d[4];                                   // gradients of pixels (0,0), (0,1), (1,0), (1,1) of the block
+};
+__device__ __forceinline__ float4 tap_sel(const uchar4 bi, const float4 g, const unsigned char k) {
+    return make_float4(bi.x == k ? g.x : 0.f, bi.y == k ? g.y : 0.f, bi.z == k ? g.z : 0.f, bi.w == k ? g.w : 0.f);
+}
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ Pool2x2 pool_grad_2x2(const float* __restrict__ dy, const uint8_t* __restrict__ idx, int n, int k, int j, int c,
+                                                 int C, int Ho, int Wo) {
+    uchar4 bi[2][2];
+    float4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const bool ok = k + a < Ho && j + b < Wo;
+            const size_t o = (((size_t)n * Ho + (ok ? k + a : k)) * Wo + (ok ? j + b : j)) * C + c;
+            bi[a][b] = *reinterpret_cast<const uchar4*>(idx + o);
+            g[a][b] = *reinterpret_cast<const float4*>(dy + o);
+            if (!ok) bi[a][b] = make_uchar4(255, 255, 255, 255);       // no such window: matches no tap
+        }
+    Pool2x2 r;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.d[0] = z; add4(r.d[0], tap_sel(bi[0][0], g[0][0], 4));
+    r.d[1] = z; add4(r.d[1], tap_sel(bi[0][0], g[0][0], 5)); add4(r.d[1], tap_sel(bi[0][1], g[0][1], 3));
+    r.d[2] = z; add4(r.d[2], tap_sel(bi[0][0], g[0][0], 7)); add4(r.d[2], tap_sel(bi[1][0], g[1][0], 1));
+    r.d[3] = z; add4(r.d[3], tap_sel(bi[0][0], g[0][0], 8)); add4(r.d[3], tap_sel(bi[0][1], g[0][1], 6));
+    add4(r.d[3], tap_sel(bi[1][0], g[1][0], 2)); add4(r.d[3], tap_sel(bi[1][1], g[1][1], 0));
+    return r;
+}
+// rows of the reduction = 2x2 blocks; the partial sums are accumulated pixel by pixel in the row-major order of the block's rows
+__global__ __launch_bounds__(256) void bn_bwd_partial_pool_kernel(const float* __restrict__ x, const float* __restrict__ dyp,
+                                                                  const uint8_t* __restrict__ idx, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ smean,
+                                                                  const float* __restrict__ sinv, int N, int H, int W, int C, int relu,
+                                                                  int blocks_per_chunk, float* __restrict__ ws) {
+    const ColMap cm = col_map(C, blockIdx.x);
+    const int Hb = H >> 1, Wb = W >> 1, Ho = Hb, Wo = Wb, nb = N * Hb * Wb;          // even H, W: Ho = H/2, Wo = W/2
+    const int chunk = blockIdx.y;
+    const int b0 = chunk * blocks_per_chunk, b1 = min(nb, b0 + blocks_per_chunk);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + cm.c0);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + cm.c0);
+    const float4 mu = *reinterpret_cast<const float4*>(smean + cm.c0);
+    const float4 is = *reinterpret_cast<const float4*>(sinv + cm.c0);
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), sg = sb;
+    for (int b = b0 + cm.rg; b < b1; b += cm.rpp) {
+        const int n = b / (Hb * Wb), rem = b - n * (Hb * Wb);
+        const int k = rem / Wb, j = rem - k * Wb;
+        const Pool2x2 pg = pool_grad_2x2(dyp, idx, n, k, j, cm.c0, C, Ho, Wo);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t off = (((size_t)n * H + 2 * k + (q >> 1)) * W + 2 * j + (q & 1)) * C + cm.c0;
+            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            float4 d = pg.d[q];
+            if (relu) d = relu_mask4(d, xv, sc, sh, nullptr, off, 1);
+            sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+            sg.x += d.x * ((xv.x - mu.x) * is.x); sg.y += d.y * ((xv.y - mu.y) * is.y);
+            sg.z += d.z * ((xv.z - mu.z) * is.z); sg.w += d.w * ((xv.w - mu.w) * is.w);
+        }
+    }
+    __shared__ float sh2[256][8];
+    sh2[threadIdx.x][0] = sb.x; sh2[threadIdx.x][1] = sb.y; sh2[threadIdx.x][2] = sb.z; sh2[threadIdx.x][3] = sb.w;
+    sh2[threadIdx.x][4] = sg.x; sh2[threadIdx.x][5] = sg.y; sh2[threadIdx.x][6] = sg.z; sh2[threadIdx.x][7] = sg.w;
+    __syncthreads();
+    if (cm.rg == 0) {
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = sh2[threadIdx.x][q];
+        for (int g = 1; g < cm.rpp; ++g) {
+            const int t = g * cm.lpr + cm.cv;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] += sh2[t][q];
+        }
+        float* w = ws + (size_t)chunk * 2 * C;      // [chunk][2][C] : dbeta, dgamma
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w[cm.c0 + q] = a[q]; w[C + cm.c0 + q] = a[4 + q]; }
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ dyp,
+                                                                const uint8_t* __restrict__ idx, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ smean,
+                                                                const float* __restrict__ sinv, const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, int N, int H, int W, int C, float invM,
+                                                                int relu, float* __restrict__ dx) {
+    const int Hb = H >> 1, Wb = W >> 1, cv = C >> 2;
+    const int64_t total = (int64_t)N * Hb * Wb * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 4;
+        int64_t t = i / cv;
+        const int j = (int)(t % Wb); t /= Wb;
+        const int k = (int)(t % Hb);
+        const int n = (int)(t / Hb);
+        const Pool2x2 pg = pool_grad_2x2(dyp, idx, n, k, j, c, C, Hb, Wb);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(smean + c), is = *reinterpret_cast<const float4*>(sinv + c);
+        const float4 dg = *reinterpret_cast<const float4*>(dgamma + c), db = *reinterpret_cast<const float4*>(dbeta + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t off = (((size_t)n * H + 2 * k + (q >> 1)) * W + 2 * j + (q & 1)) * C + c;
+            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            float4 d = pg.d[q];
+            if (relu) d = relu_mask4(d, xv, sc, sh, nullptr, off, 1);
+            float4 o;
+            o.x = sc.x * (d.x - db.x * invM - ((xv.x - mu.x) * is.x) * (dg.x * invM));
+            o.y = sc.y * (d.y - db.y * invM - ((xv.y - mu.y) * is.y) * (dg.y * invM));
+            o.z = sc.z * (d.z - db.z * invM - ((xv.z - mu.z) * is.z) * (dg.z * invM));
+            o.w = sc.w * (d.w - db.w * invM - ((xv.w - mu.w) * is.w) * (dg.w * invM));
+            *reinterpret_cast<float4*>(dx + off) = o;
+        }
+    }
+}
+extern "C" int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                      const float* save_mean, const float* save_invstd, int N, int H, int W, int C, int relu,
+                                      float* dgamma, float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
+    UEM_REQUIRE(x && dy_pool && idx && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce_pool: null pointer");
+    UEM_REQUIRE(N > 0 && H > 1 && W > 1 && col_shape_ok(C) && (int64_t)N * H * W < 2147483647LL, "bn_bwd_reduce_pool: unsupported shape");
+    if ((H | W) & 1) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_reduce_pool: H and W must be even");
+    UEM_REQUIRE(relu == 0 || relu == 1, "bn_bwd_reduce_pool: relu is 0 or 1 (mask recomputed from x)");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = N * (H / 2) * (W / 2);
+    int chunks, bpc;
+    col_chunks(nb, C, &chunks, &bpc);                 // never more chunks than uem_bn_workspace_floats(N*H*W, C) provides for
+    dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
+    bn_bwd_partial_pool_kernel<<<grid, 256, 0, st>>>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, N, H, W, C, relu, bpc, workspace);
+    bn_bwd_finalize_kernel<<<C, 64, 0, st>>>(workspace, chunks, C, dgamma, dbeta, grad_gamma, grad_beta);
+    return uem_check_launch("bn_bwd_reduce_pool");
+}
+extern "C" int uem_bn_bwd_apply_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                     const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N,
+                                     int H, int W, int C, int relu, float* dx, void* stream) {
+    UEM_REQUIRE(x && dy_pool && idx && scale && shift && save_mean && save_invstd && dgamma && dbeta && dx, "bn_bwd_apply_pool: null pointer");
+    UEM_REQUIRE(N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0 && (int64_t)N * H * W < 2147483647LL, "bn_bwd_apply_pool: bad shape");
+    if ((H | W) & 1) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pool: H and W must be even");
+    UEM_REQUIRE(relu == 0 || relu == 1, "bn_bwd_apply_pool: relu is 0 or 1 (mask recomputed from x)");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+    bn_bwd_apply_pool_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(
+        x, dy_pool, idx, scale, shift, save_mean, save_invstd, dgamma, dbeta, N, H, W, C, 1.0f / (float)((int64_t)N * H * W), relu, dx);
+    return uem_check_launch("bn_bwd_apply_pool");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // fp32 <-> bf16 (round to nearest even): the weight arena's bf16 copy, and the two ends of the bf16-storage region
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t nvec, int64_t n) {
@@ -653,8 +828,11 @@ extern "C" int uem_affine_act_bwd(const float* x, const float* dy, const float* 
 // ---------------------------------------------------------------------------------------------------------
 // MaxPool 3x3 stride 2 pad 1 (first max in row-major window order wins, like torch CPU); idx in 0..8
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
+    // AFFINE: the pooled tensor is relu(x*scale + shift) (the stem's BatchNorm + ReLU), never written to memory
     const int cv = C >> 2;
     const int64_t total = (int64_t)N * Ho * Wo * cv;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -674,7 +852,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                if (AFFINE) {
+                    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+                    v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+                    v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+                }
                 const unsigned char k = (unsigned char)(ky * 3 + kx);
                 if (!any) { best = v; bi = make_uchar4(k, k, k, k); any = true; }
                 else {
@@ -694,8 +877,16 @@ extern "C" int uem_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int 
     UEM_REQUIRE(x && y && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_fwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
-    maxpool_fwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, idx, N, H, W, C, Ho, Wo);
+    maxpool_fwd_kernel<false><<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, nullptr, nullptr, y, idx, N, H, W, C, Ho, Wo);
     return uem_check_launch("maxpool_fwd");
+}
+extern "C" int uem_maxpool3x3s2_affine_fwd(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, int N, int H,
+                                           int W, int C, void* stream) {
+    UEM_REQUIRE(x && scale && shift && y && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_affine_fwd: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    maxpool_fwd_kernel<true><<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, idx, N, H, W, C, Ho, Wo);
+    return uem_check_launch("maxpool_affine_fwd");
 }
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
@@ -708,27 +899,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         const int ix = (int)(t % W); t /= W;
         const int iy = (int)(t % H);
         const int n = (int)(t / H);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int oy0 = iy / 2, oy1 = (iy + 1) / 2;   // candidates: windows starting at 2*oy-1 covering iy
-        const int ox0 = ix / 2, ox1 = (ix + 1) / 2;
-        for (int oy = oy0; oy <= oy1; ++oy) {
-            if (oy >= Ho) continue;
-            const int ky = iy - (oy * 2 - 1);
-            if (ky < 0 || ky > 2) continue;
-            for (int ox = ox0; ox <= ox1; ++ox) {
-                if (ox >= Wo) continue;
-                const int kx = ix - (ox * 2 - 1);
-                if (kx < 0 || kx > 2) continue;
-                const unsigned char k = (unsigned char)(ky * 3 + kx);
-                const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
-                const uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o);
-                const float4 g = *reinterpret_cast<const float4*>(dy + o);
-                if (bi.x == k) acc.x += g.x;
-                if (bi.y == k) acc.y += g.y;
-                if (bi.z == k) acc.z += g.z;
-                if (bi.w == k) acc.w += g.w;
-            }
-        }
+        const float4 acc = pool_grad4(dy, idx, n, iy, ix, c, C, Ho, Wo);
         *reinterpret_cast<float4*>(dx + (((size_t)n * H + iy) * W + ix) * C + c) = acc;
     }
 }

@@ -70,11 +70,11 @@ class StemFn(Function):
     @staticmethod
     def forward(ctx, x, resnet, *params):
         x4 = ops.nchw3_to_nhwc4(x)
-        z = ops.stem_conv(x4, ops.weight_ohwi(resnet.conv1.weight))
-        st = _BN.stats(z, resnet.bn1)
-        a = ops.affine_act(z, st, relu=True)
+        # BatchNorm statistics out of the conv epilogue; BatchNorm + ReLU applied in the max-pool's fetch: the 64-channel
+        # half-resolution map (the largest activation of the network) is written once (z) and read once
+        z, st = ops.stem_conv_bn(x4, ops.weight_ohwi(resnet.conv1.weight), resnet.bn1)
         need = any(ctx.needs_input_grad)
-        y, idx = ops.maxpool_fwd(a, need)
+        y, idx = ops.maxpool_affine_fwd(z, st, need)
         ops.nbt_inc(resnet.bn1)
         if need:
             ctx.resnet = resnet
@@ -87,8 +87,12 @@ class StemFn(Function):
         x4, z, stbuf, idx = ctx.saved_tensors
         resnet = ctx.resnet
         st = _st_from(stbuf, ctx.training)
-        da = ops.maxpool_bwd(dy.contiguous(), idx, z.shape)
-        dz = ops.bn_backward(z, da, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias), None, True, dx=da)
+        if st.training and z.shape[1] % 2 == 0 and z.shape[2] % 2 == 0:
+            # the pool's backward is read in gather form inside both BatchNorm-backward passes (no full-size da)
+            dz = ops.bn_backward_pooled(z, dy.contiguous(), idx, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias))
+        else:
+            da = ops.maxpool_bwd(dy.contiguous(), idx, z.shape)
+            dz = ops.bn_backward(z, da, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias), None, True, dx=da)
         ops.stem_wgrad(x4, dz, grad_ohwi(resnet.conv1.weight))
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 

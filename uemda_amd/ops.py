@@ -362,6 +362,32 @@ def stem_conv(x4, w_ohwi):
     return y
 
 
+def stem_conv_bn(x4, w_ohwi, bn):
+    """The stem conv followed by its BatchNorm statistics -> (z, BNState): out of the conv epilogue when the tiles are full and
+    the BatchNorm is in training mode, else stem_conv + bn_stats (eval mode, odd sizes)."""
+    n, h, w, _ = x4.shape
+    ho, wo = conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1)
+    M = n * ho * wo
+    training = bn.training or bn.running_mean is None
+    if not training or M % 128 != 0 or not FUSE_BN_STATS:
+        z = stem_conv(x4, w_ohwi)
+        return z, bn_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training, bn.eps,
+                           bn.momentum if bn.momentum is not None else 0.1)
+    w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+    call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
+    z = torch.empty((n, ho, wo, 64), device=x4.device, dtype=torch.float32)
+    ts = torch.empty((M // 128, 2, 64), device=x4.device, dtype=torch.float32)
+    PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), stream()))
+    st = BNState()
+    st.training = True
+    buf = torch.empty((4, 64), device=x4.device, dtype=torch.float32)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    call("uem_bn_stats_from_tiles", ptr(ts), M // 128, M, 64, ptr(bn.weight.detach()), ptr(bn.bias.detach()), float(bn.eps),
+         float(bn.momentum if bn.momentum is not None else 0.1), ptr(bn.running_mean), ptr(bn.running_var),
+         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream())
+    return z, st
+
+
 def stem_wgrad(x4, dy, dw_ohwi):
     if dw_ohwi is None:                      # frozen stem (freeze_at >= 1)
         return
@@ -453,6 +479,31 @@ def maxpool_fwd(x, want_idx):
     idx = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_idx else None
     call("uem_maxpool3x3s2_fwd", ptr(x), ptr(y), ptr(idx), n, h, w, c, stream())
     return y, idx
+
+
+def maxpool_affine_fwd(z, st, want_idx):
+    """maxpool3x3s2(relu(z*scale + shift)) without materialising the normalised map."""
+    n, h, w, c = z.shape
+    ho, wo = conv_out_size(h, 3, 2, 1, 1), conv_out_size(w, 3, 2, 1, 1)
+    y = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.float32)
+    idx = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.uint8) if want_idx else None
+    call("uem_maxpool3x3s2_affine_fwd", ptr(z), ptr(st.scale), ptr(st.shift), ptr(y), ptr(idx), n, h, w, c, stream())
+    return y, idx
+
+
+def bn_backward_pooled(z, dy_pool, idx, st, gamma_grad, beta_grad):
+    """BatchNorm+ReLU backward of the layer in front of the 3x3/s2 max-pool, from the POOLED gradient and the argmax taps
+    (no full-size gradient tensor in between) -> dz.  Training-mode statistics; eval mode goes through maxpool_bwd + bn_backward."""
+    n, h, w, c = z.shape
+    M = n * h * w
+    tmp = torch.empty((2, c), device=z.device, dtype=torch.float32)
+    ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, c), device=z.device, dtype=torch.float32)
+    call("uem_bn_bwd_reduce_pool", ptr(z), ptr(dy_pool), ptr(idx), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         n, h, w, c, 1, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws), stream())
+    dz = torch.empty_like(z)
+    call("uem_bn_bwd_apply_pool", ptr(z), ptr(dy_pool), ptr(idx), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         ptr(tmp[0]), ptr(tmp[1]), n, h, w, c, 1, ptr(dz), stream())
+    return dz
 
 
 def maxpool_bwd(dy, idx, in_shape):
