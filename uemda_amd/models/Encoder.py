@@ -166,7 +166,12 @@ class Deeplabv2(nn.Module):
             from . import ppm
             return ppm.ppm_head(feat, self.layer5), ppm.ppm_head(feat, self.layer6)
         params = list(self.layer5.parameters()) + list(self.layer6.parameters())
-        return blocks.ASPPHeadsFn.apply(feat, self.layer5, self.layer6, *params)
+        # bf16 storage (training): the two heads' GEMM takes bf16 operands (fp32 feat / logits in memory, fp32 accumulate)
+        blocks.ASPPHeadsFn.prec = "bf16" if (self.encoder.storage == "bf16" and self.training) else None
+        try:
+            return blocks.ASPPHeadsFn.apply(feat, self.layer5, self.layer6, *params)
+        finally:
+            blocks.ASPPHeadsFn.prec = None
 
     def forward(self, x):
         ops.need_gpu(x)

@@ -251,13 +251,18 @@ class ASPPHeadsFn(Function):
     ONE 1x1 GEMM G = feat x Wall on the MFMA kernel (feat is read once), then a 36-term gather rebuilds the
     dilated 3x3 sums; see uem_aspp_gather_* in include/uemda_hip.h."""
 
+    # operand precision of the heads' GEMMs (None = the global setting); Deeplabv2 sets "bf16" for the bf16-storage model
+    prec = None
+
     @staticmethod
     def forward(ctx, feat, head5, head6, *params):
         import ctypes
         wall, bias, C, nd, R, used = _aspp_pack(head5, head6, feat)
         n, h, w, cin = feat.shape
         dil = (ctypes.c_int * nd)(*head5.dilations)
-        G = ops.conv2d(feat, wall, algo_cout=used)
+        ctx.prec = ASPPHeadsFn.prec
+        with ops.conv_precision(ctx.prec):
+            G = ops.conv2d(feat, wall, algo_cout=used)
         out = torch.empty((n, h, w, 2 * C), device=feat.device, dtype=torch.float32)
         ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(out), n, h, w, 2 * C, R, nd, dil, ops.stream())
         x1 = out[..., 0:C].contiguous()
@@ -284,8 +289,9 @@ class ASPPHeadsFn(Function):
         dil = (ctypes.c_int * nd)(*head5.dilations)
         ops.call("uem_aspp_gather_bwd", ops.ptr(dout), ops.ptr(dG), n, h, w, 2 * C, R, nd, dil, ops.stream())
         dwall = torch.zeros((R, 1, 1, cin), device=feat.device, dtype=torch.float32)
-        ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
-        dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
+        with ops.conv_precision(ctx.prec):
+            ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
+            dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
         dwv = dwall.view(R, cin)[:used].view(nd, 9, 2, C, cin)
         for i in range(nd):
             for hd, head in enumerate((head5, head6)):

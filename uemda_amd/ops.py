@@ -35,6 +35,28 @@ def set_conv_precision(name):
     CONV_PREC, CONV_PREC_BWD = _PREC_FLAGS[name]
 
 
+class conv_precision:
+    """`with ops.conv_precision("bf16"):` -- the operand precision of the fp32-storage conv kernels for the launches inside the
+    block (None: leave it alone); the bf16-storage model runs its fp32 ASPP GEMMs with bf16 operands this way."""
+
+    def __init__(self, name):
+        if name is not None and name not in _PREC_FLAGS:
+            raise UemError(f"conv precision must be one of {sorted(_PREC_FLAGS)}, got {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        global CONV_PREC, CONV_PREC_BWD
+        self.saved = (CONV_PREC, CONV_PREC_BWD)
+        if self.name is not None:
+            CONV_PREC, CONV_PREC_BWD = _PREC_FLAGS[self.name]
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_PREC, CONV_PREC_BWD
+        CONV_PREC, CONV_PREC_BWD = self.saved
+        return False
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
