@@ -85,12 +85,16 @@ int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* dx, const ue
                           float* tile_partials, int flags, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
-/* the same with the per-tile BatchNorm statistics of uem_conv2d_fwd_stats out of the epilogue ([2][64][M/128]; N*Ho*Wo % 128 == 0) */
-int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, void* stream);
+/* the same with the per-tile BatchNorm statistics of uem_conv2d_fwd_stats out of the epilogue ([2][64][M/128]; N*Ho*Wo % 128 == 0);
+ * flags: 0 or one UEM_CONV_PREC_* operand precision                                                                      */
+int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags,
+                              void* stream);
 /* dw[o][ky][kx][i] += sum_m dy[m][o] * x'[m@tap][i]   (fp32 atomics: callers zero / accumulate)   */
 int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, const float* in_shift,
                      float* dw, const uem_conv_shape* s, int flags, void* stream);
 int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw8, int N, int H, int W, void* stream);
+/* the same with an operand precision (0 or one UEM_CONV_PREC_* flag) */
+int uem_conv2d_stem_wgrad_prec(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream);
 /* weight re-layouts (tiny): transposed copy for dgrad; stem pack / unpack-add                     */
 int uem_weight_transpose(const float* w /*[Cout][KH][KW][Cin]*/, float* wt /*[Cin][KH][KW][Cout]*/, int Cout,
                          int KH, int KW, int Cin, void* stream);

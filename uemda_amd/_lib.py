@@ -59,7 +59,8 @@ SIGNATURES = {
     "uem_maxpool3x3s2_affine_fwd": [P, P, P, P, P, I, I, I, I, P],
     "uem_bn_bwd_reduce_pool": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "uem_bn_bwd_apply_pool": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P],
-    "uem_conv2d_stem_fwd_stats": [P, P, P, I, I, I, P, P],
+    "uem_conv2d_stem_fwd_stats": [P, P, P, I, I, I, P, I, P],
+    "uem_conv2d_stem_wgrad_prec": [P, P, P, I, I, I, I, P],
     "uem_instnorm_fwd": [P, P, P, P, I, I, I, F, P],
     "uem_instnorm_bwd": [P, P, P, P, I, I, I, P],
     "uem_adaptive_avgpool_fwd": [P, P, I, I, I, I, I, P],

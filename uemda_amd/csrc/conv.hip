@@ -1288,17 +1288,19 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     return UEM_OK;
 }
 
-static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, void* stream);
+static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream);
 extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream) {
-    return stem_fwd_impl(x4, w8, y, N, H, W, nullptr, stream);
+    return stem_fwd_impl(x4, w8, y, N, H, W, nullptr, 0, stream);
 }
-extern "C" int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, void* stream) {
+extern "C" int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags,
+                                         void* stream) {
     UEM_REQUIRE(tile_stats, "conv2d_stem_fwd_stats: null pointer");
+    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_stem_fwd_stats: only precision flags are accepted");
     const int64_t M = (int64_t)N * ((H + 6 - 7) / 2 + 1) * ((W + 6 - 7) / 2 + 1);
     if (M % 128 != 0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_stem_fwd_stats: needs N*Ho*Wo %% 128 == 0");
-    return stem_fwd_impl(x4, w8, y, N, H, W, tile_stats, stream);
+    return stem_fwd_impl(x4, w8, y, N, H, W, tile_stats, flags, stream);
 }
-static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, void* stream) {
+static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream) {
     UEM_REQUIRE(x4 && w8 && y && N > 0 && H >= 7 && W >= 7, "conv2d_stem_fwd: bad arguments");
     ConvP p;
     p.x = x4; p.w = w8; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = y;
@@ -1308,7 +1310,7 @@ static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int 
     p.accumulate = 0; p.relu = 0; p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0; p.dbg = 0;
     p.M = N * p.Ho * p.Wo;
-    return conv_launch<2>(p, false, (hipStream_t)stream);
+    return conv_launch<2>(p, false, (hipStream_t)stream, (flags & UEM_CONV_PREC_BF16) ? 2 : ((flags & UEM_CONV_PREC_BF16X3) ? 1 : 0));
 }
 
 // =========================================================================================================
@@ -1673,14 +1675,24 @@ extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in
     return uem_check_launch("conv2d_wgrad");
 }
 
+static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream);
 extern "C" int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw8, int N, int H, int W, void* stream) {
+    return stem_wgrad_impl(x4, dy, dw8, N, H, W, 0, stream);
+}
+extern "C" int uem_conv2d_stem_wgrad_prec(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream) {
+    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_stem_wgrad_prec: only precision flags are accepted");
+    return stem_wgrad_impl(x4, dy, dw8, N, H, W, flags, stream);
+}
+static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream) {
     UEM_REQUIRE(x4 && dy && dw8 && N > 0 && H >= 7 && W >= 7, "conv2d_stem_wgrad: bad arguments");
     WgradP p;
     p.x = x4; p.dy = dy; p.in_scale = p.in_shift = nullptr; p.dw = dw8;
     p.N = N; p.H = H; p.W = W; p.Cin = 32; p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.dy_ld = 64; p.relu = 0; p.rows_per_split = 0;
     p.M = N * p.Ho * p.Wo;
-    wgrad_go<64, 32, 2, 1, 2, 2>(p, false, (hipStream_t)stream);
+    if (flags & UEM_CONV_PREC_BF16) wgrad_go<64, 32, 2, 1, 2, 2, 2>(p, false, (hipStream_t)stream);
+    else if (flags & UEM_CONV_PREC_BF16X3) wgrad_go<64, 32, 2, 1, 2, 2, 1>(p, false, (hipStream_t)stream);
+    else wgrad_go<64, 32, 2, 1, 2, 2>(p, false, (hipStream_t)stream);
     return uem_check_launch("conv2d_stem_wgrad");
 }
 

@@ -67,12 +67,17 @@ def _st_from(buf, training=True):
 class StemFn(Function):
     """conv7x7 s2 -> BN -> ReLU -> maxpool3x3 s2   (_resnets.py:149-153, resnet.py:142-143)"""
 
+    # operand precision of the 7x7 conv and its weight gradient (None = the global setting); "bf16" under bf16 storage
+    prec = None
+
     @staticmethod
     def forward(ctx, x, resnet, *params):
+        ctx.prec = StemFn.prec
         x4 = ops.nchw3_to_nhwc4(x)
         # BatchNorm statistics out of the conv epilogue; BatchNorm + ReLU applied in the max-pool's fetch: the 64-channel
         # half-resolution map (the largest activation of the network) is written once (z) and read once
-        z, st = ops.stem_conv_bn(x4, ops.weight_ohwi(resnet.conv1.weight), resnet.bn1)
+        with ops.conv_precision(ctx.prec):
+            z, st = ops.stem_conv_bn(x4, ops.weight_ohwi(resnet.conv1.weight), resnet.bn1)
         need = any(ctx.needs_input_grad)
         y, idx = ops.maxpool_affine_fwd(z, st, need)
         ops.nbt_inc(resnet.bn1)
@@ -93,7 +98,8 @@ class StemFn(Function):
         else:
             da = ops.maxpool_bwd(dy.contiguous(), idx, z.shape)
             dz = ops.bn_backward(z, da, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias), None, True, dx=da)
-        ops.stem_wgrad(x4, dz, grad_ohwi(resnet.conv1.weight))
+        with ops.conv_precision(ctx.prec):
+            ops.stem_wgrad(x4, dz, grad_ohwi(resnet.conv1.weight))
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

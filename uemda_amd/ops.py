@@ -399,7 +399,7 @@ def stem_conv_bn(x4, w_ohwi, bn):
     call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
     z = torch.empty((n, ho, wo, 64), device=x4.device, dtype=torch.float32)
     ts = torch.empty((M // 128, 2, 64), device=x4.device, dtype=torch.float32)
-    PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), stream()))
+    PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), CONV_PREC, stream()))
     st = BNState()
     st.training = True
     buf = torch.empty((4, 64), device=x4.device, dtype=torch.float32)
@@ -416,7 +416,7 @@ def stem_wgrad(x4, dy, dw_ohwi):
     n, h, w, _ = x4.shape
     dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
     PROF.run("conv_wgrad", 2.0 * dy.numel() * 147,
-             lambda: call("uem_conv2d_stem_wgrad", ptr(x4), ptr(dy), ptr(dw8), n, h, w, stream()))
+             lambda: call("uem_conv2d_stem_wgrad_prec", ptr(x4), ptr(dy), ptr(dw8), n, h, w, CONV_PREC_BWD, stream()))
     call("uem_stem_unpack_grad", ptr(dw8), ptr(dw_ohwi), stream())
 
 

@@ -186,8 +186,12 @@ class ResNetEncoder(nn.Module):
     def forward_nhwc(self, x):
         r = self.resnet
         params = [r.conv1.weight, r.bn1.weight, r.bn1.bias]
-        y = blocks.StemFn.apply(x, r, *params)
         bf16 = self.storage == "bf16" and self.training
+        blocks.StemFn.prec = "bf16" if bf16 else None          # bf16 storage: bf16 operands for the stem conv too (fp32 in memory)
+        try:
+            y = blocks.StemFn.apply(x, r, *params)
+        finally:
+            blocks.StemFn.prec = None
         if bf16:
             from .models.blocks_bf16 import CastFn
             y = CastFn.apply(y, True)
