@@ -329,17 +329,17 @@ FUSED_TOL, FUSED_TOL_IDENTITY = 2e-2, 1e-3
 CHAIN_TOL = {1: (2e-3, 3e-2, 4e-2), 3: (2e-2, 2.5e-1, 3e-1)}      # blocks in the chain -> relative L2 bounds on y, dx, parameter gradients
 
 
-def _damped_sd(rtype, damp=0.2):
+def _damped_sd(rtype, damp=0.2, use_ppm=False):
     from oracle.weights import det_state_dict
-    sd = det_state_dict(rtype, 6, False, seed=2333)
+    sd = det_state_dict(rtype, 6, use_ppm, seed=2333)
     for k in sd:
         if k.endswith("bn3.weight"):
             sd[k] = sd[k] * damp
     return sd
 
 
-@pytest.mark.parametrize("rtype,size", [("resnet50", 512), ("resnet101", 1024)])
-def test_bf16_storage_ssl_step_vs_oracle(rtype, size):
+@pytest.mark.parametrize("rtype,size,use_ppm,B", [("resnet50", 512, False, 1), ("resnet101", 1024, False, 1), ("resnet50", 256, True, 2)])
+def test_bf16_storage_ssl_step_vs_oracle(rtype, size, use_ppm, B):
     """One train_ssl_uem step with bf16 STORAGE (activations, activation gradients and weight copies in bf16 between the
     max-pool and layer4; fp32 accumulation, statistics and master weights) against the oracle, B = 1 + 1 tiles.  Residual
     branches damped (gamma3 x 0.2) as in tests/test_gpu_config5.py -- at the default initialisation the network is chaotic
@@ -356,16 +356,19 @@ def test_bf16_storage_ssl_step_vs_oracle(rtype, size):
     from uemda_amd.optim import FusedSGD
     from uemda_amd.step import HYPER, StepState, ssl_step
     C = 6
-    sd = _damped_sd(rtype)
-    bc = synth.make_batch(B=1, H=size, W=size, C=C, k=2048, seed=31)
-    om = OracleDeeplabv2({k: v.clone() for k, v in sd.items()}, rtype, C, False)
-    ref = oracle_ssl(om, SGDState(om.parameters(), 0.9, 5e-4), bc["prototypes"], bc, 2e-3, OH)
+    sd = _damped_sd(rtype, use_ppm=use_ppm)
+    bc = synth.make_batch(B=B, H=size, W=size, C=C, k=2048, seed=31)
+    om = OracleDeeplabv2({k: v.clone() for k, v in sd.items()}, rtype, C, use_ppm)
+    ref = oracle_ssl(om, SGDState(om.parameters(), 0.9, 5e-4), bc["prototypes"], bc, 2e-3, OH, dropout=False)
     cfg = dict(backbone=dict(resnet_type=rtype, output_stride=16, pretrained=False), multi_layer=True, cascade=False,
-               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+               use_ppm=use_ppm, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
     res, grads = {}, {}
     for storage in ("fp32", "bf16"):
         model = Deeplabv2(cfg)
         model.load_state_dict(sd)
+        if use_ppm:                                                    # Dropout2d off, as in the oracle run
+            model.layer5.conv_last[3].p = 0.0
+            model.layer6.conv_last[3].p = 0.0
         model = model.cuda().set_storage(storage)
         b = {k: v.cuda() for k, v in bc.items()}
         al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])

@@ -162,12 +162,18 @@ class Deeplabv2(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------------------
     def _heads(self, feat):
+        bf16 = self.encoder.storage == "bf16" and self.training
         if self.config.use_ppm:
             from . import ppm
-            return ppm.ppm_head(feat, self.layer5), ppm.ppm_head(feat, self.layer6)
+            # bf16 storage (training): the heads' convs take bf16 operands (fp32 tensors in memory, fp32 accumulate)
+            ppm.PPMHeadFn.prec = "bf16" if bf16 else None
+            try:
+                return ppm.ppm_head(feat, self.layer5), ppm.ppm_head(feat, self.layer6)
+            finally:
+                ppm.PPMHeadFn.prec = None
         params = list(self.layer5.parameters()) + list(self.layer6.parameters())
         # bf16 storage (training): the two heads' GEMM takes bf16 operands (fp32 feat / logits in memory, fp32 accumulate)
-        blocks.ASPPHeadsFn.prec = "bf16" if (self.encoder.storage == "bf16" and self.training) else None
+        blocks.ASPPHeadsFn.prec = "bf16" if bf16 else None
         try:
             return blocks.ASPPHeadsFn.apply(feat, self.layer5, self.layer6, *params)
         finally:

@@ -31,8 +31,22 @@ def _avgpool(x, s):
 
 
 class PPMHeadFn(Function):
+    # operand precision of the head's convs (None = the global setting); Deeplabv2 sets "bf16" for the bf16-storage model
+    prec = None
+
     @staticmethod
     def forward(ctx, feat, head, *params):
+        ctx.prec = PPMHeadFn.prec
+        with ops.conv_precision(ctx.prec):
+            return PPMHeadFn._forward(ctx, feat, head)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with ops.conv_precision(ctx.prec):
+            return PPMHeadFn._backward(ctx, dout)
+
+    @staticmethod
+    def _forward(ctx, feat, head):
         n, h, w, cin = feat.shape
         scales = head.pool_scales
         nb = len(scales)
@@ -77,7 +91,7 @@ class PPMHeadFn(Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def _backward(ctx, dout):
         head, C = ctx.head, ctx.C
         feat, cat, zc, stcb, a, w4, mask = ctx.saved_tensors[:7]
         branch = ctx.saved_tensors[7:]
