@@ -14,6 +14,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1162,6 +1163,11 @@ static int conv_dma_try(const ConvP& p, bool affine, hipStream_t st) {
 template <int MODE>
 static int conv_launch(const ConvP& p, bool affine, hipStream_t st, int prec = 0) {
     if (prec == 0 && conv_dma_try<MODE>(p, affine, st)) return uem_check_launch("conv2d (dma)");
+    static const int trace_legacy = getenv("UEM_CONV_TRACE_LEGACY") ? atoi(getenv("UEM_CONV_TRACE_LEGACY")) : 0;
+    if (trace_legacy)                                   // diagnostic: which launches stay on the register-staged kernels, and why
+        fprintf(stderr, "[uemda] register-staged conv: mode %d prec %d M=%d Cin=%d Cout=%d k=%dx%d stride=%d pad=%d dil=%d x_ld=%d y_ld=%d affine=%d x%%16=%d w%%16=%d\n",
+                MODE, prec, p.M, p.Cin, p.Cout, p.KH, p.KW, p.stride, p.pad, p.dil, p.x_ld, p.y_ld, (int)affine,
+                (int)((uintptr_t)p.x & 15), (int)((uintptr_t)p.w & 15));
     static const int nbuf = getenv("UEM_CONV_NBUF") ? atoi(getenv("UEM_CONV_NBUF")) : 1;
     static const int smallk_bn64 = getenv("UEM_CONV_SMALLK_BN64") ? atoi(getenv("UEM_CONV_SMALLK_BN64")) : 0;
     const int tiles_m = (int)uem_cdiv(p.M, BM);

@@ -94,10 +94,12 @@ class Deeplabv2(nn.Module):
         if not params:
             return
         dev = params[0].device
-        total = sum(p.numel() for p in params)
-        total_pad = (total + 3) // 4 * 4
-        arena = torch.zeros(total_pad, device=dev, dtype=torch.float32)
-        garena = torch.zeros(total_pad, device=dev, dtype=torch.float32)
+        # every tensor starts on a 16-byte boundary: the conv kernels fetch weights by 16-byte LDS-DMA and fall back to the
+        # register-staged loop for a misaligned filter bank (a 6-element bias used to shift everything behind it by 24 bytes:
+        # the second PPM head's 4096 -> 512 conv ran at half speed); the padding floats stay zero under the optimizer
+        total = sum((p.numel() + 3) // 4 * 4 for p in params)
+        arena = torch.zeros(total, device=dev, dtype=torch.float32)
+        garena = torch.zeros(total, device=dev, dtype=torch.float32)
         off = 0
         for p in params:
             n = p.numel()
@@ -119,7 +121,7 @@ class Deeplabv2(nn.Module):
             p._uem_grad_view = (lambda vo=view_of, ga=garena: vo(ga))
             p._uem_owner = self
             p._uem_off = off
-            off += n
+            off += (n + 3) // 4 * 4
         self._arena, self._grad_arena, self._n_params = arena, garena, total
         # one int64 arena for every BatchNorm's num_batches_tracked: a training forward bumps all of them with ONE
         # add instead of one tiny launch per layer (53 per forward on ResNet-50)
