@@ -180,6 +180,11 @@ int uem_instnorm_bwd(const float* y, const float* dy, const float* save_invstd, 
 /* ---- PPM head pieces: adaptive avg-pool + bilinear (align_corners=False) (Encoder.py:18,48-51) ------ */
 int uem_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int S, void* stream);
 int uem_adaptive_avgpool_bwd(const float* dy, float* dx /* += */, int N, int H, int W, int C, int S, void* stream);
+/* the feature gradient of a PPM head in one pass: dfeat (N,H,W,C) = dcat[..., :C] (row stride dcat_ld) + sum_i
+ * adaptive_avgpool_bwd(dp[i] (N,S_i,S_i,C)) -- replaces the slice copy and one uem_adaptive_avgpool_bwd pass per branch; dp and
+ * scales are HOST arrays of nbranch <= 4 entries (device pointers / bin counts)                                          */
+int uem_ppm_feat_grad(const float* dcat, int dcat_ld, const float* const* dp, const int* scales, int nbranch, float* dfeat, int N,
+                      int H, int W, int C, void* stream);
 int uem_bilinear_up_fwd(const float* x, float* y, int N, int h, int w, int C, int H, int W, int y_ld,
                         int align_corners, const float* scale, const float* shift, int relu, void* stream);
 int uem_bilinear_up_bwd(const float* dy, float* dx /* = */, int N, int h, int w, int C, int H, int W, int dy_ld,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "uem_instnorm_bwd": [P, P, P, P, I, I, I, P],
     "uem_adaptive_avgpool_fwd": [P, P, I, I, I, I, I, P],
     "uem_adaptive_avgpool_bwd": [P, P, I, I, I, I, I, P],
+    "uem_ppm_feat_grad": [P, I, P, P, I, P, I, I, I, I, P],
     "uem_bilinear_up_fwd": [P, P, I, I, I, I, I, I, I, I, P, P, I, P],
     "uem_bilinear_up_bwd": [P, P, I, I, I, I, I, I, I, I, P],
     "uem_dropout2d": [P, P, P, I, I, I, F, c_uint64, P],

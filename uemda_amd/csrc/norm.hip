@@ -1068,6 +1068,61 @@ extern "C" int uem_adaptive_avgpool_bwd(const float* dy, float* dx, int N, int H
     return uem_check_launch("adaptive_avgpool_bwd");
 }
 
+// The feature gradient of a PPM head in ONE pass (Encoder.py:34-41 backward): dfeat = dcat[..., :C] (the concat's first C
+// channels, row stride dcat_ld) + sum over the pooled branches of the adaptive-average-pool backward of dp_i -- instead of a
+// slice copy plus one read-modify-write pass over dfeat per branch (5 passes over a 268 MB tensor per head).  Bins of scales
+// that do not divide the map overlap, so a pixel collects from up to 2 x 2 bins per branch; the terms are added in the order
+// of the per-branch kernel (branch by branch, bin rows outermost).
+struct PpmGradP {
+    const float* dp[4];
+    int S[4];
+    int nb;
+};
+__global__ __launch_bounds__(256) void ppm_feat_grad_kernel(const float* __restrict__ dcat, int dcat_ld, const PpmGradP g,
+                                                            float* __restrict__ dfeat, int N, int H, int W, int C) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 4;
+        int64_t t = i / cv;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 v = *reinterpret_cast<const float4*>(dcat + (((size_t)n * H + yy) * W + xx) * dcat_ld + c);
+        for (int b = 0; b < g.nb; ++b) {
+            const int S = g.S[b];
+            float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            // bins containing yy: lo(o) <= yy < hi(o); o = floor(yy*S/H) always does, o - 1 may (overlap), never more
+            const int oy1 = (yy * S) / H, ox1 = (xx * S) / W;
+            for (int oy = max(oy1 - 1, 0); oy <= min(oy1 + 1, S - 1); ++oy) {
+                const int y0 = bin_lo(oy, H, S), y1 = bin_hi(oy, H, S);
+                if (yy < y0 || yy >= y1) continue;
+                for (int ox = max(ox1 - 1, 0); ox <= min(ox1 + 1, S - 1); ++ox) {
+                    const int x0 = bin_lo(ox, W, S), x1 = bin_hi(ox, W, S);
+                    if (xx < x0 || xx >= x1) continue;
+                    const float area = (float)((y1 - y0) * (x1 - x0));
+                    const float4 d = *reinterpret_cast<const float4*>(g.dp[b] + (((size_t)n * S + oy) * S + ox) * C + c);
+                    sacc.x += d.x / area; sacc.y += d.y / area; sacc.z += d.z / area; sacc.w += d.w / area;
+                }
+            }
+            v.x += sacc.x; v.y += sacc.y; v.z += sacc.z; v.w += sacc.w;
+        }
+        *reinterpret_cast<float4*>(dfeat + (((size_t)n * H + yy) * W + xx) * C + c) = v;
+    }
+}
+extern "C" int uem_ppm_feat_grad(const float* dcat, int dcat_ld, const float* const* dp, const int* scales, int nbranch, float* dfeat,
+                                 int N, int H, int W, int C, void* stream) {
+    UEM_REQUIRE(dcat && dp && scales && dfeat && nbranch >= 0 && nbranch <= 4 && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 &&
+                    dcat_ld >= C && (dcat_ld % 4) == 0, "ppm_feat_grad: bad arguments");
+    PpmGradP g;
+    g.nb = nbranch;
+    for (int i = 0; i < 4; ++i) { g.dp[i] = i < nbranch ? dp[i] : nullptr; g.S[i] = i < nbranch ? scales[i] : 1; }
+    for (int i = 0; i < nbranch; ++i) UEM_REQUIRE(g.dp[i] && g.S[i] > 0 && g.S[i] <= H && g.S[i] <= W, "ppm_feat_grad: bad branch %d", i);
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    ppm_feat_grad_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dcat, dcat_ld, g, dfeat, N, H, W, C);
+    return uem_check_launch("ppm_feat_grad");
+}
+
 __global__ void bilinear_up_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int h, int w, int C, int H,
                                        int W, int y_ld, int align, const float* __restrict__ scale,
                                        const float* __restrict__ shift, int relu) {
@@ -1123,9 +1178,58 @@ __global__ void bilinear_up_bwd_kernel(const float* __restrict__ dy, float* __re
         dx[i] = s;
     }
 }
+// block = (image, low-res cell, 64 channels): the cell's row / column weights over the destination map go to LDS once (the
+// gather above recomputed both lerps -- two divisions each -- for every one of the H x W pixels, per element), then 16 pixel
+// groups x 16 lanes x float4 walk the pixels of the cell's support with 256-byte accesses and combine through LDS
+__global__ __launch_bounds__(256) void bilinear_up_bwd_tiled_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int h,
+                                                                    int w, int C, int H, int W, int dy_ld, int align) {
+    __shared__ float wy[128], wx[128];
+    __shared__ int ylist[128], xlist[128], ny, nx;
+    __shared__ float red[16][64];
+    const int cgroups = C >> 6;
+    int b = blockIdx.x;
+    const int cg = b % cgroups; b /= cgroups;
+    const int cx = b % w; b /= w;
+    const int cy = b % h;
+    const int n = b / h;
+    const int tid = threadIdx.x, l = tid & 15, g = tid >> 4, c = cg * 64 + l * 4;
+    if (tid < H) {
+        const Lerp ly = lerp_setup(tid, h, H, align != 0);
+        wy[tid] = (ly.i0 == cy ? ly.l0 : 0.f) + (ly.i1 == cy ? ly.l1 : 0.f);
+    }
+    if (tid >= 128 && tid - 128 < W) {
+        const Lerp lx = lerp_setup(tid - 128, w, W, align != 0);
+        wx[tid - 128] = (lx.i0 == cx ? lx.l0 : 0.f) + (lx.i1 == cx ? lx.l1 : 0.f);
+    }
+    __syncthreads();
+    if (tid == 0) { int k = 0; for (int Y = 0; Y < H; ++Y) if (wy[Y] != 0.f) ylist[k++] = Y; ny = k; }
+    if (tid == 64) { int k = 0; for (int X = 0; X < W; ++X) if (wx[X] != 0.f) xlist[k++] = X; nx = k; }
+    __syncthreads();
+    const int npix = ny * nx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = g; q < npix; q += 16) {
+        const int Y = ylist[q / nx], X = xlist[q % nx];
+        const float wgt = wy[Y] * wx[X];
+        const float4 d = *reinterpret_cast<const float4*>(dy + (((size_t)n * H + Y) * W + X) * dy_ld + c);
+        acc.x += wgt * d.x; acc.y += wgt * d.y; acc.z += wgt * d.z; acc.w += wgt * d.w;
+    }
+    red[g][l * 4 + 0] = acc.x; red[g][l * 4 + 1] = acc.y; red[g][l * 4 + 2] = acc.z; red[g][l * 4 + 3] = acc.w;
+    __syncthreads();
+    if (tid < 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a += red[j][tid];
+        dx[(((size_t)n * h + cy) * w + cx) * C + cg * 64 + tid] = a;
+    }
+}
 extern "C" int uem_bilinear_up_bwd(const float* dy, float* dx, int N, int h, int w, int C, int H, int W, int dy_ld,
                                    int align_corners, void* stream) {
     UEM_REQUIRE(dy && dx && N > 0 && h > 0 && w > 0 && C > 0 && H > 0 && W > 0 && dy_ld >= C, "bilinear_up_bwd: bad arguments");
+    if (C % 64 == 0 && H <= 128 && W <= 128 && dy_ld % 4 == 0 && (((uintptr_t)dy) & 15) == 0 && (int64_t)N * h * w * (C / 64) < 2147483647LL) {
+        const int blocks = N * h * w * (C / 64);
+        bilinear_up_bwd_tiled_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dy, dx, N, h, w, C, H, W, dy_ld, align_corners);
+        return uem_check_launch("bilinear_up_bwd");
+    }
     const int64_t total = (int64_t)N * h * w * C;
     bilinear_up_bwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dy, dx, N, h, w, C, H, W, dy_ld, align_corners);
     return uem_check_launch("bilinear_up_bwd");

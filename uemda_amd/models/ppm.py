@@ -30,6 +30,24 @@ def _avgpool(x, s):
     return y
 
 
+# layer5 and layer6 pool the SAME feature map (Encoder.py:148-149): the pooled tensors are computed once per forward
+_pool_cache = {"key": None, "pools": {}}
+
+
+def _shared_pool(feat, s):
+    key = (feat.data_ptr(), feat._version, tuple(feat.shape))
+    if _pool_cache["key"] != key:
+        _pool_cache["key"], _pool_cache["pools"] = key, {}
+    pools = _pool_cache["pools"]
+    if s not in pools:
+        pools[s] = _avgpool(feat, s)
+    return pools[s]
+
+
+def clear_pool_cache():
+    _pool_cache["key"], _pool_cache["pools"] = None, {}
+
+
 class PPMHeadFn(Function):
     # operand precision of the head's convs (None = the global setting); Deeplabv2 sets "bf16" for the bf16-storage model
     prec = None
@@ -59,7 +77,7 @@ class PPMHeadFn(Function):
             conv, bn = head.ppm[i][1], head.ppm[i][2]
             if training and n * s * s < 2:
                 raise ValueError("Expected more than 1 value per channel when training (PPM scale-1 branch needs B >= 2)")
-            p = _avgpool(feat, s)
+            p = _shared_pool(feat, s)
             z = ops.conv2d(p, ops.weight_ohwi(conv.weight))
             st = _BN.stats(z, bn)
             call("uem_bilinear_up_fwd", ptr(z), ptr(cat[..., cin + 512 * i:]), n, s, s, 512, h, w, ctot, 0,
@@ -111,7 +129,7 @@ class PPMHeadFn(Function):
         dzc = ops.bn_backward(zc, da, stc, grad_buffer(bn0.weight), grad_buffer(bn0.bias), None, True, dx=da)
         ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
         dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose(ops.weight_ohwi(conv0.weight)), cat.shape, pad=1)
-        dfeat = dcat[..., :cin].contiguous()
+        dps = []
         for i, s in enumerate(head.pool_scales):
             conv, bn = head.ppm[i][1], head.ppm[i][2]
             p, z, stb = branch[3 * i:3 * i + 3]
@@ -120,8 +138,16 @@ class PPMHeadFn(Function):
             call("uem_bilinear_up_bwd", ptr(dcat[..., cin + 512 * i:]), ptr(du), n, s, s, 512, h, w, ctot, 0, stream())
             dz = ops.bn_backward(z, du, st, grad_buffer(bn.weight), grad_buffer(bn.bias), None, True, dx=du)
             ops.conv2d_wgrad(p, dz, grad_ohwi(conv.weight))
-            dp = ops.conv2d_dgrad(dz, ops.weight_transpose(ops.weight_ohwi(conv.weight)), p.shape)
-            call("uem_adaptive_avgpool_bwd", ptr(dp), ptr(dfeat), n, h, w, cin, s, stream())
+            dps.append(ops.conv2d_dgrad(dz, ops.weight_transpose(ops.weight_ohwi(conv.weight)), p.shape))
+        # concat slice + the four adaptive-average-pool backward passes in one kernel (one read of dcat's slice, one write)
+        import ctypes
+        nb = len(dps)
+        if nb > 4:
+            raise ops.UemError("PPMBilinear: at most 4 pooled branches")
+        dfeat = torch.empty((n, h, w, cin), device=feat.device, dtype=torch.float32)
+        dp_ptrs = (ctypes.c_void_p * 4)(*([ptr(t) for t in dps] + [None] * (4 - nb)))
+        sc = (ctypes.c_int * 4)(*(list(head.pool_scales) + [1] * (4 - nb)))
+        call("uem_ppm_feat_grad", ptr(dcat), ctot, dp_ptrs, sc, nb, ptr(dfeat), n, h, w, cin, stream())
         return (dfeat, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
