@@ -1080,6 +1080,28 @@ struct PpmGradP {
 };
 __global__ __launch_bounds__(256) void ppm_feat_grad_kernel(const float* __restrict__ dcat, int dcat_ld, const PpmGradP g,
                                                             float* __restrict__ dfeat, int N, int H, int W, int C) {
+    // per block: for every branch and every row / column of the map, the first bin that contains it, how many do (1 or 2:
+    // bins overlap when the scale does not divide the map) and every bin's extent -- the per-element loop is then table
+    // look-ups and at most 2 x 2 sixteen-byte loads per branch (H, W <= 128, scales <= 16: checked by the launcher)
+    __shared__ unsigned char first_y[4][128], cnt_y[4][128], first_x[4][128], cnt_x[4][128];
+    __shared__ float ext_y[4][16], ext_x[4][16];
+    for (int t = threadIdx.x; t < 4 * 128; t += 256) {
+        const int b = t >> 7, p = t & 127;
+        if (b >= g.nb) continue;
+        const int S = g.S[b];
+        if (p < H) {
+            int f = -1, k = 0;
+            for (int o = 0; o < S; ++o) if (p >= bin_lo(o, H, S) && p < bin_hi(o, H, S)) { if (f < 0) f = o; ++k; }
+            first_y[b][p] = (unsigned char)f; cnt_y[b][p] = (unsigned char)k;
+        }
+        if (p < W) {
+            int f = -1, k = 0;
+            for (int o = 0; o < S; ++o) if (p >= bin_lo(o, W, S) && p < bin_hi(o, W, S)) { if (f < 0) f = o; ++k; }
+            first_x[b][p] = (unsigned char)f; cnt_x[b][p] = (unsigned char)k;
+        }
+        if (p < S) { ext_y[b][p] = (float)(bin_hi(p, H, S) - bin_lo(p, H, S)); ext_x[b][p] = (float)(bin_hi(p, W, S) - bin_lo(p, W, S)); }
+    }
+    __syncthreads();
     const int cv = C >> 2;
     const int64_t total = (int64_t)N * H * W * cv;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -1092,19 +1114,13 @@ __global__ __launch_bounds__(256) void ppm_feat_grad_kernel(const float* __restr
         for (int b = 0; b < g.nb; ++b) {
             const int S = g.S[b];
             float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-            // bins containing yy: lo(o) <= yy < hi(o); o = floor(yy*S/H) always does, o - 1 may (overlap), never more
-            const int oy1 = (yy * S) / H, ox1 = (xx * S) / W;
-            for (int oy = max(oy1 - 1, 0); oy <= min(oy1 + 1, S - 1); ++oy) {
-                const int y0 = bin_lo(oy, H, S), y1 = bin_hi(oy, H, S);
-                if (yy < y0 || yy >= y1) continue;
-                for (int ox = max(ox1 - 1, 0); ox <= min(ox1 + 1, S - 1); ++ox) {
-                    const int x0 = bin_lo(ox, W, S), x1 = bin_hi(ox, W, S);
-                    if (xx < x0 || xx >= x1) continue;
-                    const float area = (float)((y1 - y0) * (x1 - x0));
+            const int oy0 = first_y[b][yy], ny = cnt_y[b][yy], ox0 = first_x[b][xx], nx = cnt_x[b][xx];
+            for (int oy = oy0; oy < oy0 + ny; ++oy)
+                for (int ox = ox0; ox < ox0 + nx; ++ox) {
+                    const float area = ext_y[b][oy] * ext_x[b][ox];         // small integers: exact, = (y1 - y0) * (x1 - x0)
                     const float4 d = *reinterpret_cast<const float4*>(g.dp[b] + (((size_t)n * S + oy) * S + ox) * C + c);
                     sacc.x += d.x / area; sacc.y += d.y / area; sacc.z += d.z / area; sacc.w += d.w / area;
                 }
-            }
             v.x += sacc.x; v.y += sacc.y; v.z += sacc.z; v.w += sacc.w;
         }
         *reinterpret_cast<float4*>(dfeat + (((size_t)n * H + yy) * W + xx) * C + c) = v;
@@ -1117,7 +1133,8 @@ extern "C" int uem_ppm_feat_grad(const float* dcat, int dcat_ld, const float* co
     PpmGradP g;
     g.nb = nbranch;
     for (int i = 0; i < 4; ++i) { g.dp[i] = i < nbranch ? dp[i] : nullptr; g.S[i] = i < nbranch ? scales[i] : 1; }
-    for (int i = 0; i < nbranch; ++i) UEM_REQUIRE(g.dp[i] && g.S[i] > 0 && g.S[i] <= H && g.S[i] <= W, "ppm_feat_grad: bad branch %d", i);
+    for (int i = 0; i < nbranch; ++i) UEM_REQUIRE(g.dp[i] && g.S[i] > 0 && g.S[i] <= H && g.S[i] <= W && g.S[i] <= 16, "ppm_feat_grad: bad branch %d", i);
+    if (H > 128 || W > 128) return uem_fail(UEM_ERR_UNSUPPORTED, "ppm_feat_grad: feature maps up to 128 x 128");
     const int64_t total = (int64_t)N * H * W * (C / 4);
     ppm_feat_grad_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dcat, dcat_ld, g, dfeat, N, H, W, C);
     return uem_check_launch("ppm_feat_grad");

@@ -128,7 +128,7 @@ class PPMHeadFn(Function):
         stc = _st_from(stcb, ctx.training)
         dzc = ops.bn_backward(zc, da, stc, grad_buffer(bn0.weight), grad_buffer(bn0.bias), None, True, dx=da)
         ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
-        dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose(ops.weight_ohwi(conv0.weight)), cat.shape, pad=1)
+        dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose_cached(conv0.weight), cat.shape, pad=1)
         dps = []
         for i, s in enumerate(head.pool_scales):
             conv, bn = head.ppm[i][1], head.ppm[i][2]
@@ -138,7 +138,7 @@ class PPMHeadFn(Function):
             call("uem_bilinear_up_bwd", ptr(dcat[..., cin + 512 * i:]), ptr(du), n, s, s, 512, h, w, ctot, 0, stream())
             dz = ops.bn_backward(z, du, st, grad_buffer(bn.weight), grad_buffer(bn.bias), None, True, dx=du)
             ops.conv2d_wgrad(p, dz, grad_ohwi(conv.weight))
-            dps.append(ops.conv2d_dgrad(dz, ops.weight_transpose(ops.weight_ohwi(conv.weight)), p.shape))
+            dps.append(ops.conv2d_dgrad(dz, ops.weight_transpose_cached(conv.weight), p.shape))
         # concat slice + the four adaptive-average-pool backward passes in one kernel (one read of dcat's slice, one write)
         import ctypes
         nb = len(dps)
