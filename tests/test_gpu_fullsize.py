@@ -141,3 +141,52 @@ def test_conv_adjoint_identities_at_b32(cin, cout, k, stride, dil, hin):
     scale = (y.double().norm() * dy.double().norm())
     assert abs(a - b) / scale < 1e-5 and abs(a - c) / scale < 1e-5, (float(a), float(b), float(c))
     assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
+
+
+def test_stem_fusions_at_b32():
+    """The stem's fused passes at the benchmark size (32 tiles of 512x512: a 32 x 256 x 256 x 64 map, 537 MB) against the passes
+    they replace: max-pool with BatchNorm + ReLU in its fetch is bit-identical to the max-pool of the materialised map (values and
+    argmax taps); the BatchNorm backward that reads the pooled gradient agrees with max-pool backward + BatchNorm backward to
+    summation order; every input pixel receives each window's gradient at most once (sum of dz over a channel is zero:
+    training-mode BatchNorm backward annihilates the mean)."""
+    from uemda_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(12)
+    z = torch.randn(B, 256, 256, 64, device="cuda", generator=g)
+    gamma = torch.rand(64, device="cuda", generator=g) + 0.5
+    beta = torch.randn(64, device="cuda", generator=g) * 0.3
+    st = ops.bn_stats(z, gamma, beta, torch.zeros(64, device="cuda"), torch.ones(64, device="cuda"), True)
+    y, idx = ops.maxpool_affine_fwd(z, st, True)
+    a = ops.affine_act(z, st, relu=True)
+    y_ref, idx_ref = ops.maxpool_fwd(a, True)
+    assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
+    del a, y_ref, idx_ref
+    dy = torch.randn(y.shape, device="cuda", generator=g)
+    gg, gb = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dz = ops.bn_backward_pooled(z, dy, idx, st, gg, gb)
+    da = ops.maxpool_bwd(dy, idx, z.shape)
+    gg2, gb2 = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dz_ref = ops.bn_backward(z, da, st, gg2, gb2, None, True, dx=da)
+    torch.testing.assert_close(gg, gg2, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(gb, gb2, rtol=1e-4, atol=1e-2)
+    assert float((dz - dz_ref).abs().max()) <= 1e-5 * float(dz_ref.abs().max()) + 1e-6
+    # sum over (n, y, x) of the masked-and-normalised gradient: sum_p dz = scale * (sum dp - M * dbeta / M) = 0 up to rounding
+    assert float(dz.double().sum((0, 1, 2)).abs().max()) < 1e-2 * float(dz.double().abs().sum((0, 1, 2)).max()) * 1e-3 + 1.0
+
+
+def test_ppm_feature_gradient_at_b32():
+    """uem_ppm_feat_grad (concat slice + the four adaptive-average-pool backward passes in one kernel) against the slice copy and
+    the per-branch read-modify-write kernel it replaces, bit for bit, on the benchmark's 32 x 32 x 32 x 2048 feature map."""
+    import ctypes
+    from uemda_amd.ops import call, ptr, stream
+    g = torch.Generator(device="cuda").manual_seed(13)
+    n, h, w, cin, ctot = B, 32, 32, 2048, 4096
+    scales = (1, 2, 3, 6)
+    dcat = torch.randn(n, h, w, ctot, device="cuda", generator=g)
+    dps = [torch.randn(n, s, s, cin, device="cuda", generator=g) for s in scales]
+    ref = dcat[..., :cin].contiguous()
+    for s, dp in zip(scales, dps):
+        call("uem_adaptive_avgpool_bwd", ptr(dp), ptr(ref), n, h, w, cin, s, stream())
+    out = torch.empty_like(ref)
+    call("uem_ppm_feat_grad", ptr(dcat), ctot, (ctypes.c_void_p * 4)(*[ptr(t) for t in dps]), (ctypes.c_int * 4)(*scales), 4, ptr(out),
+         n, h, w, cin, stream())
+    assert torch.equal(out, ref)
