@@ -292,9 +292,9 @@ __device__ __forceinline__ bf16x8 wgb_frag(const unsigned short* img, const int 
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int TM, int TN, int NTAP, int S, int D>
+template <int TM, int TN, int NTAP, int S, int D, int BK_ = 32>
 struct WgbCfg {
-    static constexpr int BK = 32;
+    static constexpr int BK = BK_;                                         // pixels per step (64 on the linear 1x1 layers)
     static constexpr int MT = TM / 64, NT = TN / 64;
     static constexpr int XR = NTAP == 1 ? BK : (BK - 1) * S + 2 * D + 1;
     static constexpr int RPI_D = 512 / TM, RPI_X = 512 / TN;               // rows per 1-KiB wave instruction
@@ -308,9 +308,9 @@ struct WgbCfg {
     static constexpr int BPC = ACC <= 64 ? 3 : 2;
 };
 
-template <int TM, int TN, int NTAP, int S, int D, bool LINEAR>
-__global__ __launch_bounds__(256, (WgbCfg<TM, TN, NTAP, S, D>::BPC)) void wgrad_bf16_kernel(const WgP p) {
-    using C = WgbCfg<TM, TN, NTAP, S, D>;
+template <int TM, int TN, int NTAP, int S, int D, bool LINEAR, int BK_ = 32>
+__global__ __launch_bounds__(256, (WgbCfg<TM, TN, NTAP, S, D, BK_>::BPC)) void wgrad_bf16_kernel(const WgP p) {
+    using C = WgbCfg<TM, TN, NTAP, S, D, BK_>;
     constexpr int MT = C::MT, NT = C::NT, BK = C::BK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
@@ -569,9 +569,9 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
 }
 
 // ---- bf16-storage weight gradient: launcher ------------------------------------------------------------------
-template <int TM, int TN, int NTAP, int S, int D, bool LINEAR>
+template <int TM, int TN, int NTAP, int S, int D, bool LINEAR, int BK_ = 32>
 static void wgb_go(WgP p, hipStream_t st) {
-    using C = WgbCfg<TM, TN, NTAP, S, D>;
+    using C = WgbCfg<TM, TN, NTAP, S, D, BK_>;
     p.tiles_co = p.Cout / TM;
     p.tiles_ci = p.Cin / TN;
     const int tiles = p.tiles_co * p.tiles_ci * (NTAP == 3 ? p.KH : 1);
@@ -591,7 +591,7 @@ static void wgb_go(WgP p, hipStream_t st) {
     p.steps_per_split = (int)uem_cdiv(p.steps_total, splits);
     splits = (int)uem_cdiv(p.steps_total, p.steps_per_split);
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
-    auto k = wgrad_bf16_kernel<TM, TN, NTAP, S, D, LINEAR>;
+    auto k = wgrad_bf16_kernel<TM, TN, NTAP, S, D, LINEAR, BK_>;
     static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
     (void)attr;
     k<<<grid, 256, C::LDS_BYTES, st>>>(p);
@@ -599,7 +599,14 @@ static void wgb_go(WgP p, hipStream_t st) {
 template <int TM, int TN>
 static bool wgb_dispatch(const WgP& p, const uem_conv_shape* s, hipStream_t st) {
     if (s->KH == 1 && s->KW == 1 && s->pad == 0) {
-        if (s->stride == 1) { wgb_go<TM, TN, 1, 1, 0, true>(p, st); return true; }
+        if (s->stride == 1) {
+            // 64-pixel steps on the linear 1x1 layers: a 32-pixel step is two MFMA k-steps per barrier (4 MFMAs per wave),
+            // too little work per step for layers that only have to stream their operands
+            static const int bk64 = getenv("UEM_WGRAD_BF16_BK64") ? atoi(getenv("UEM_WGRAD_BF16_BK64")) : 1;
+            if (bk64) wgb_go<TM, TN, 1, 1, 0, true, 64>(p, st);
+            else wgb_go<TM, TN, 1, 1, 0, true>(p, st);
+            return true;
+        }
         if (s->stride == 2 && s->Wo % 32 == 0) { wgb_go<TM, TN, 1, 2, 0, false>(p, st); return true; }
         return false;
     }
