@@ -85,7 +85,8 @@ int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* dx, const ue
                           float* tile_partials, int flags, void* stream);
 /* stem: x4 is the NHWC4 image (C padded 3->4), w8 is [64][7][8][4] (kx padded 7->8, c 3->4).     */
 int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream);
-/* the same with the per-tile BatchNorm statistics of uem_conv2d_fwd_stats out of the epilogue ([2][64][M/128]; N*Ho*Wo % 128 == 0);
+/* the same with the per-tile BatchNorm statistics of uem_conv2d_fwd_stats out of the epilogue ([2][64][M/128]; N*Ho*Wo % 128 == 0):
+ * conv1 + the statistics pass of bn1, uemda/_resnets.py:149-150;
  * flags: 0 or one UEM_CONV_PREC_* operand precision                                                                      */
 int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags,
                               void* stream);
@@ -151,7 +152,8 @@ int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* d
 int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
-/* BatchNorm(+ReLU, mask recomputed from x) backward of the layer in front of that max-pool, reading the POOLED gradient
+/* BatchNorm(+ReLU, mask recomputed from x) backward of the layer in front of that max-pool (autograd of bn1 / relu / maxpool,
+ * uemda/_resnets.py:150-153), reading the POOLED gradient
  * dy_pool (N, Ho, Wo, C) and the argmax taps in gather form instead of uem_maxpool3x3s2_bwd's (N, H, W, C) output: same
  * sums and the same dx as uem_bn_bwd_reduce / uem_bn_bwd_apply on that tensor                                             */
 int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
@@ -180,7 +182,8 @@ int uem_instnorm_bwd(const float* y, const float* dy, const float* save_invstd, 
 /* ---- PPM head pieces: adaptive avg-pool + bilinear (align_corners=False) (Encoder.py:18,48-51) ------ */
 int uem_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int S, void* stream);
 int uem_adaptive_avgpool_bwd(const float* dy, float* dx /* += */, int N, int H, int W, int C, int S, void* stream);
-/* the feature gradient of a PPM head in one pass: dfeat (N,H,W,C) = dcat[..., :C] (row stride dcat_ld) + sum_i
+/* the feature gradient of a PPM head in one pass (autograd of the concat and the pooled branches, uemda/models/Encoder.py:45-54):
+ * dfeat (N,H,W,C) = dcat[..., :C] (row stride dcat_ld) + sum_i
  * adaptive_avgpool_bwd(dp[i] (N,S_i,S_i,C)) -- replaces the slice copy and one uem_adaptive_avgpool_bwd pass per branch; dp and
  * scales are HOST arrays of nbranch <= 4 entries (device pointers / bin counts)                                          */
 int uem_ppm_feat_grad(const float* dcat, int dcat_ld, const float* const* dp, const int* scales, int nbranch, float* dfeat, int N,
