@@ -35,6 +35,9 @@ struct WgP {
     int M, N, H, W, Cin, Ho, Wo, Cout, KH, KW, pad, x_ld, dy_ld;
     int steps_total, steps_per_split, tiles_co, tiles_ci;
     unsigned x_bytes, dy_bytes;
+    // batched pixel-reduction GEMM (Winograd weight gradient, uem_wino_wgrad_gemm; 1x1 LINEAR form only): item b reduces the rows
+    // [b*M, (b+1)*M) of x / dy into dw + b*Cout*Cin; nbatch == 1 everywhere else
+    int nbatch;
 };
 
 __device__ __forceinline__ i32x4 wg_rsrc(const void* p, unsigned bytes) {
@@ -84,14 +87,16 @@ __global__ __launch_bounds__(256, (WgCfg<BK, TM, TN, NTAP, S, D, AFFINE, LINEAR>
         const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int split = lin / ntiles;
-    int t_ = lin - split * ntiles;
+    const int split = lin / (ntiles * p.nbatch);
+    int t_ = lin - split * (ntiles * p.nbatch);
+    const int bi = t_ / ntiles;                                            // batch item (0 unless batched)
+    t_ -= bi * ntiles;
     const int ci_t = t_ % p.tiles_ci; t_ /= p.tiles_ci;
     const int ky = t_ % rows_k;
     const int co_t = t_ / rows_k;
     const int co0 = co_t * TM, ci0 = ci_t * TN;
-    const int q_beg = split * p.steps_per_split;
-    const int q_end = min(p.steps_total, q_beg + p.steps_per_split);
+    const int q_beg = bi * p.steps_total + split * p.steps_per_split;
+    const int q_end = bi * p.steps_total + min(p.steps_total, (split + 1) * p.steps_per_split);
     const int T = q_end - q_beg;
 
     const i32x4 rs_d = wg_rsrc(p.dy, p.dy_bytes), rs_x = wg_rsrc(p.x, p.x_bytes);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, (WgCfg<BK, TM, TN, NTAP, S, D, AFFINE, LINEAR>
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                float* base = p.dw + (size_t)tap * p.Cin + (ci0 + wn + j * 32 + fr);
+                float* base = p.dw + (size_t)bi * p.Cout * row_ld + (size_t)tap * p.Cin + (ci0 + wn + j * 32 + fr);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -476,8 +481,8 @@ static void wg_go(WgP p, bool affine, hipStream_t st) {
     using C = WgCfg<BK, TM, TN, NTAP, S, D, false, LINEAR>;
     p.tiles_co = p.Cout / TM;
     p.tiles_ci = p.Cin / TN;
-    const int tiles = p.tiles_co * p.tiles_ci * (NTAP == 3 ? p.KH : 1);
-    p.steps_total = (int)uem_cdiv(p.M, BK);
+    const int tiles = p.tiles_co * p.tiles_ci * (NTAP == 3 ? p.KH : 1) * p.nbatch;
+    p.steps_total = (int)uem_cdiv(p.M, BK);                                // per batch item
     // split-K sizing.  Blocks of one launch run in lock step, so the grid is sized to whole ROUNDS of the chip's resident
     // block slots; every block ends with one fp32-atomic pass over its tile (chip-wide 1.3 TB/s), so the fewest rounds that
     // fill the slots to >= 97 % win (profiles/r02_b_wgrad_sweep.txt: 1 round beats 2 and 3 wherever it fills the chip).
@@ -504,13 +509,13 @@ static void wg_go(WgP p, bool affine, hipStream_t st) {
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
     if (affine) {
         auto k = wgrad_dma_kernel<BK, TM, TN, NTAP, S, D, true, LINEAR>;
-        static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
-        (void)attr;
+        // per launch, not once per process: the attribute is per device and the C ABI takes streams of any device
+        if (C::LDS_BYTES > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;
         k<<<grid, 256, C::LDS_BYTES, st>>>(p);
     } else {
         auto k = wgrad_dma_kernel<BK, TM, TN, NTAP, S, D, false, LINEAR>;
-        static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
-        (void)attr;
+        // per launch, not once per process: the attribute is per device and the C ABI takes streams of any device
+        if (C::LDS_BYTES > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;
         k<<<grid, 256, C::LDS_BYTES, st>>>(p);
     }
 }
@@ -546,7 +551,7 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
     p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
     p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
     p.KH = s->KH; p.KW = s->KW; p.pad = s->pad; p.x_ld = s->x_ld; p.dy_ld = s->y_ld;
-    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db; p.nbatch = 1;
     // tile rule (profiles/r02_b_wgrad_sweep.txt): 128 output channels x 64 input channels everywhere -- the narrower input
     // tile halves the LDS footprint (3 resident blocks per CU instead of 2 on the 1x1 layers) and the per-block atomic pass
     const bool m128 = s->Cout % 128 == 0 && g_tm != 64, n128 = s->Cin % 128 == 0 && g_tn == 128;
@@ -566,6 +571,25 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
     else if (n128) ok = wg_dispatch<32, 64, 128>(p, s, affine, st);
     else ok = wg_dispatch<32, 64, 64>(p, s, affine, st);
     return ok ? 1 : 0;
+}
+
+// Winograd weight gradient (winograd.hip): dU[pos][n][k] += sum over the T tiles of dM[pos][tile][n] * V[pos][tile][k], the 16 positions
+// as ONE batched launch of the linear (1x1) kernel; dU (16, N, K) must be zeroed by the caller (split-K atomics land in it).
+extern "C" int uem_wino_wgrad_gemm(const float* V, const float* dM, float* dU, int T, int K, int N, void* stream) {
+    UEM_REQUIRE(V && dM && dU && T > 0 && K > 0 && N > 0, "wino_wgrad_gemm: bad arguments");
+    if (T % 32 != 0 || K % 64 != 0 || N % 64 != 0 || (((uintptr_t)V | (uintptr_t)dM) & 15))
+        return uem_fail(UEM_ERR_UNSUPPORTED, "wino_wgrad_gemm: needs T %% 32 == 0, K %% 64 == 0, N %% 64 == 0, 16-byte aligned operands");
+    const double xb = 16.0 * T * K * 4.0, db = 16.0 * T * N * 4.0;
+    if (xb >= 4294967280.0 || db >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "wino_wgrad_gemm: tensor beyond 32-bit byte offsets");
+    WgP p;
+    p.x = V; p.dy = dM; p.in_scale = p.in_shift = nullptr; p.dw = dU;
+    p.M = T; p.N = 1; p.H = 1; p.W = T; p.Cin = K; p.Ho = 1; p.Wo = T; p.Cout = N;
+    p.KH = p.KW = 1; p.pad = 0; p.x_ld = K; p.dy_ld = N;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db; p.nbatch = 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (N % 128 == 0) wg_go<32, 128, 64, 1, 1, 0, true>(p, false, st);
+    else wg_go<32, 64, 64, 1, 1, 0, true>(p, false, st);
+    return uem_check_launch("wino_wgrad_gemm");
 }
 
 // ---- bf16-storage weight gradient: launcher ------------------------------------------------------------------
@@ -592,8 +616,7 @@ static void wgb_go(WgP p, hipStream_t st) {
     splits = (int)uem_cdiv(p.steps_total, p.steps_per_split);
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
     auto k = wgrad_bf16_kernel<TM, TN, NTAP, S, D, LINEAR, BK_>;
-    static const hipError_t attr = C::LDS_BYTES > 48 * 1024 ? hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) : hipSuccess;
-    (void)attr;
+    if (C::LDS_BYTES > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;
     k<<<grid, 256, C::LDS_BYTES, st>>>(p);
 }
 template <int TM, int TN>
@@ -627,7 +650,7 @@ extern "C" int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
     p.x = (const float*)x; p.dy = (const float*)dy; p.in_scale = p.in_shift = nullptr; p.dw = dw;
     p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
     p.KH = s->KH; p.KW = s->KW; p.pad = s->pad; p.x_ld = s->x_ld; p.dy_ld = s->y_ld;
-    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db; p.nbatch = 1;
     const bool ok = s->Cout % 128 == 0 ? wgb_dispatch<128, 64>(p, s, (hipStream_t)stream) : wgb_dispatch<64, 64>(p, s, (hipStream_t)stream);
     if (!ok) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_wgrad_bf16: 1x1 (stride 1, or 2 with rows of 32 pixels) and 3x3 on rows of 32 pixels only");
     return uem_check_launch("conv2d_wgrad_bf16");

@@ -1,0 +1,377 @@
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the deep layers (layer3 / layer4 / the PPM head's 4096 -> 512 conv),
+// exact fp32 (gfx950).  Y = A^T [ (G g G^T) (.) (B^T d B) ] A summed over input channels: 16 multiplies per 2x2 output block and
+// channel pair instead of 36, i.e. 2.25x fewer MFMA flops for the same fp32 result up to summation order (measured against fp64:
+// 4.2e-7 relative L2 against 1.9e-7 for the direct sum at Cin = 512 -- inside the 2-8e-7 band of the direct kernels).
+//
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]    A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// The 16 element-wise products over Cin are 16 independent GEMMs [tiles x Cin] x [Cin x Cout]: they run on the f32-MFMA 1x1 kernel
+// of conv.hip as ONE launch (`uem_wino_gemm`: rows = (position, tile), the filter bank of a row tile chosen by its position).  The
+// kernels in this file are the HBM-bound transforms around it:
+//   uem_wino_input    x (N,H,W,C) [-> relu(x*scale + shift), the producer's BatchNorm, zero padding AFTER it] -> V[16][T][C]
+//   uem_wino_output   M[16][T][C] -> y (N,H,W,C), with the per-128-pixel BatchNorm statistics (forward) or the first pass of the
+//                     consumer's BatchNorm+ReLU backward (data gradient) in the same [2][C][M/128] format as the conv epilogues
+//   uem_wino_dy       dY (N,H,W,C) -> dM[16][T][C] = A dY A^T     (weight gradient: dU[pos] = sum_tiles dM[pos]^T V[pos], a batched
+//                     pixel-reduction GEMM on the wgrad kernel, then uem_wino_filter_grad: dW += G^T dU G)
+//   uem_wino_filter   W (Cout,3,3,Cin) -> U[16][Cout][Cin]; flipped + transposed -> U'[16][Cin][Cout] for the data gradient
+//                     (dX = conv(dY, W') with W'[ci][ky][kx][co] = W[co][2-ky][2-kx][ci], same padding and dilation)
+// Dilation d: the d*d interleaved sub-images are independent dilation-1 convolutions; a tile is (image, sub-image, ty, tx).
+// Replaces cuDNN behind nn.Conv2d(3x3): reference uemda/_resnets.py:100-103 (conv2 of a Bottleneck), Encoder.py:35 (PPM conv_last).
+#include "common.h"
+
+struct WinoP {
+    const float* x;            // NHWC tensor read (input transform, dY transform) or written (output transform)
+    float* v;                  // transform-domain tensor [16][T][C]
+    const float* scale;        // input transform: optional BatchNorm affine (+ ReLU) prologue
+    const float* shift;
+    int relu;
+    int N, H, W, C, d;
+    int th, tw, T;             // tiles per sub-image (rows, cols), tiles in all
+    // output transform extras
+    float* tile_stats;         // [2][C][M/128]: sum y, sum y*y per 128-pixel group (32 tiles)
+    const float* bn_z;         // data gradient: first pass of the consumer's BatchNorm+ReLU backward
+    const float* bn_vec;       // (4, C): scale, shift, mean, invstd
+    float* tile_bnbwd;         // [2][C][M/128]: sum dp, sum dp*xhat
+};
+
+__device__ __forceinline__ void wino_tile(const WinoP& p, const int tile, int& n, int& ry, int& rx, int& ty, int& tx) {
+    tx = tile % p.tw;
+    int r = tile / p.tw;
+    ty = r % p.th;
+    r /= p.th;
+    const int dd = p.d * p.d;
+    const int sub = r % dd;
+    n = r / dd;
+    ry = sub / p.d;
+    rx = sub - ry * p.d;
+}
+
+__device__ __forceinline__ float4 f4add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(const float4 a, const float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4neg(const float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ float4 f4half(const float4 a) { return make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * a.z, 0.5f * a.w); }
+
+// block = 16 channel quads (64 channels) x 16 tiles; grid = (T / 16, C / 64)
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
+    const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int tile = blockIdx.x * 16 + tl;
+    const int c = blockIdx.y * 64 + q * 4;
+    if (tile >= p.T) return;
+    int n, ry, rx, ty, tx;
+    wino_tile(p, tile, n, ry, rx, ty, tx);
+    const int Hs = p.H / p.d, Ws = p.W / p.d;
+    float4 sc, sh;
+    if (AFFINE) { sc = *reinterpret_cast<const float4*>(p.scale + c); sh = *reinterpret_cast<const float4*>(p.shift + c); }
+    float4 dv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int Y = 2 * ty - 1 + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int X = 2 * tx - 1 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (Y >= 0 && Y < Hs && X >= 0 && X < Ws) {
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + (size_t)(Y * p.d + ry)) * p.W + (size_t)(X * p.d + rx)) * p.C + c);
+                if (AFFINE) {           // one fused rounding, as the conv kernels' operand fetch; zero padding stays zero
+                    v.x = __builtin_fmaf(v.x, sc.x, sh.x); v.y = __builtin_fmaf(v.y, sc.y, sh.y);
+                    v.z = __builtin_fmaf(v.z, sc.z, sh.z); v.w = __builtin_fmaf(v.w, sc.w, sh.w);
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+            }
+            dv[i][j] = v;
+        }
+    }
+    // B^T d: rows
+    float4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = f4sub(dv[0][j], dv[2][j]);
+        t[1][j] = f4add(dv[1][j], dv[2][j]);
+        t[2][j] = f4sub(dv[2][j], dv[1][j]);
+        t[3][j] = f4sub(dv[1][j], dv[3][j]);
+    }
+    // (B^T d) B: columns
+    const size_t pos_stride = (size_t)p.T * p.C;
+    float* const out = p.v + (size_t)tile * p.C + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 0) * pos_stride) = f4sub(t[i][0], t[i][2]);
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 1) * pos_stride) = f4add(t[i][1], t[i][2]);
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 2) * pos_stride) = f4sub(t[i][2], t[i][1]);
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 3) * pos_stride) = f4sub(t[i][1], t[i][3]);
+    }
+}
+
+// dM = A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1]; same thread mapping as the input transform
+__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoP p) {
+    const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int tile = blockIdx.x * 16 + tl;
+    const int c = blockIdx.y * 64 + q * 4;
+    if (tile >= p.T) return;
+    int n, ry, rx, ty, tx;
+    wino_tile(p, tile, n, ry, rx, ty, tx);
+    float4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            g[a][b] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + (size_t)((2 * ty + a) * p.d + ry)) * p.W + (size_t)((2 * tx + b) * p.d + rx)) * p.C + c);
+    float4 u[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u[0][s] = g[0][s];
+        u[1][s] = f4add(g[0][s], g[1][s]);
+        u[2][s] = f4sub(g[0][s], g[1][s]);
+        u[3][s] = f4neg(g[1][s]);
+    }
+    const size_t pos_stride = (size_t)p.T * p.C;
+    float* const out = p.v + (size_t)tile * p.C + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 0) * pos_stride) = u[i][0];
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 1) * pos_stride) = f4add(u[i][0], u[i][1]);
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 2) * pos_stride) = f4sub(u[i][0], u[i][1]);
+        *reinterpret_cast<float4*>(out + (size_t)(i * 4 + 3) * pos_stride) = f4neg(u[i][1]);
+    }
+}
+
+// block = 16 channel quads (64 channels) x 16 tile lanes x 2 tiles each = 32 tiles = 128 output pixels = one statistics group;
+// grid = (T / 32, C / 64).  EXTRA: 0 plain, 1 BatchNorm statistics of y (forward), 2 BatchNorm+ReLU backward partials (data gradient)
+template <int EXTRA>
+__global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
+    __shared__ float red[2][16][64];
+    const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + q * 4;
+    const size_t pos_stride = (size_t)p.T * p.C;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;
+    float4 sc, sh, mu, is;
+    if (EXTRA == 2) {
+        sc = *reinterpret_cast<const float4*>(p.bn_vec + c);
+        sh = *reinterpret_cast<const float4*>(p.bn_vec + p.C + c);
+        mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.C + c);
+        is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.C + c);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int tile = blockIdx.x * 32 + it * 16 + tl;
+        if (tile >= p.T) continue;
+        int n, ry, rx, ty, tx;
+        wino_tile(p, tile, n, ry, rx, ty, tx);
+        const float* const in = p.v + (size_t)tile * p.C + c;
+        float4 m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(in + (size_t)(i * 4 + j) * pos_stride);
+        float4 t[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = f4add(f4add(m[0][j], m[1][j]), m[2][j]);
+            t[1][j] = f4sub(f4sub(m[1][j], m[2][j]), m[3][j]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float4 y[2];
+            y[0] = f4add(f4add(t[a][0], t[a][1]), t[a][2]);
+            y[1] = f4sub(f4sub(t[a][1], t[a][2]), t[a][3]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const size_t off = (((size_t)n * p.H + (size_t)((2 * ty + a) * p.d + ry)) * p.W + (size_t)((2 * tx + b) * p.d + rx)) * p.C + c;
+                const float4 v = y[b];
+                *reinterpret_cast<float4*>(const_cast<float*>(p.x) + off) = v;
+                if (EXTRA == 1) {
+                    bb = f4add(bb, v);
+                    bg.x = fmaf(v.x, v.x, bg.x); bg.y = fmaf(v.y, v.y, bg.y); bg.z = fmaf(v.z, v.z, bg.z); bg.w = fmaf(v.w, v.w, bg.w);
+                }
+                if (EXTRA == 2) {
+                    const float4 z = *reinterpret_cast<const float4*>(p.bn_z + off);
+                    const float dx_ = z.x * sc.x + sh.x > 0.f ? v.x : 0.f, dy_ = z.y * sc.y + sh.y > 0.f ? v.y : 0.f;
+                    const float dz_ = z.z * sc.z + sh.z > 0.f ? v.z : 0.f, dw_ = z.w * sc.w + sh.w > 0.f ? v.w : 0.f;
+                    bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
+                    bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
+                    bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
+                }
+            }
+        }
+    }
+    if (EXTRA == 0) return;
+    *reinterpret_cast<float4*>(&red[0][tl][q * 4]) = bb;
+    *reinterpret_cast<float4*>(&red[1][tl][q * 4]) = bg;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, col = threadIdx.x & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += red[which][r][col];
+        float* const out = EXTRA == 1 ? p.tile_stats : p.tile_bnbwd;
+        out[((size_t)which * p.C + blockIdx.y * 64 + col) * (size_t)gridDim.x + blockIdx.x] = a;
+    }
+}
+
+// U = G g G^T.  TRANSPOSED = false: U[pos][co][ci] from w[co][ky][kx][ci];  true: U'[pos][ci][co] from the flipped taps w[co][2-ky][2-kx][ci]
+// (the data gradient's filter bank).  One thread per (co, ci quad); the transposed form goes through LDS so that both the reads
+// (ci contiguous) and the writes (co contiguous) are coalesced: block = 16 co x 16 ci quads.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin) {
+    __shared__ float tile[TRANSPOSED ? 8 : 1][16][65];                   // TRANSPOSED: [pos (half of them)][co][ci (64 + 1 pad)]
+    const int q = threadIdx.x & 15, col = threadIdx.x >> 4;
+    const int co = blockIdx.y * 16 + col, ci = blockIdx.x * 64 + q * 4;
+    float4 g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int ky = TRANSPOSED ? 2 - a : a, kx = TRANSPOSED ? 2 - b : b;
+            g[a][b] = *reinterpret_cast<const float4*>(w + (((size_t)co * 3 + ky) * 3 + kx) * Cin + ci);
+        }
+    float4 r[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        r[0][b] = g[0][b];
+        r[1][b] = f4half(f4add(f4add(g[0][b], g[1][b]), g[2][b]));
+        r[2][b] = f4half(f4add(f4sub(g[0][b], g[1][b]), g[2][b]));
+        r[3][b] = g[2][b];
+    }
+    const size_t pos_stride = (size_t)Cout * Cin;
+    const int wco = threadIdx.x & 15, wci0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = half * 2 + ii;
+            float4 u[4];
+            u[0] = r[i][0];
+            u[1] = f4half(f4add(f4add(r[i][0], r[i][1]), r[i][2]));
+            u[2] = f4half(f4add(f4sub(r[i][0], r[i][1]), r[i][2]));
+            u[3] = r[i][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!TRANSPOSED) {
+                    *reinterpret_cast<float4*>(U + (size_t)(i * 4 + j) * pos_stride + (size_t)co * Cin + ci) = u[j];
+                } else {
+                    float* t = &tile[ii * 4 + j][col][q * 4];
+                    t[0] = u[j].x; t[1] = u[j].y; t[2] = u[j].z; t[3] = u[j].w;
+                }
+            }
+        }
+        if (TRANSPOSED) {
+            __syncthreads();
+            // write U'[pos][ci][co]: 16 consecutive co per ci row
+#pragma unroll
+            for (int pl = 0; pl < 8; ++pl)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cil = wci0 + 16 * k;
+                    U[(size_t)(half * 8 + pl) * pos_stride + (size_t)(blockIdx.x * 64 + cil) * Cout + blockIdx.y * 16 + wco] = tile[pl][wco][cil];
+                }
+            __syncthreads();
+        }
+    }
+}
+
+// dW[co][ky][kx][ci] += (G^T dU G)[ky][kx], dU[pos][co][ci]; one thread per (co, ci quad)
+__global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __restrict__ dU, float* __restrict__ dw, const int Cout, const int Cin) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int cq = Cin / 4;
+    if (idx >= Cout * cq) return;
+    const int co = idx / cq, ci = (idx - co * cq) * 4;
+    const size_t pos_stride = (size_t)Cout * Cin;
+    float4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(dU + (size_t)(i * 4 + j) * pos_stride + (size_t)co * Cin + ci);
+    float4 s[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 h1 = f4half(m[1][j]), h2 = f4half(m[2][j]);
+        s[0][j] = f4add(f4add(m[0][j], h1), h2);
+        s[1][j] = f4sub(h1, h2);
+        s[2][j] = f4add(f4add(h1, h2), m[3][j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float4 h1 = f4half(s[a][1]), h2 = f4half(s[a][2]);
+        float4 o[3];
+        o[0] = f4add(f4add(s[a][0], h1), h2);
+        o[1] = f4sub(h1, h2);
+        o[2] = f4add(f4add(h1, h2), s[a][3]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float4* dst = reinterpret_cast<float4*>(dw + (((size_t)co * 3 + a) * 3 + b) * Cin + ci);
+            *dst = f4add(*dst, o[b]);
+        }
+    }
+}
+
+static int wino_geometry(WinoP& p, int N, int H, int W, int C, int d, const char* what) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || d <= 0 || d > 4) return uem_fail(UEM_ERR_INVALID, "%s: bad shape", what);
+    if (H % (2 * d) != 0 || W % (2 * d) != 0 || C % 64 != 0)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs H, W multiples of 2*dilation and C a multiple of 64", what);
+    p.N = N; p.H = H; p.W = W; p.C = C; p.d = d;
+    p.th = H / d / 2; p.tw = W / d / 2;
+    const int64_t T = (int64_t)N * d * d * p.th * p.tw;
+    if (T * 16 * C >= ((int64_t)1 << 30) || T % 32 != 0)                 // 32-bit byte offsets into the transform-domain tensor
+        return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs N*H*W/4 a multiple of 32 and 16*T*C < 2^30 elements (split the batch)", what);
+    p.T = (int)T;
+    p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.scale = p.shift = nullptr; p.relu = 0;
+    return UEM_OK;
+}
+
+extern "C" int uem_wino_input(const float* x, const float* in_scale, const float* in_shift, int relu, float* V, int N, int H, int W,
+                              int C, int dil, void* stream) {
+    UEM_REQUIRE(x && V, "wino_input: null pointer");
+    UEM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_input: scale and shift go together");
+    WinoP p;
+    const int rc = wino_geometry(p, N, H, W, C, dil, "wino_input");
+    if (rc) return rc;
+    p.x = x; p.v = V; p.scale = in_scale; p.shift = in_shift; p.relu = relu;
+    const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
+    if (in_scale) wino_input_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else wino_input_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    return uem_check_launch("wino_input");
+}
+
+extern "C" int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, void* stream) {
+    UEM_REQUIRE(dy && dM, "wino_dy: null pointer");
+    WinoP p;
+    const int rc = wino_geometry(p, N, H, W, C, dil, "wino_dy");
+    if (rc) return rc;
+    p.x = dy; p.v = dM;
+    const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
+    wino_dy_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    return uem_check_launch("wino_dy");
+}
+
+extern "C" int uem_wino_output(const float* Mt, float* y, int N, int H, int W, int C, int dil, float* tile_stats, const float* bn_z,
+                               const float* bn_vec, float* tile_bnbwd, void* stream) {
+    UEM_REQUIRE(Mt && y, "wino_output: null pointer");
+    UEM_REQUIRE((bn_z == nullptr) == (bn_vec == nullptr) && (bn_z == nullptr) == (tile_bnbwd == nullptr), "wino_output: bn_z, bn_vec and tile_bnbwd go together");
+    UEM_REQUIRE(!(tile_stats && tile_bnbwd), "wino_output: either forward statistics or backward partials");
+    WinoP p;
+    const int rc = wino_geometry(p, N, H, W, C, dil, "wino_output");
+    if (rc) return rc;
+    p.x = y; p.v = const_cast<float*>(Mt); p.tile_stats = tile_stats; p.bn_z = bn_z; p.bn_vec = bn_vec; p.tile_bnbwd = tile_bnbwd;
+    const dim3 grid((unsigned)(p.T / 32), (unsigned)(C / 64));
+    if (tile_stats) wino_output_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else if (tile_bnbwd) wino_output_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else wino_output_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    return uem_check_launch("wino_output");
+}
+
+extern "C" int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, void* stream) {
+    UEM_REQUIRE(w_ohwi && U && Cout > 0 && Cin > 0, "wino_filter: bad arguments");
+    if (Cout % 16 != 0 || Cin % 64 != 0) return uem_fail(UEM_ERR_UNSUPPORTED, "wino_filter: needs Cout %% 16 == 0 and Cin %% 64 == 0");
+    const dim3 grid((unsigned)(Cin / 64), (unsigned)(Cout / 16));
+    if (transposed) wino_filter_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(w_ohwi, U, Cout, Cin);
+    else wino_filter_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(w_ohwi, U, Cout, Cin);
+    return uem_check_launch("wino_filter");
+}
+
+extern "C" int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, void* stream) {
+    UEM_REQUIRE(dU && dw_ohwi && Cout > 0 && Cin > 0 && Cin % 4 == 0, "wino_filter_grad: bad arguments");
+    const int64_t n = (int64_t)Cout * (Cin / 4);
+    wino_filter_grad_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(dU, dw_ohwi, Cout, Cin);
+    return uem_check_launch("wino_filter_grad");
+}

@@ -362,6 +362,159 @@ def weight_transpose_cached(param):
     return hit[1]
 
 
+# ------------------------------------------------------------------------------------------------
+# Winograd F(2x2, 3x3): the stride-1 3x3 convolutions of the deep layers (csrc/winograd.hip), exact fp32, 2.25x fewer multiplies
+# ------------------------------------------------------------------------------------------------
+WINOGRAD = os.environ.get("UEM_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_CH = int(os.environ.get("UEM_WINOGRAD_MIN_CH", "256"))     # narrower layers are HBM-bound on the 4x larger transform tensors
+
+
+def wino_ok(x_shape, cout, kh, kw, stride, pad, dil):
+    """Does the Winograd path take this conv?  Exact fp32 only (the opt-in operand precisions stay on the direct kernels)."""
+    n, h, w, cin = x_shape
+    if not (WINOGRAD and CONV_PREC == 0 and CONV_PREC_BWD == 0 and kh == 3 and kw == 3 and stride == 1 and pad == dil and dil in (1, 2)):
+        return False
+    if h % (2 * dil) or w % (2 * dil) or cin % 64 or cout % 64 or min(cin, cout) < WINOGRAD_MIN_CH:
+        return False
+    t = n * h * w // 4
+    return t % 128 == 0 and 16 * t * max(cin, cout) < 2 ** 30
+
+
+def wino_filter_cached(param, transposed):
+    """U = G w G^T of a 3x3 conv weight (transposed: the data gradient's flipped bank), kept until the weights change."""
+    key = (WEIGHT_EPOCH, param._version, param.data_ptr())
+    name = "_uem_wino_ut" if transposed else "_uem_wino_u"
+    hit = getattr(param, name, None)
+    if hit is None or hit[0] != key:
+        w = weight_ohwi(param)
+        cout, _, _, cin = w.shape
+        u = torch.empty((16, cin, cout) if transposed else (16, cout, cin), device=w.device, dtype=torch.float32)
+        call("uem_wino_filter", ptr(w), ptr(u), cout, cin, 1 if transposed else 0, stream())
+        hit = (key, u)
+        setattr(param, name, hit)
+    return hit[1]
+
+
+def wino_input(x, dil, in_scale=None, in_shift=None, in_relu=False):
+    n, h, w, c = x.shape
+    v = torch.empty((16, n * h * w // 4, c), device=x.device, dtype=torch.float32)
+    call("uem_wino_input", ptr(x), ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, ptr(v), n, h, w, c, dil, stream())
+    return v
+
+
+def wino_gemm(v, u):
+    _, t, k = v.shape
+    nn = u.shape[1]
+    m = torch.empty((16, t, nn), device=v.device, dtype=torch.float32)
+    call("uem_wino_gemm", ptr(v), ptr(u), ptr(m), t, k, nn, stream())
+    return m
+
+
+def conv3x3_wino_bn(x, param, bn, dil, in_scale=None, in_shift=None, in_relu=False):
+    """3x3 stride-1 conv (pad = dil) + training-mode BatchNorm statistics on the Winograd path -> (y, BNState, V); V (the
+    transformed input, 4x the input's bytes) is what the weight gradient reduces over."""
+    need_gpu(x)
+    _f32c(x, "conv3x3 x")
+    n, h, w, cin = x.shape
+    u = wino_filter_cached(param, False)
+    cout = u.shape[1]
+    M = n * h * w
+    y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    ts = torch.empty((M // 128, 2, cout), device=x.device, dtype=torch.float32)
+    box = {}
+
+    def run():
+        box["v"] = wino_input(x, dil, in_scale, in_shift, in_relu)
+        m = wino_gemm(box["v"], u)
+        call("uem_wino_output", ptr(m), ptr(y), n, h, w, cout, dil, ptr(ts), None, None, None, stream())
+
+    PROF.run("conv_fwd", 2.0 * M * cout * 9 * cin, run)
+    st = BNState()
+    st.training = True
+    buf = torch.empty((4, cout), device=x.device, dtype=torch.float32)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    call("uem_bn_stats_from_tiles", ptr(ts), M // 128, M, cout, ptr(bn.weight.detach()), ptr(bn.bias.detach()), float(bn.eps),
+         float(bn.momentum if bn.momentum is not None else 0.1), ptr(bn.running_mean), ptr(bn.running_var),
+         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream())
+    return y, st, box["v"]
+
+
+def conv3x3_wino(x, param, dil, in_scale=None, in_shift=None, in_relu=False, want_v=False):
+    """plain Winograd forward (no statistics) -> y or (y, V)"""
+    need_gpu(x)
+    _f32c(x, "conv3x3 x")
+    n, h, w, cin = x.shape
+    u = wino_filter_cached(param, False)
+    cout = u.shape[1]
+    y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    box = {}
+
+    def run():
+        box["v"] = wino_input(x, dil, in_scale, in_shift, in_relu)
+        m = wino_gemm(box["v"], u)
+        call("uem_wino_output", ptr(m), ptr(y), n, h, w, cout, dil, None, None, None, None, stream())
+
+    PROF.run("conv_fwd", 2.0 * n * h * w * cout * 9 * cin, run)
+    return (y, box["v"]) if want_v else y
+
+
+def conv3x3_wino_dgrad(dy, param, dil, bn_z=None, bn_st=None):
+    """dx of the 3x3 stride-1 conv on the Winograd path: dx = conv(dy, flipped transposed filters).  With bn_z / bn_st also the
+    per-128-pixel partial sums of the BatchNorm+ReLU backward of the layer dx feeds -> (dx, partials or None)."""
+    need_gpu(dy)
+    _f32c(dy, "dgrad dy")
+    n, h, w, cout = dy.shape
+    ut = wino_filter_cached(param, True)                  # (16, cin, cout)
+    cin = ut.shape[1]
+    M = n * h * w
+    dx = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
+    tp = torch.empty((M // 128, 2, cin), device=dy.device, dtype=torch.float32) if bn_z is not None else None
+    vec = None
+    if bn_z is not None:
+        vec = bn_st.scale._base if bn_st.scale._base is not None else None
+        if vec is None or vec.shape != (4, cin):
+            raise UemError("conv3x3_wino_dgrad: BNState vectors must live in one (4, C) buffer")
+
+    def run():
+        m = wino_gemm(wino_input(dy, dil), ut)
+        call("uem_wino_output", ptr(m), ptr(dx), n, h, w, cin, dil, None, ptr(bn_z), ptr(vec), ptr(tp), stream())
+
+    PROF.run("conv_dgrad", 2.0 * M * cout * 9 * cin, run)
+    return dx, tp
+
+
+def conv3x3_wino_dgrad_bn_backward(dy, param, z, st, gamma_grad, beta_grad, dil):
+    """Winograd twin of conv2d_dgrad_bn_backward: dA = dgrad(dy), then the BatchNorm+ReLU backward of the bn that produced the
+    conv's input (reduction pass inside the output transform) -> dz in dA's buffer."""
+    cin = z.shape[-1]
+    M = z.numel() // cin
+    da, tp = conv3x3_wino_dgrad(dy, param, dil, bn_z=z, bn_st=st)
+    tmp = torch.empty((2, cin), device=dy.device, dtype=torch.float32)
+    call("uem_bn_bwd_from_tiles", ptr(tp), M // 128, cin, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
+    call("uem_bn_bwd_apply", ptr(z), ptr(da), None, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         ptr(tmp[0]), ptr(tmp[1]), M, cin, 1, ptr(da), None, stream())
+    return da
+
+
+def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil):
+    """dw (Cout,3,3,Cin) += weight gradient from the saved transformed input V (16, T, Cin) and dy (N,H,W,Cout)."""
+    if dw_ohwi is None:
+        return
+    need_gpu(v, dy, dw_ohwi)
+    _f32c(dy, "wgrad dy"), _f32c(dw_ohwi, "wgrad dw")
+    n, h, w, cout = dy.shape
+    _, t, cin = v.shape
+
+    def run():
+        dm = torch.empty((16, t, cout), device=dy.device, dtype=torch.float32)
+        call("uem_wino_dy", ptr(dy), ptr(dm), n, h, w, cout, dil, stream())
+        du = torch.zeros((16, cout, cin), device=dy.device, dtype=torch.float32)
+        call("uem_wino_wgrad_gemm", ptr(v), ptr(dm), ptr(du), t, cin, cout, stream())
+        call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, stream())
+
+    PROF.run("conv_wgrad", 2.0 * n * h * w * cout * 9 * cin, run)
+
+
 def nchw3_to_nhwc4(x):
     need_gpu(x)
     x = _f32c(x.contiguous(), "image")
