@@ -198,6 +198,65 @@ def test_two_rank_gloo_data_parallel_object():
     assert res[0][1:] == res[1][1:]                                   # same start weights, same reduced gradient
 
 
+def _class_balance_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from uemda_amd import dp
+    from uemda_amd.gast.balance import ClassBalance
+    dp.init("gloo")
+    gen = torch.Generator().manual_seed(11)
+    C = 7
+    labels = torch.randint(-1, C, (3, 4, 24, 24), generator=gen)              # three steps of a global batch of 4
+    labels[:, :2][labels[:, :2] == 3] = -1                                    # rank 0's half never sees class 3, more ignored pixels
+    cb = ClassBalance(class_num=C, ignore_label=-1, decay=0.9, temperature=0.5, device="cpu")
+    for step in range(3):
+        mine = labels[step, rank * 2: rank * 2 + 2]
+        counts = torch.stack([(mine == c).sum() for c in list(range(C)) + [-1]]).float()      # what uem_class_count returns
+        cb.freq = (1.0 - cb.decay) * cb._freq_from_counts(counts) + cb.decay * cb.freq         # ema_update on rank-local counts
+    out.put((rank, cb.freq.clone(), cb._get_class_wight().clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_class_balance_counts_are_all_reduced():
+    """SURVEY 8e collective (3), reference uemda/gast/balance.py:45-61: with the batch split over two ranks the class-frequency
+    EMA (and the per-pixel weights built from it) must equal the single-process ones on the whole batch."""
+    from oracle import gast
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_class_balance_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        r, freq, cw = out.get(timeout=120)
+        res[r] = (freq, cw)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gen = torch.Generator().manual_seed(11)
+    C = 7
+    labels = torch.randint(-1, C, (3, 4, 24, 24), generator=gen)
+    labels[:, :2][labels[:, :2] == 3] = -1
+    freq = torch.ones(C) / C
+    for step in range(3):                                                     # the reference formula on the whole batch
+        lab = labels[step]
+        cls = torch.stack([(lab == c).sum() for c in range(C)]).float()
+        freq = 0.1 * (cls / ((lab != -1).sum().float() + 1e-7)) + 0.9 * freq
+    prob = torch.softmax((1.0 - freq) / 0.5, dim=0)
+    cw = prob / (prob.max() + 1e-7)
+    for r in range(2):
+        torch.testing.assert_close(res[r][0], freq, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(res[r][1], cw, rtol=1e-6, atol=1e-7)
+    assert torch.equal(res[0][0], res[1][0])                                  # replicas bit-identical
+    # and the rank-local frequencies would NOT have been the same (the test can fail)
+    l0, l1 = labels[0, :2], labels[0, 2:]
+    f0 = torch.stack([(l0 == c).sum() for c in range(C)]).float() / (l0 != -1).sum()
+    f1 = torch.stack([(l1 == c).sum() for c in range(C)]).float() / (l1 != -1).sum()
+    assert (f0 - f1).abs().max() > 1e-2
+
+
 def test_dropout_seed_is_per_rank():
     from uemda_amd.models.ppm import dropout_seed
     assert len({dropout_seed(1, r) for r in range(8)}) == 8 and dropout_seed(1, 0) != dropout_seed(2, 0)

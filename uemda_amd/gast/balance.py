@@ -62,19 +62,34 @@ class ClassBalance(nn.Module):
     """EMA of class frequency -> per-pixel loss weight (balance.py:15-78).  The per-class vector math
     (class_num values) is host-side bookkeeping; the per-pixel passes are HIP kernels."""
 
-    def __init__(self, class_num=7, ignore_label=-1, decay=0.99, temperature=0.5, device="cuda"):
+    def __init__(self, class_num=7, ignore_label=-1, decay=0.99, temperature=0.5, device="cuda", process_group=None):
         super().__init__()
         assert temperature > 0
         self.class_num, self.ignore_label, self.decay = class_num, ignore_label, decay
         self.temperature, self.eps = temperature, 1e-7
         self.freq = torch.ones([class_num], device=device).float() / class_num
+        self.process_group = process_group          # data parallel (SURVEY 8e, collective 3): None = the default group
 
-    def _local_freq(self, label):
+    def _class_counts(self, label):
+        """(class_num + 1,) pixel counts of this rank's labels: classes, then ignored pixels (HIP kernel)."""
         lab = label.contiguous().view(-1)
         counts = torch.zeros(self.class_num + 1, device=lab.device, dtype=torch.float32)
         call("uem_class_count", ptr(lab), lab.numel(), self.class_num, int(self.ignore_label), ptr(counts), stream())
+        return counts
+
+    def _freq_from_counts(self, counts):
+        """class frequency over the GLOBAL batch (balance.py:45-53: class count / valid-pixel count).  Under data parallel the
+        counts are all-reduced first -- class counts and, with them, the valid-pixel count -- so every replica's `freq` EMA and
+        per-pixel weights stay the single-process ones; rank-local frequencies would let the replicas drift apart."""
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(self.process_group) > 1:
+            counts = counts.clone()
+            torch.distributed.all_reduce(counts, group=self.process_group)
         cls = counts[: self.class_num]
         return cls / (cls.sum() + self.eps)
+
+    def _local_freq(self, label):
+        return self._freq_from_counts(self._class_counts(label))
 
     def ema_update(self, label):
         self.freq = (1.0 - self.decay) * self._local_freq(label) + self.decay * self.freq
