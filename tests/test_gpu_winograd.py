@@ -16,7 +16,8 @@ def nchw(t):
 
 
 def rel(a, b):
-    return float((a.double().cpu() - b.double()).norm() / b.double().norm())
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
 
 
 WINO_CASES = [
@@ -104,10 +105,10 @@ def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(case):
 
 def test_winograd_declines_shapes_it_does_not_take():
     from uemda_amd import ops
-    assert not ops.wino_ok((2, 16, 16, 128, 128), 128, 3, 3, 1, 1, 1)        # narrow layers stay on the direct kernels
-    assert not ops.wino_ok((2, 16, 16, 256, 256), 256, 3, 3, 2, 1, 1)        # stride 2
-    assert not ops.wino_ok((2, 16, 16, 256, 256), 256, 1, 1, 1, 0, 1)        # 1x1
-    assert not ops.wino_ok((2, 18, 18, 256, 256), 256, 3, 3, 1, 2, 2)        # 18 is not a multiple of 2 * dilation
-    assert not ops.wino_ok((1, 8, 8, 256, 256), 256, 3, 3, 1, 1, 1)          # T = 16 tiles: not a multiple of 128
+    assert not ops.wino_ok((2, 16, 16, 128), 128, 3, 3, 1, 1, 1)        # narrow layers stay on the direct kernels
+    assert not ops.wino_ok((2, 16, 16, 256), 256, 3, 3, 2, 1, 1)        # stride 2
+    assert not ops.wino_ok((2, 16, 16, 256), 256, 1, 1, 1, 0, 1)        # 1x1
+    assert not ops.wino_ok((2, 18, 18, 256), 256, 3, 3, 1, 2, 2)        # 18 is not a multiple of 2 * dilation
+    assert not ops.wino_ok((1, 8, 8, 256), 256, 3, 3, 1, 1, 1)          # T = 16 tiles: not a multiple of 128
     with pytest.raises(ops.UemError):
         ops.wino_input(torch.zeros(1, 6, 6, 64, device="cuda"), 1)           # the C ABI refuses too (T % 32)
