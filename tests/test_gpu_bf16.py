@@ -399,3 +399,44 @@ def test_bf16_storage_ssl_step_vs_oracle(rtype, size, use_ppm, B):
     cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
     print(f"{rtype} {size}x{size}: gradient arena bf16 vs fp32 storage: cosine {cos:.5f}, relative L2 {float((g32 - g16).norm() / g32.norm()):.3e}")
     assert cos > 0.7, cos
+
+
+def test_bf16_weight_copies_follow_torch_optim_sgd_and_load_state_dict():
+    """the bf16 copy of the parameter arena was keyed on the arena's version, which in-place writes THROUGH a
+    parameter (torch.optim.SGD, load_state_dict's copy_) never move -- after the first bf16 forward every later forward ran on the
+    initial weights while the data gradient used the current ones.  A bf16-storage step with torch.optim.SGD must (1) change the
+    next forward, (2) give exactly the forward of a fresh model loaded with the updated weights; and loading the initial
+    state_dict back must restore the initial forward bit for bit."""
+    from oracle import synth
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.utils.tools import loss_calc
+    from uemda_amd.gast.balance import CrossEntropy
+    C = 6
+    sd0 = _damped_sd("resnet50")
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+
+    def build(sd):
+        m = Deeplabv2(cfg)
+        m.load_state_dict(sd)
+        return m.cuda().set_storage("bf16").train()
+    model = build(sd0)
+    b = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=5).items()}
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    p1, p2, _ = model(b["images_s"])
+    first = p1.detach().clone()
+    loss = loss_calc([p1, p2], b["label_s"], loss_fn=CrossEntropy(ignore_label=-1), multi=True)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()                                                       # in place through the parameters: arena._version stays put
+    with torch.no_grad():
+        after = model(b["images_s"])[0]
+    assert (after - first).abs().max() > 1e-4, "the forward after the step still ran on the initial bf16 weight copy"
+    fresh = build({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        ref = fresh(b["images_s"])[0]
+    assert torch.equal(after, ref)
+    model.load_state_dict(sd0)                                       # mid-run reload
+    with torch.no_grad():
+        back = model(b["images_s"])[0]
+    assert torch.equal(back, first)

@@ -170,10 +170,10 @@ class Deeplabv2(nn.Module):
             # bf16 storage (training): the heads' convs take bf16 operands (fp32 tensors in memory, fp32 accumulate)
             ppm.PPMHeadFn.prec = "bf16" if bf16 else None
             try:
-                return ppm.ppm_head(feat, self.layer5), ppm.ppm_head(feat, self.layer6)
+                with ppm.shared_pools():         # the pooled maps are shared by the two heads of THIS forward only
+                    return ppm.ppm_head(feat, self.layer5), ppm.ppm_head(feat, self.layer6)
             finally:
                 ppm.PPMHeadFn.prec = None
-                ppm.clear_pool_cache()           # the pooled maps are shared by the two heads of THIS forward only
         params = list(self.layer5.parameters()) + list(self.layer6.parameters())
         # bf16 storage (training): the two heads' GEMM takes bf16 operands (fp32 feat / logits in memory, fp32 accumulate)
         blocks.ASPPHeadsFn.prec = "bf16" if bf16 else None

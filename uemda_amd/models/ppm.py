@@ -30,22 +30,40 @@ def _avgpool(x, s):
     return y
 
 
-# layer5 and layer6 pool the SAME feature map (Encoder.py:148-149): the pooled tensors are computed once per forward
-_pool_cache = {"key": None, "pools": {}}
+# layer5 and layer6 pool the SAME feature map (Encoder.py:148-149): inside a `shared_pools()` scope (Deeplabv2._heads) the pooled
+# tensors are computed once per forward.  Outside a scope nothing is shared: a cache keyed on (address, shape) alone would hand the
+# PREVIOUS feature map's pools to the next same-shape tensor the allocator places at the same address (kernel outputs are written
+# through raw pointers, so their _version never moves) -- ADVICE r2.
+_pool_scope = {"depth": 0, "feat": None, "pools": {}}
+
+
+class shared_pools:
+    """`with shared_pools():` -- ppm_head calls inside the block that are given the SAME tensor object share their pooled maps."""
+
+    def __enter__(self):
+        _pool_scope["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _pool_scope["depth"] -= 1
+        if _pool_scope["depth"] == 0:
+            _pool_scope["feat"], _pool_scope["pools"] = None, {}
+        return False
 
 
 def _shared_pool(feat, s):
-    key = (feat.data_ptr(), feat._version, tuple(feat.shape))
-    if _pool_cache["key"] != key:
-        _pool_cache["key"], _pool_cache["pools"] = key, {}
-    pools = _pool_cache["pools"]
+    if _pool_scope["depth"] == 0:
+        return _avgpool(feat, s)
+    if _pool_scope["feat"] is not feat:                # identity of the tensor object, held alive by the scope
+        _pool_scope["feat"], _pool_scope["pools"] = feat, {}
+    pools = _pool_scope["pools"]
     if s not in pools:
         pools[s] = _avgpool(feat, s)
     return pools[s]
 
 
 def clear_pool_cache():
-    _pool_cache["key"], _pool_cache["pools"] = None, {}
+    _pool_scope["feat"], _pool_scope["pools"] = None, {}
 
 
 class PPMHeadFn(Function):
@@ -85,8 +103,17 @@ class PPMHeadFn(Function):
             saved_branch += [p, z, _st_tensor(st)]
             ops.nbt_inc(bn)
         conv0, bn0, drop, conv4 = head.conv_last[0], head.conv_last[1], head.conv_last[3], head.conv_last[4]
-        zc = ops.conv2d(cat, ops.weight_ohwi(conv0.weight), pad=1)
-        stc = _BN.stats(zc, bn0)
+        # the 4096 -> 512 3x3 conv (99.7 % of the head's FLOPs) takes the Winograd path when the shape allows (ops.wino_ok)
+        vcat = None
+        wino = ops.wino_ok(cat.shape, conv0.weight.shape[0], 3, 3, 1, 1, 1) and tuple(conv0.weight.shape[2:]) == (3, 3)
+        if wino and (bn0.training or bn0.running_mean is None) and ops.FUSE_BN_STATS:
+            zc, stc, vcat = ops.conv3x3_wino_bn(cat, conv0.weight, bn0, 1)
+        elif wino:
+            zc, vcat = ops.conv3x3_wino(cat, conv0.weight, 1, want_v=True)
+            stc = _BN.stats(zc, bn0)
+        else:
+            zc = ops.conv2d(cat, ops.weight_ohwi(conv0.weight), pad=1)
+            stc = _BN.stats(zc, bn0)
         ops.nbt_inc(bn0)
         a = ops.affine_act(zc, stc, relu=True)
         mask = None
@@ -104,8 +131,10 @@ class PPMHeadFn(Function):
         if any(ctx.needs_input_grad):
             ctx.head, ctx.training, ctx.C = head, stc.training, C
             ctx.has_mask = mask is not None
-            ctx.save_for_backward(feat, cat, zc, _st_tensor(stc), a, w4, mask if mask is not None else a.new_empty(0),
-                                  *saved_branch)
+            ctx.wino = vcat is not None
+            # Winograd: the weight gradient reduces over the transformed input, cat itself is not needed again
+            ctx.save_for_backward(feat, vcat if vcat is not None else cat, zc, _st_tensor(stc), a, w4,
+                                  mask if mask is not None else a.new_empty(0), *saved_branch)
         return out
 
     @staticmethod
@@ -114,7 +143,7 @@ class PPMHeadFn(Function):
         feat, cat, zc, stcb, a, w4, mask = ctx.saved_tensors[:7]
         branch = ctx.saved_tensors[7:]
         n, h, w, cin = feat.shape
-        ctot = cat.shape[3]
+        ctot = cat.shape[-1]
         conv0, bn0, conv4 = head.conv_last[0], head.conv_last[1], head.conv_last[4]
         d32 = torch.zeros((n, h, w, 32), device=feat.device, dtype=torch.float32)
         d32[..., :C].copy_(dout)
@@ -127,8 +156,12 @@ class PPMHeadFn(Function):
             call("uem_dropout2d", ptr(da), ptr(da), ptr(mask), n, h * w, 512, 0.0, 0, stream())   # seed 0: reuse mask
         stc = _st_from(stcb, ctx.training)
         dzc = ops.bn_backward(zc, da, stc, grad_buffer(bn0.weight), grad_buffer(bn0.bias), None, True, dx=da)
-        ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
-        dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose_cached(conv0.weight), cat.shape, pad=1)
+        if ctx.wino:
+            ops.conv3x3_wino_wgrad(cat, dzc, grad_ohwi(conv0.weight), 1)        # `cat` is the saved transformed input here
+            dcat, _ = ops.conv3x3_wino_dgrad(dzc, conv0.weight, 1)
+        else:
+            ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
+            dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose_cached(conv0.weight), cat.shape, pad=1)
         dps = []
         for i, s in enumerate(head.pool_scales):
             conv, bn = head.ppm[i][1], head.ppm[i][2]

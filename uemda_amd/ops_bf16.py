@@ -150,10 +150,17 @@ def weight(param):
     owner = getattr(param, "_uem_owner", None)
     off = getattr(param, "_uem_off", None)
     if owner is not None and off is not None and owner._arena is not None and param.data_ptr() == owner._arena.data_ptr() + 4 * off:
+        # The copy is valid while nothing has written the arena since the cast.  Writers: FusedSGD (its kernel writes behind torch's
+        # back and bumps ops.WEIGHT_EPOCH), in-place ops on the arena itself (arena._version), and in-place ops THROUGH a parameter
+        # -- `p.data` is a view of the arena with its own version counter: torch.optim.SGD, load_state_dict's copy_, p.mul_() under
+        # no_grad move p._version and leave arena._version alone (keyed on the arena's version only, the forward kept
+        # the weights of the first bf16 step).  So the versions of ALL parameters are recorded at the cast (once per step, a few
+        # hundred integers) and the requested parameter's is compared on every call.
         key = (ops.WEIGHT_EPOCH, owner._arena._version)
         hit = getattr(owner, "_uem_arena_bf16", None)
-        if hit is None or hit[0] != key:
-            hit = (key, to_bf16(owner._arena))
+        if hit is None or hit[0] != key or hit[2].get(id(param), -1) != param._version:
+            versions = {id(q): q._version for q in owner.parameters()}
+            hit = (key, to_bf16(owner._arena), versions)
             owner._uem_arena_bf16 = hit
         o, i, kh, kw = param.shape
         return hit[1][off:off + param.numel()].view(o, kh, kw, i)
