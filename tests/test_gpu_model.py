@@ -727,10 +727,11 @@ def test_ppm_head_does_not_reuse_pooled_maps_of_a_freed_feature_map():
     from uemda_amd.models import ppm
     from uemda_amd.models.Encoder import PPMBilinear
     head = _load_into(PPMBilinear(num_classes=C, fc_dim=32), "layer_ppm")
+    holder = _Holder(head).cuda().flatten()         # noqa: F841  (owns the arenas the head's parameters are views of)
     head.train()
     head.conv_last[3].p = 0.0
     gen = torch.Generator().manual_seed(3)
-    xa, xb = torch.randn(2, 32, 12, 12, generator=gen), torch.randn(2, 32, 12, 12, generator=gen)
+    xa, xb = torch.randn(2, 32, 16, 16, generator=gen), torch.randn(2, 32, 16, 16, generator=gen)
     with torch.no_grad():
         ref_b = ppm.ppm_head(nhwc(xb), head).cpu()
         fa = nhwc(xa)
