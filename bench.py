@@ -11,12 +11,17 @@ Rank 0 prints ONE JSON line.  `value` = tiles (source + target) per second over 
 HBM when the timed region starts.  `roofline` is for the dominant kernel family (the f32-MFMA implicit-GEMM
 convolution), from HIP events around every one of its launches inside the timed region.  `cpu_baseline` is the
 oracle (CPU restatement of the reference, `kind: "port"`) timed on the host cores at BASELINE config 1.
+`other_configs` (N = 1): the same step in the other configurations BASELINE.json names (bf16 storage, the PPM head,
+ResNet-101 on 1024x1024 tiles), 3 timed steps each AFTER the headline, each with its own roofline entry; they never touch `value`.
 """
 import argparse
+import gc
+import hashlib
 import json
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -27,19 +32,96 @@ import torch.distributed as dist
 
 F32_MATRIX_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 BF16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the peak of the opt-in "bf16" operand mode)
-GFLOP_PER_TILE = {("resnet50", "aspp", 512): (66.66, 198.8)}       # BASELINE.md section 3 (fwd, fwd+bwd)
 
 
-def cpu_baseline(seconds_budget=30.0):
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the conv kernel sources: profiles/traffic_latest.json is valid for ONE build of them."""
+    h = hashlib.sha256()
+    for f in ("conv.hip", "wgrad.hip", "winograd.hip"):
+        with open(os.path.join(ROOT, "uemda_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pin_cpus(local_rank, local_world):
+    """One slice of the host's cores per rank (eight ranks enqueue ~1400 launches per step each; left to the scheduler they migrate
+    across sockets).  Returns the number of cores this rank may use."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        if local_world > 1 and len(cpus) >= local_world:
+            per = len(cpus) // local_world
+            mine = cpus[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, mine)
+            return len(mine)
+        return len(cpus)
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def note(msg):
+    """progress line on stderr (a long silent run looks hung to the GPU harness)"""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cpus():
+    """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota (a one-GPU box shows all 256 host
+    CPUs in the mask and grants 16 of them; 256 torch threads on 16 cores take minutes per step)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def _all_threads_leg(nthreads, q):
+    """child process: the R50-ASPP ssl step of BASELINE config 1 on `nthreads` torch threads (killed by the parent on time-out)"""
+    from oracle import synth
+    from oracle.model import OracleDeeplabv2
+    from oracle.step import HYPER, SGDState, ssl_step
+    from oracle.weights import det_state_dict
+    torch.set_num_threads(nthreads)
+    model = OracleDeeplabv2(det_state_dict("resnet50", 6, False, seed=2333), "resnet50", 6, False)
+    opt = SGDState(model.parameters(), 0.9, 5e-4)
+    batch = synth.make_batch(B=2, H=256, W=256, C=6, k=2048, seed=2333)
+    protos, times = batch["prototypes"], []
+    for i in range(3):
+        t0 = time.time()
+        protos = ssl_step(model, opt, protos, batch, 1e-3, HYPER)["prototypes"]
+        if i >= 1:
+            times.append(time.time() - t0)
+    q.put(dict(tiles_per_s=round(4.0 / min(times), 3), s_per_step=round(min(times), 3), timed_steps=len(times), threads=nthreads))
+
+
+def cpu_baseline(seconds_budget=45.0):
     """The oracle (CPU restatement of the reference, kind "port") on the host cores, as SURVEY 8(d) specifies: BASELINE
     config 1 (B=2, 256x256, fp32), R50-ASPP and R50-PPM, (i) train_src-style and (ii) train_ssl_uem-style steps, 1 warm-up
-    + 3 timed steps each on all of the box's CPU share, plus one timed step of the ASPP pair pinned to ONE thread.
-    `value` is the leg that matches the metric (R50-ASPP ssl step on 512x512 tiles, counting source + target)."""
+    + 3 timed steps each on the box's CPU share, one timed step of the ASPP pair pinned to ONE thread, and the ASPP ssl step on
+    ALL the host threads the process may use.  `value` is the leg that matches the metric (R50-ASPP ssl step on 512x512 tiles,
+    counting source + target)."""
     from oracle import synth
     from oracle.model import OracleDeeplabv2
     from oracle.step import HYPER, SGDState, src_step, ssl_step
     from oracle.weights import det_state_dict
-    threads = min(16, os.cpu_count() or 1)            # the one-GPU box's CPU share
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        visible = os.cpu_count() or 1
+    avail = usable_cpus()
+    threads = min(16, avail)                          # the one-GPU box's CPU share
     t_stop = time.time() + seconds_budget
 
     def leg(head, style, size, nthreads, warm, timed):
@@ -74,13 +156,130 @@ def cpu_baseline(seconds_budget=30.0):
     for style in ("src", "ssl"):
         if time.time() < t_stop:
             cfg1[f"r50-aspp {style} 1 thread"] = leg("aspp", style, 256, 1, 0, 1)       # no warm-up: one cold step
+    # every host thread the affinity mask shows ("all host threads"), in a child process with a deadline: where the
+    # cgroup grants fewer cores than the mask shows, hundreds of threads on 16 cores would take minutes per step
+    if visible > threads:
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=_all_threads_leg, args=(visible, q), daemon=True)
+        p.start()
+        p.join(40.0)
+        name = f"r50-aspp ssl all {visible} visible host threads"
+        if p.is_alive():
+            p.terminate()
+            p.join(5.0)
+            cfg1[name] = dict(skipped=f"no result within 40 s: the affinity mask shows {visible} CPUs, the cgroup grants {avail}")
+        else:
+            try:
+                cfg1[name] = q.get(timeout=2.0)
+            except Exception:                         # noqa: BLE001
+                cfg1[name] = dict(error=f"child exited with code {p.exitcode}")
     torch.set_num_threads(threads)
     return dict(value=headline["tiles_per_s"], unit="tiles/s", cores=threads, kind="port",
                 sample=f"oracle (CPU restatement) ssl_step, R50-ASPP, 2 source + 2 target 512x512 tiles per step, fp32, best of "
-                       f"{headline['timed_steps']} steps ({headline['s_per_step']:.3f} s/step), {os.cpu_count()} host CPUs visible; "
-                       f"config1 = BASELINE config 1 (B=2, 256x256 tiles: tiles/s counts 256x256 tiles, src = 2 per step, "
-                       f"ssl = 4 per step)",
+                       f"{headline['timed_steps']} steps ({headline['s_per_step']:.3f} s/step), {visible} host CPUs in the affinity mask, "
+                       f"{avail} granted by the cgroup; config1 = BASELINE config 1 (B=2, 256x256 tiles: tiles/s counts 256x256 "
+                       f"tiles, src = 2 per step, ssl = 4 per step) on {threads} threads, 1 thread and all usable threads",
                 config1=cfg1)
+
+
+class Setup:
+    """Model + synthetic batch + optimizer for one configuration; `one_step(i)` runs one iteration."""
+
+    def __init__(self, cfg, rank, world, wrapper_factory):
+        from uemda_amd import ops
+        from uemda_amd.utils import synth             # seeded synthetic tiles (SURVEY 8d)
+        from uemda_amd.gast.alignment import Aligner
+        from uemda_amd.models.Encoder import Deeplabv2
+        from uemda_amd.optim import FusedSGD
+        from uemda_amd.step import HYPER, StepState, src_step, ssl_step
+        from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
+        self.cfg, self.world = cfg, world
+        ops.set_conv_precision(cfg.conv_prec)
+        C, B, S = 6, cfg.batch, cfg.size
+        seed_torch(2333)
+        mcfg = dict(backbone=dict(resnet_type=cfg.model, output_stride=16, pretrained=False), multi_layer=True,
+                    cascade=False, use_ppm=(cfg.head == "ppm"), ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
+                    inchannels=2048, num_classes=C, is_ins_norm=True)
+        self.model = Deeplabv2(mcfg).cuda().set_storage(cfg.storage)   # random init of the reference's architecture (no checkpoints)
+        self.wrapper = wrapper_factory(self.model) if wrapper_factory is not None else None
+        # synthetic tiles (SURVEY 8d): a small seeded pool generated on the host, tiled to the batch on the device
+        data_rank = rank if cfg.data_rank is None else cfg.data_rank
+        pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + data_rank)
+        self.rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]
+        self.batch = {k: (v.cuda().repeat((self.rep,) + (1,) * (v.dim() - 1))[:B].contiguous() if k != "prototypes" else v.cuda())
+                      for k, v in pool.items()}
+        self.aligner = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+        # replicas start from the same prototypes (SURVEY 8e): seeded independently of the rank, then broadcast
+        self.aligner.prototypes = synth.make_batch(B=1, H=32, W=32, C=C, k=2048, seed=2333)["prototypes"].cuda().contiguous()
+        from uemda_amd import dp as udp
+        udp.broadcast_flat(self.aligner.prototypes)
+        self.opt = FusedSGD(self.model, lr=HYPER["lr"], momentum=HYPER["momentum"], weight_decay=HYPER["weight_decay"])
+        self.state = StepState(C)
+        self.sup_ignore = (S // 16) * (S // 16)            # explicit ignored superpixel id (DP-safe, SURVEY 8e)
+        self.tiles_per_step = (2 * B if cfg.workload == "ssl" else B) * world
+        stop_steps = 6000
+
+        def lr_at(i):                                 # train_ssl_uem.py:82-84 + tools.py:191-207
+            pre = int(stop_steps / 20)
+            return lr_warmup(HYPER["lr"], i, pre) if i < pre else lr_poly(HYPER["lr"], i, stop_steps * 1.5, 0.9)
+        self.lr_at = lr_at
+        self._ssl, self._src = ssl_step, src_step
+
+    def one_step(self, i, mark=None):
+        if self.cfg.workload == "ssl":
+            return self._ssl(self.model, self.aligner, self.opt, self.state, self.batch, self.lr_at(i + 1), dp=self.wrapper,
+                             sup_ignore_id=self.sup_ignore, mark=mark)
+        return self._src(self.model, self.opt, self.state, self.batch, self.lr_at(i + 1), dp=self.wrapper)
+
+
+def roofline_of(prof, peak, traffic_for=None):
+    """bench `roofline` object from the per-launch HIP events of one step: the family with the most time."""
+    if not prof:
+        return None
+    fam, agg = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    ach = agg["flops"] / (agg["ms"] * 1e-3) / 1e12
+    return dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                traffic=traffic_for(fam) if traffic_for else None,
+                launches_per_step=agg["launches"], avg_launch_ms=round(agg["ms"] / agg["launches"], 4),
+                algorithmic_gflop_per_launch=round(agg["flops"] / agg["launches"] / 1e9, 3),
+                families={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms_per_step=round(v["ms"], 2),
+                                  executed_tflops=round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in prof.items()},
+                measured="HIP events around every conv launch of the last timed step; flops = ALGORITHMIC flops of the convolution "
+                         "(2*M*Cout*k*k*Cin), also for the 3x3 layers that run as Winograd F(2x2,3x3) (input transform + 16-position "
+                         "GEMM + output transform inside one event pair): `executed_tflops` counts the multiplies actually issued "
+                         "(algorithmic / 2.25 on those layers) and is what the matrix pipe's utilisation is")
+
+
+def short_leg(cfg, steps=3, warmup=2):
+    """One of the `other_configs`: fresh model, `warmup` untimed + `steps` timed steps, per-launch events on the last one."""
+    from uemda_amd import ops
+    s = Setup(cfg, 0, 1, None)
+    for i in range(warmup):
+        s.one_step(i)
+    ops.PROF.enabled = False
+    ops.PROF.records = []
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ops.PROF.enabled = i == steps - 1
+        s.one_step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ops.PROF.enabled = False
+    bf16 = cfg.storage == "bf16" or cfg.conv_prec == "bf16"
+    out = dict(value=round(s.tiles_per_step / dt, 2), unit=f"tiles({cfg.size}x{cfg.size})/s", ms_per_step=round(1e3 * dt, 2), steps=steps,
+               warmup=warmup, dtype="bf16 storage (fp32 accumulate / statistics / master weights)" if cfg.storage == "bf16" else "f32",
+               workload=f"{cfg.model}-{cfg.head} {cfg.workload} step, {cfg.batch} source + {cfg.batch} target {cfg.size}x{cfg.size} tiles",
+               roofline=roofline_of(ops.PROF.summary(), BF16_MATRIX_PEAK_TFLOPS if bf16 else F32_MATRIX_PEAK_TFLOPS),
+               peak_allocated_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
+    ops.PROF.records = []
+    del s
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -107,49 +306,25 @@ def main():
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: activations / weight copies of the encoder stored in bf16, bf16 matrix cores (BASELINE config 5)")
     ap.add_argument("--no-other-precisions", action="store_true",
-                    help="skip the short extra legs that time the same step in the two opt-in precisions (N=1 only)")
+                    help="skip the short extra legs that time the same step in the opt-in operand precisions (N=1 only)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs for the other BASELINE configurations (bf16 storage, PPM head, R101 1024^2; N=1 only)")
     args = ap.parse_args()
 
     from uemda_amd import dp as udp, ops
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    cores = pin_cpus(int(os.environ.get("LOCAL_RANK", "0")), local_world)     # before any thread pool or GPU call
     if args.device is not None:
         torch.cuda.set_device(args.device)
     rank, world, local = udp.init(args.backend, device=args.device)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local if args.device is None else args.device)
-    from uemda_amd.utils import synth             # seeded synthetic tiles
-    from uemda_amd.gast.alignment import Aligner
-    from uemda_amd.models.Encoder import Deeplabv2
-    from uemda_amd.optim import FusedSGD
-    from uemda_amd.step import HYPER, StepState, src_step, ssl_step
-    from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
 
-    ops.set_conv_precision(args.conv_prec)
-    C, B, S = 6, args.batch, args.size
-    seed_torch(2333)
-    cfg = dict(backbone=dict(resnet_type=args.model, output_stride=16, pretrained=False), multi_layer=True,
-               cascade=False, use_ppm=(args.head == "ppm"), ppm=dict(num_classes=C, use_aux=False, fc_dim=2048),
-               inchannels=2048, num_classes=C, is_ins_norm=True)
-    model = Deeplabv2(cfg).cuda().set_storage(args.storage)   # random init of the reference's architecture (no checkpoints)
-    wrapper = udp.DataParallel(model, overlap=not args.no_overlap) if (world > 1 or udp.FORCE) else None
-    # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
-    data_rank = rank if args.data_rank is None else args.data_rank
-    pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + data_rank)
-    rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]
-    batch = {k: (v.cuda().repeat((rep,) + (1,) * (v.dim() - 1))[:B].contiguous() if k != "prototypes" else v.cuda())
-             for k, v in pool.items()}
-    aligner = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
-    # replicas start from the same prototypes: seeded independently of the rank, then broadcast
-    aligner.prototypes = synth.make_batch(B=1, H=32, W=32, C=C, k=2048, seed=2333)["prototypes"].cuda().contiguous()
-    udp.broadcast_flat(aligner.prototypes)
-    opt = FusedSGD(model, lr=HYPER["lr"], momentum=HYPER["momentum"], weight_decay=HYPER["weight_decay"])
-    state = StepState(C)
-    sup_ignore = (S // 16) * (S // 16)            # explicit ignored superpixel id (DP-safe)
-    stop_steps = 6000
-
-    def lr_at(i):                                 # train_ssl_uem.py:82-84 + tools.py:191-207
-        pre = int(stop_steps / 20)
-        return lr_warmup(HYPER["lr"], i, pre) if i < pre else lr_poly(HYPER["lr"], i, stop_steps * 1.5, 0.9)
+    make_wrapper = (lambda m: udp.DataParallel(m, overlap=not args.no_overlap)) if (world > 1 or udp.FORCE) else None
+    s = Setup(args, rank, world, make_wrapper)
+    model, wrapper, aligner = s.model, s.wrapper, s.aligner
+    B, S = args.batch, args.size
 
     marks = []                                    # (phase name, HIP event) of the last timed step
 
@@ -168,10 +343,7 @@ def main():
             first_grad["norm"] = float((garena[:n].double() * scale).norm())
 
     def one_step(i, marked=False):
-        if args.workload == "ssl":
-            return ssl_step(model, aligner, opt, state, batch, lr_at(i + 1), dp=wrapper, sup_ignore_id=sup_ignore,
-                            mark=mark if marked else (grab_first_grad if args.dump_params and not first_grad else None))
-        return src_step(model, opt, state, batch, lr_at(i + 1), dp=wrapper)
+        return s.one_step(i, mark=mark if marked else (grab_first_grad if args.dump_params and not first_grad else None))
 
     def barrier():
         if world > 1:
@@ -186,7 +358,6 @@ def main():
     # model's ~10^5 long-lived objects that pass takes ~60 ms and, landing in the first step after the barrier (empty device
     # queue), stalled the device for as long (steps_ms[0] = 180-220 ms against 134).  Collect now and move the survivors
     # out of the collector's reach; the steady-state loop is unaffected either way (the host runs half a step ahead).
-    import gc
     gc.collect()
     gc.freeze()
     barrier()
@@ -210,13 +381,32 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
-    prof_steps = 1
+    replicas = None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    tiles_per_step = (2 * B if args.workload == "ssl" else B) * world
+        # are the replicas still one model?  every rank's (parameter, prototype) checksums, gathered; and the slowest rank's wait
+        # for the gradient collective in the last step
+        arena, _, n = model.flat_parameters()
+        wait_ms = 0.0
+        ph_local = {b[0]: a[1].elapsed_time(b[1]) for a, b in zip(marks[:-1], marks[1:])} if marks else {}
+        wait_ms = ph_local.get("grad_allreduce_wait", 0.0)
+        mine = torch.tensor([float(arena[:n].double().sum()), float(arena[:n].double().abs().sum()),
+                             float(aligner.prototypes.double().sum()), float(aligner.prototypes.double().abs().sum()), wait_ms],
+                            device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        replicas = dict(identical=bool((allr[:, :4] == allr[0, :4]).all()), param_sum=float(allr[0, 0]), proto_sum=float(allr[0, 2]),
+                        grad_allreduce_wait_ms_max=round(float(allr[:, 4].max()), 3),
+                        grad_allreduce_wait_ms_per_rank=[round(float(v), 3) for v in allr[:, 4]])
+    tiles_per_step = s.tiles_per_step
     value = tiles_per_step * args.steps / elapsed
+    if rank == 0:
+        note(f"headline: {value:.1f} tiles/s, {1e3 * elapsed / args.steps:.2f} ms/step")
+    headline_prof = ops.PROF.summary()
+    ops.PROF.records = []
 
     others = None
     if world == 1 and not args.no_other_precisions and args.storage == "fp32":
@@ -238,39 +428,29 @@ def main():
                 others[prec] = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=3)
             except Exception as e:                # noqa: BLE001
                 others[prec] = dict(error=repr(e)[:200])
+            note(f"other precision {prec}: {others[prec]}")
         ops.set_conv_precision(args.conv_prec)
 
     peak = BF16_MATRIX_PEAK_TFLOPS if (args.conv_prec == "bf16" or args.storage == "bf16") else F32_MATRIX_PEAK_TFLOPS
     prec_text = {"fp32": "fp32 (f32 MFMA)", "bf16x3": "fp32 storage, 3xbf16 split MFMA with fp32 accumulate",
                  "mixed": "fp32 (f32 MFMA) forward, 3xbf16 split MFMA data/weight gradients",
                  "bf16": "fp32 storage, bf16 MFMA operands with fp32 accumulate"}[args.conv_prec]
+    line = None
     if rank == 0:
-        roof = None
-        prof = ops.PROF.summary()
-        if prof:
-            fam, agg = max(prof.items(), key=lambda kv: kv[1]["ms"])
-            ach = agg["flops"] / (agg["ms"] * 1e-3) / 1e12
-            # HBM bytes per launch of that family from the PMC passes (scripts/pmc_traffic.py), valid ONLY for the
-            # configuration they were collected on: any other run reports null
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}" + ("" if args.storage == "fp32" else " storage=bf16")
-            if os.path.exists(tfile):
-                tj = json.load(open(tfile))
-                if tj.get("config") == key:
-                    traffic = tj.get(fam)
-            roof = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 4), traffic=traffic,
-                        launches_per_step=agg["launches"] // prof_steps,
-                        avg_launch_ms=round(agg["ms"] / agg["launches"], 4),
-                        algorithmic_gflop_per_launch=round(agg["flops"] / agg["launches"] / 1e9, 3),
-                        families={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                          ms_per_step=round(v["ms"] / prof_steps, 2)) for k, v in prof.items()},
-                        measured="HIP events around every conv launch of the last timed step")
+        # HBM bytes per launch of a family from the PMC passes (scripts/pmc_traffic.py), valid ONLY for the configuration AND the
+        # build of the conv kernels they were collected on: anything else reports null
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}" + ("" if args.storage == "fp32" else " storage=bf16")
+        tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
+        traffic_ok = tj.get("config") == key and tj.get("kernel_source_sha256_16") == kernel_source_hash()
+        roof = roofline_of(headline_prof, peak, (lambda fam: tj.get(fam)) if traffic_ok else None)
+        if roof is not None and not traffic_ok:
+            roof["traffic_note"] = "profiles/traffic_latest.json was taken on another configuration or another build of the conv kernels"
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             metric = "512x512 tiles/sec (fwd+bwd+pseudo-label) ResNet50-ASPP bs=32, 1/2/4/8 GPU"
+        arena_bytes = 4 * model.flat_parameters()[2]
         line = {
             "metric": metric,
             "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -280,14 +460,19 @@ def main():
             "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text if args.storage == 'fp32' else 'bf16 storage in the encoder (bf16 MFMA, fp32 accumulate)'}, "
                                    f"random init; tiles counted = source + target; the batch repeats {min(B, 4)} unique seeded "
-                                   f"tiles x{rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
+                                   f"tiles x{s.rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
                                    f"events (660 event records: about 1 ms of command-processor bubbles)",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
                        "collective": None if wrapper is None else ("uem_allreduce_flat (RCCL through the C ABI)" if wrapper.native
-                                                                   is not None else f"torch.distributed {args.backend}")},
+                                                                   is not None else f"torch.distributed {args.backend}"),
+                       "collective_bytes_per_step": None if wrapper is None else arena_bytes + 4 * (6 * 2048 + 6),
+                       "host_cores_per_rank": cores},
             "loss_source": round(float(out["loss_source"]), 5),
             "roofline": roof,
         }
+        if replicas is not None:
+            line["replicas_identical"] = replicas["identical"]
+            line["replicas"] = replicas
         # device time of every timed step (one HIP event per step boundary) and when the host had finished enqueuing it
         line["steps_ms"] = [round(a.elapsed_time(b), 2) for a, b in zip(step_events[:-1], step_events[1:])]
         line["host_enqueued_at_ms"] = [round(1e3 * t, 1) for t in step_host]
@@ -305,12 +490,6 @@ def main():
                                  "alloc_retries": int(ms.get("num_alloc_retries", 0))}
         if others:
             line["other_precisions"] = others
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline()
-            except Exception as e:                # noqa: BLE001  (reported, never fatal for the measured line)
-                line["cpu_baseline"] = dict(error=repr(e)[:200])
-        print(json.dumps(line), flush=True)
     if args.dump_params:
         arena, _, n = model.flat_parameters()
         with open(f"{args.dump_params}.rank{rank}", "w") as f:
@@ -319,6 +498,34 @@ def main():
                         prototypes=aligner.prototypes.cpu(), first_grad_sample=first_grad.get("sample"),
                         first_grad_norm=first_grad.get("norm"), unpaired_forwards=getattr(wrapper, "unpaired_forwards", None)),
                    f"{args.dump_params}.rank{rank}.pt")
+    if rank == 0 and world == 1 and not args.no_other_configs and (args.model, args.head, args.storage, S, args.conv_prec) == ("resnet50", "aspp", "fp32", 512, "fp32"):
+        # the other configurations BASELINE.json names, after the headline and without touching it: the headline's model is
+        # released first (R101 on 1024^2 tiles needs ~105 GB of the 288)
+        del s, model, aligner, one_step, out
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+        oc = {}
+        legs = {"bf16 storage r50-aspp 512": dict(storage="bf16"), "fp32 r50-ppm 512": dict(head="ppm"),
+                "bf16 storage r101-aspp 1024 (BASELINE config 5, one GPU's share)": dict(storage="bf16", model="resnet101", size=1024)}
+        for name, over in legs.items():
+            cfg = types.SimpleNamespace(**{**vars(args), "conv_prec": "fp32", "data_rank": None, **over})
+            try:
+                oc[name] = short_leg(cfg)
+            except Exception as e:                # noqa: BLE001  (an extra leg must never cost the headline line)
+                oc[name] = dict(error=repr(e)[:300])
+                gc.collect()
+                torch.cuda.empty_cache()
+            note(f"other config {name}: {oc[name].get('value')} {oc[name].get('unit')} {oc[name].get('ms_per_step')} ms {oc[name].get('error', '')}")
+        line["other_configs"] = oc
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline (oracle on the host cores, ~45 s)")
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                # noqa: BLE001  (reported, never fatal for the measured line)
+                line["cpu_baseline"] = dict(error=repr(e)[:200])
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

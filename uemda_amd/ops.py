@@ -76,23 +76,26 @@ class _Profiler:
         self.enabled = False
         self.records = []          # (family, algorithmic flops, start event, end event)
 
-    def run(self, family, flops, launch):
+    def run(self, family, flops, launch, executed=None):
+        """flops: ALGORITHMIC flops of the op (2*M*Cout*k*k*Cin); executed: the multiplies actually issued where they differ
+        (Winograd: algorithmic / 2.25)."""
         if not self.enabled:
             return launch()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = launch()
         e.record()
-        self.records.append((family, flops, s, e))
+        self.records.append((family, flops, s, e, flops if executed is None else executed))
         return out
 
     def summary(self):
-        """family -> dict(launches, flops, ms); call after torch.cuda.synchronize()."""
+        """family -> dict(launches, flops, executed, ms); call after torch.cuda.synchronize()."""
         agg = {}
-        for fam, fl, s, e in self.records:
-            a = agg.setdefault(fam, dict(launches=0, flops=0.0, ms=0.0))
+        for fam, fl, s, e, ex in self.records:
+            a = agg.setdefault(fam, dict(launches=0, flops=0.0, executed=0.0, ms=0.0))
             a["launches"] += 1
             a["flops"] += fl
+            a["executed"] += ex
             a["ms"] += s.elapsed_time(e)
         return agg
 
@@ -428,7 +431,7 @@ def conv3x3_wino_bn(x, param, bn, dil, in_scale=None, in_shift=None, in_relu=Fal
         m = wino_gemm(box["v"], u)
         call("uem_wino_output", ptr(m), ptr(y), n, h, w, cout, dil, ptr(ts), None, None, None, stream())
 
-    PROF.run("conv_fwd", 2.0 * M * cout * 9 * cin, run)
+    PROF.run("conv_fwd", 2.0 * M * cout * 9 * cin, run, executed=2.0 * M * cout * 4 * cin)
     st = BNState()
     st.training = True
     buf = torch.empty((4, cout), device=x.device, dtype=torch.float32)
@@ -454,7 +457,7 @@ def conv3x3_wino(x, param, dil, in_scale=None, in_shift=None, in_relu=False, wan
         m = wino_gemm(box["v"], u)
         call("uem_wino_output", ptr(m), ptr(y), n, h, w, cout, dil, None, None, None, None, stream())
 
-    PROF.run("conv_fwd", 2.0 * n * h * w * cout * 9 * cin, run)
+    PROF.run("conv_fwd", 2.0 * n * h * w * cout * 9 * cin, run, executed=2.0 * n * h * w * cout * 4 * cin)
     return (y, box["v"]) if want_v else y
 
 
@@ -479,7 +482,7 @@ def conv3x3_wino_dgrad(dy, param, dil, bn_z=None, bn_st=None):
         m = wino_gemm(wino_input(dy, dil), ut)
         call("uem_wino_output", ptr(m), ptr(dx), n, h, w, cin, dil, None, ptr(bn_z), ptr(vec), ptr(tp), stream())
 
-    PROF.run("conv_dgrad", 2.0 * M * cout * 9 * cin, run)
+    PROF.run("conv_dgrad", 2.0 * M * cout * 9 * cin, run, executed=2.0 * M * cout * 4 * cin)
     return dx, tp
 
 
@@ -512,7 +515,7 @@ def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil):
         call("uem_wino_wgrad_gemm", ptr(v), ptr(dm), ptr(du), t, cin, cout, stream())
         call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, stream())
 
-    PROF.run("conv_wgrad", 2.0 * n * h * w * cout * 9 * cin, run)
+    PROF.run("conv_wgrad", 2.0 * n * h * w * cout * 9 * cin, run, executed=2.0 * n * h * w * cout * 4 * cin)
 
 
 def nchw3_to_nhwc4(x):
