@@ -526,8 +526,12 @@ def main():
             except Exception as e:                # noqa: BLE001  (reported, never fatal for the measured line)
                 line["cpu_baseline"] = dict(error=repr(e)[:200])
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        # also the single-rank group of UEM_DP_FORCE=1: left alive, its RCCL watchdog thread can outlive the HIP context at interpreter
+        # exit and abort the process after the line was printed
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -150,5 +150,8 @@ def test_tta_d4_batched_equals_sequential(hw):
         a = tta_predict(model, img, batched=True)
         b = tta_predict(model, img, batched=False)
     assert a.shape == (1, C, *hw)
-    torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    # round 3: at batch 8 the 3x3 convs of layer3/4 take the Winograd path, at batch 1 (16 tiles) the direct kernels: the same
+    # fp32 products summed in another order (1e-6 on a probability), no longer the very same kernels on the very same rows
+    torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-6)
+    assert (a.argmax(1) == b.argmax(1)).float().mean() > 0.9999
     assert ((a.sum(1) - 1).abs() < 1e-5).all()
