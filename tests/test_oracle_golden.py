@@ -325,3 +325,62 @@ def test_superpixel_edge_shrinking_golden():
     for k in ("a", "b", "c"):
         got = gast.edge_shrinking(g[f"in_{k}"].numpy(), 3, 16)
         assert (got == g[f"out_{k}"].numpy()).all(), k
+
+
+# ---------------- 7 classes: the reference's LoveDA configuration (tests/golden/make_golden_c7.py) ------------------------------
+def test_c7_ops_golden():
+    """The oracle at C = 7 against the reference: label_refine in every mode, pseudo_selection, DownscaleLabel, update_prototype,
+    Pearson distance, CE / UVEM with gradients, ClassBalance, PrototypeContrastiveLoss."""
+    C7 = 7
+    g = load_golden("ops_c7")
+    for m, h in zip(g["masks"], g["hards"]):
+        assert torch.equal(gast.pseudo_selection(m, 0.8, 0.6, -1), h)
+    for mode in ("all", "s", "p", "l"):
+        out = gast.label_refine(g["sup"], g["feat"], [g["p1"], g["p2"]], g["soft"], g["protos"], True, mode, 2.0)
+        torch.testing.assert_close(out, g["refine_" + mode], rtol=1e-5, atol=2e-7)
+    out = gast.label_refine(g["sup_irregular"], g["feat"], [g["p1"], g["p2"]], g["soft"], g["protos"], True, "all", 2.0)
+    torch.testing.assert_close(out, g["refine_all_irregular"], rtol=1e-5, atol=2e-7)
+    torch.testing.assert_close(gast.pearson_dist(g["pearson_x"], g["protos"]), g["pearson_dist"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(gast.downscale_label(g["ds_label"], C7), g["ds_out"])
+    new, ds = gast.update_prototype(g["up_feat"], g["up_label"], g["protos"], C7, 0.996)
+    assert torch.equal(ds, g["up_label_ds"])
+    torch.testing.assert_close(new, g["up_protos_out"], rtol=1e-6, atol=1e-7)
+    l1, l2 = g["logits1"].clone().requires_grad_(True), g["logits2"].clone().requires_grad_(True)
+    loss = gast.loss_calc_uvem([l1, l2], g["loss_hard"], g["loss_soft"], 0.2, 0.7, 4.0, -1, C7)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g["uvem"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(l1.grad, g["uvem_g1"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(l2.grad, g["uvem_g2"], rtol=1e-4, atol=1e-8)
+    l3, l4 = g["logits1"].clone().requires_grad_(True), g["logits2"].clone().requires_grad_(True)
+    ce = gast.loss_calc([l3, l4], g["label_s"], -1)
+    ce.backward()
+    torch.testing.assert_close(ce.detach(), g["ce"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(l3.grad, g["ce_g1"], rtol=1e-4, atol=1e-8)
+    cb = gast.ClassBalance(C7, -1, 0.99, 0.5)
+    torch.testing.assert_close(cb.get_class_weight_4pixel(g["label_s"]), g["cb_weights"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(cb.freq, g["cb_freq"], rtol=1e-6, atol=1e-8)
+    f = g["pcl_feat"].clone().requires_grad_(True)
+    lp = gast.pcl_loss(g["pcl_protos"], f, g["pcl_labels"], 8.0, -1)
+    lp.backward()
+    torch.testing.assert_close(lp.detach(), g["pcl"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(f.grad, g["pcl_gfeat"], rtol=1e-5, atol=1e-8)
+
+
+def test_c7_full_model_ppm_ssl_step():
+    """One train_ssl_uem step of R50-PPM with num_classes = 7 (reference configs/st/uemda/2urban.py:11, train_ssl_uem.py:80)."""
+    C7 = 7
+    g = load_golden("model_ppm_r50_b2_256_c7")
+    sd = det_state_dict("resnet50", C7, True, seed=2333)
+    assert tuple(sd["layer6.conv_last.4.weight"].shape) == (7, 512, 1, 1)
+    model = OracleDeeplabv2(sd, "resnet50", C7, True)
+    batch = synth.make_batch(B=2, H=256, W=256, C=C7, k=2048, seed=2333)
+    opt = SGDState(model.parameters(), HYPER["momentum"], HYPER["weight_decay"])
+    out = ssl_step(model, opt, batch["prototypes"], batch, float(g["lr"]), HYPER, dropout=False, n_classes=C7)
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        torch.testing.assert_close(out[k], g[k], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["label_t_soft"][:, :, ::4, ::4], g["soft_sample"], rtol=1e-4, atol=1e-6)
+    assert (out["label_t_hard"] == g["hard"].long()).float().mean().item() >= 0.9999
+    torch.testing.assert_close(out["loss_source"], g["loss_source"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["loss_target"], g["loss_target"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["prototypes"], g["prototypes"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["grad_norm"], g["grad_norm"], rtol=1e-3, atol=1e-5)
