@@ -1,6 +1,7 @@
 """BASELINE config 5's single-GPU half: ResNet-101 + ASPP on 1024x1024 tiles, one train_ssl_uem step against the oracle,
-in the exact-fp32 default and in the bf16-operand mode config 5 names ("bf16 (CDNA4 bf16 MFMA)": bf16 matrix-core operands,
-fp32 accumulate; storage stays fp32 in this round -- DESIGN.md 3.2).  B = 1 source + 1 target tile keeps the oracle's CPU
+in the exact-fp32 default and in the bf16-OPERAND mode (bf16 matrix-core operands, fp32 accumulate, fp32 tensors in memory --
+DESIGN.md 3.2).  Config 5's own arithmetic, bf16 STORAGE, is tested at this shape in tests/test_gpu_bf16.py
+(test_bf16_storage_ssl_step_vs_oracle[resnet101-1024]).  B = 1 source + 1 target tile keeps the oracle's CPU
 step in the tens of seconds; the benchmark batch is covered by size-independent properties in test_gpu_fullsize.py.
 
 Tolerances (stated here, derived in DESIGN.md 3.2):

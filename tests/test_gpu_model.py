@@ -413,7 +413,11 @@ def test_full_model_aspp_ssl_step_matches_reference_golden(conv_precision):
     al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
     al.prototypes = batch["prototypes"].clone()
     opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    from uemda_amd.models import blocks as _blocks
+    hits0 = _blocks._Link.hits
     out = ssl_step(model, al, opt, StepState(C), batch, float(g["lr"]))
+    # the fused residual path is really taken: 15 of the 16 blocks of each forward get their gradient handed over by the next one
+    assert _blocks._Link.hits - hits0 == 30, _blocks._Link.hits - hits0
     # north_star: fp logits within 1e-3 rel of the reference CPU path
     for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
         ref = g[k]

@@ -106,10 +106,25 @@ class StemFn(Function):
 class _Link:
     """What the NEXT block's backward needs to take this block's bn3 reduction pass into its last data-gradient epilogue
     (ops.conv2d_dgrad_tail): travels as an attribute of the block's output tensor; the next block's forward picks it up."""
-    __slots__ = ("z3", "bits", "vec", "tiles", "dx_ptr")
+    __slots__ = ("z3", "bits", "vec", "tiles", "dx", "dx_version")
+    hits = 0                    # how often a block found its incoming gradient to be the handed-over tensor (tests read this)
 
     def __init__(self, z3, bits, vec):
-        self.z3, self.bits, self.vec, self.tiles, self.dx_ptr = z3, bits, vec, None, 0
+        self.z3, self.bits, self.vec, self.tiles, self.dx, self.dx_version = z3, bits, vec, None, None, -1
+
+    def hand_over(self, dx, tiles):
+        """the next block's backward produced `dx` (this block's incoming gradient) and, with it, the partial sums `tiles` of this
+        block's bn3 backward over exactly that tensor"""
+        self.tiles, self.dx, self.dx_version = tiles, dx, dx._version
+
+    def owns(self, dy):
+        """Is `dy` the very tensor the next block's backward handed over, untouched since?  Ownership is POSITIVE: the
+        same tensor OBJECT at the same version -- not merely the same address.  If autograd summed another consumer's gradient
+        into it in place (InputBuffer add_), the object is the same but its version moved: the partial sums no longer describe it
+        and it may not be overwritten.  (The kernels write through raw pointers and never move a version.)"""
+        ok = self.dx is not None and dy is self.dx and dy._version == self.dx_version
+        _Link.hits += int(ok)
+        return ok
 
 
 class BottleneckFn(Function):
@@ -182,7 +197,7 @@ class BottleneckFn(Function):
         lo = ctx.link_out
         # dy may be overwritten in place only when it is the buffer the next block's backward allocated for us (a gradient
         # handed in by the caller, or one autograd summed from several consumers, is left alone)
-        own = lo is not None and lo.dx_ptr == dy.data_ptr()
+        own = lo is not None and lo.owns(dy)
         if own and lo.tiles is not None:
             dz3 = ops.bn_backward_from_partials(z3, dy, st3, lo.tiles, gb(blk.bn3.weight), gb(blk.bn3.bias), ybits, dres=dp)
             lo.tiles = None
@@ -232,7 +247,7 @@ class BottleneckFn(Function):
         else:
             dx = ops.conv2d_dgrad(dz1, wt1, x.shape, out=dp, accumulate=True)     # identity grad + conv1 dgrad
         if li is not None:
-            li.tiles, li.dx_ptr = tp, dx.data_ptr()
+            li.hand_over(dx, tp)
         cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
         if cb is not None:
             cb()

@@ -71,7 +71,7 @@ class BottleneckBf16Fn(Function):
         need_dp = not ctx.has_ds and not tail_ok
         lo = ctx.link_out
         # dy may be overwritten in place only when it is the buffer the next block's backward allocated for us
-        own = lo is not None and lo.dx_ptr == dy.data_ptr()
+        own = lo is not None and lo.owns(dy)
         dp = None
         if own and lo.tiles is not None:
             dz3 = ob.bn_backward_from_partials(z3, dy, st3, lo.tiles, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits)
@@ -111,7 +111,7 @@ class BottleneckBf16Fn(Function):
         else:
             dx = ob.conv2d_dgrad(dz1, wt1, x.shape, out=dp, accumulate=True)      # identity gradient + conv1's
         if li is not None:
-            li.tiles, li.dx_ptr = tp, dx.data_ptr()
+            li.hand_over(dx, tp)
         cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
         if cb is not None:
             cb()
