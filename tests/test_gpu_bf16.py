@@ -398,7 +398,10 @@ def test_bf16_storage_ssl_step_vs_oracle(rtype, size, use_ppm, B):
     g32, g16 = grads["fp32"].double(), grads["bf16"].double()
     cos = float((g32 * g16).sum() / (g32.norm() * g16.norm()))
     print(f"{rtype} {size}x{size}: gradient arena bf16 vs fp32 storage: cosine {cos:.5f}, relative L2 {float((g32 - g16).norm() / g32.norm()):.3e}")
-    assert cos > 0.7, cos
+    # printed, not asserted (round 2 asserted cos > 0.7, which a 10 % systematic error would have passed): at B = 1 + 1 through
+    # 50-100 layers this number is dominated by moved ReLU masks.  What can fail on a systematic error in the bf16 backward:
+    # test_bf16_seven_block_chain_well_conditioned_vs_emulation (the gain of every gradient tensor) and
+    # test_bf16_storage_training_trajectory_tracks_fp32_storage (30 steps against fp32 storage).
 
 
 def test_bf16_weight_copies_follow_torch_optim_sgd_and_load_state_dict():
@@ -440,3 +443,139 @@ def test_bf16_weight_copies_follow_torch_optim_sgd_and_load_state_dict():
     with torch.no_grad():
         back = model(b["images_s"])[0]
     assert torch.equal(back, first)
+
+
+def test_bf16_seven_block_chain_well_conditioned_vs_emulation():
+    """the whole seven-block chain (every block shape of the encoder) ASSERTED, not printed.  At the default
+    initialisation a chain of training-mode BatchNorm blocks whose branches are as large as their trunk amplifies one flipped bf16
+    rounding by ~2 per block forward (more backward, through the ReLU masks it moves), so seven blocks sit at 3e-1 from their own
+    float64 emulation and nothing can be asserted.  With the residual branches damped the way trained networks are (gamma of
+    every block's last BatchNorm x 0.2), B = 8 and 32x32 maps the forward is well conditioned (y 8e-3).  The backward keeps an unbiased noise of ~1.1e-1 from ReLU masks
+    moved by flipped roundings (see BF16_CHAIN7_TOL), so besides relative-L2 bounds at ~2x measured the test asserts the least-squares
+    GAIN of dx and of EVERY parameter gradient against the float64 emulation of the same arithmetic: within 8 % of 1 (dx: 3 %).  A
+    10 % systematic error anywhere in the bf16 backward -- a wrong factor, a missing term, a mis-indexed partial sum in the fused
+    epilogues -- moves a gain to 0.9 or worse and fails."""
+    sd = {k: v.clone() for k, v in _block_stack().state_dict().items()}
+    for k in sd:
+        if k.endswith("bn3.weight"):
+            sd[k] = sd[k] * 0.2
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(8, 32, 32, 64, generator=g).bfloat16().float().cuda()
+    gy = torch.randn(8, 16, 16, 512, generator=g).bfloat16().float().cuda()
+    y16, dx16, g16, offs = _run_stack(sd, x, gy, "bf16", True, 0, 7)
+    y16u, dx16u, g16u, _ = _run_stack(sd, x, gy, "bf16", False, 0, 7)
+    ye, dxe, ge = _emulated_stack(sd, x, gy, 0, 7)
+
+    def rel(a, b):
+        return float((a.cpu() - b.cpu()).norm() / b.cpu().norm())
+
+    def layer_grad(arena, n):
+        o, c = offs[n]
+        t = arena[o:o + c].cpu()
+        if ge[n].dim() == 4:
+            co, ci, kh, kw = ge[n].shape
+            t = t.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return t.reshape(ge[n].shape)
+    def gain(a, b):
+        """least-squares scale of a against b: <a, b> / <b, b>.  Rounding flips and the ReLU masks they move are unbiased noise and
+        average out of it; a systematic error (a wrong factor, a missing term) does not."""
+        a, b = a.cpu().double().reshape(-1), b.cpu().double().reshape(-1)
+        return float((a * b).sum() / (b * b).sum())
+    per_layer = {n: rel(layer_grad(g16, n), ge[n]) for n in ge}
+    gains = {n: gain(layer_grad(g16, n), ge[n]) for n in ge}
+    worst = max(per_layer.items(), key=lambda kv: kv[1])
+    worst_gain = max(gains.items(), key=lambda kv: abs(kv[1] - 1.0))
+    ry, rdx, rfu = rel(y16, ye), rel(dx16, dxe), max(rel(dx16, dx16u), rel(g16, g16u))
+    gdx = gain(dx16, dxe)
+    srt = sorted(per_layer.values())
+    print(f"damped seven-block chain, B=8: y {ry:.2e}, dx {rdx:.2e} (gain {gdx:.4f}), parameter gradients median {srt[len(srt) // 2]:.2e} "
+          f"worst {worst}, worst gain {worst_gain}; fused vs plain backward {rfu:.2e}")
+    ty, tdx, tdw, tfu, tg = BF16_CHAIN7_TOL
+    assert ry < ty and rdx < tdx, (ry, rdx)
+    assert worst[1] < tdw, worst
+    assert rfu < tfu, rfu
+    assert abs(gdx - 1.0) < 0.03 and abs(worst_gain[1] - 1.0) < tg, (gdx, worst_gain)
+
+
+# measured round 3 (gpurun_out / profiles/README.md): see the numbers printed by the test; bounds <= 3x measured and <= 5e-2
+# Why not 5e-2 on dx: each conv output is rounded to bf16, and where fp32 accumulation order differs from the float64 emulation one
+# rounding in ~200 flips (2^-8 relative on that element).  Forward that is 3e-4 per layer (y: 7.9e-3 after 21 conv+BatchNorm layers).
+# Backward every pre-activation within that distance of zero flips its ReLU mask -- an O(1) change of that element's gradient, on a
+# fraction ~3e-4 of the elements: 1.7e-2 per layer, unbiased, growing as sqrt(layers) -- 1.1e-1 after seven blocks, damped or not.
+# It is NOISE: the least-squares gain of every gradient tensor against the emulation stays within 5 % of 1 (dx: 0.7 %), and that is
+# what a systematic error (wrong factor, missing term, mis-indexed partial sum: gain 0.9 or worse on some tensor) cannot do.
+# measured: y 7.9e-3, dx 1.12e-1 (gain 0.9934), parameter gradients median 1.13e-1, worst 1.62e-1, worst gain 0.9466, fused vs plain 6.9e-3
+BF16_CHAIN7_TOL = (2.4e-2, 2.5e-1, 3.5e-1, 2e-2, 0.08)       # y, dx, worst parameter gradient, fused vs plain, |gain - 1| (dx: 0.03)
+
+
+def test_bf16_storage_training_trajectory_tracks_fp32_storage():
+    """30 train_ssl_uem steps of R50-ASPP on 256x256 tiles (B = 4 + 4), bf16 storage against fp32 storage from
+    identical weights, inputs and seeds (damped residual branches, as every bf16 comparison here): at EVERY step the two losses
+    within 2 % and the hard pseudo-labels >= 99 % identical; after 30 steps the weights of the two runs apart by a bounded fraction
+    of the distance they travelled.  Replaces the whole-arena gradient cosine > 0.7 of round 2, which a 10 % systematic error
+    in the bf16 backward would have passed."""
+    from oracle import synth
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    C, B, S, STEPS = 6, 4, 256, 30
+    sd = _damped_sd("resnet50")
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    bc = synth.make_batch(B=B, H=S, W=S, C=C, k=2048, seed=77)
+    hist, final = {}, {}
+    for storage in ("fp32", "bf16"):
+        model = Deeplabv2(cfg)
+        model.load_state_dict(sd)
+        model = model.cuda().set_storage(storage)
+        b = {k: v.cuda() for k, v in bc.items()}
+        al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+        al.prototypes = b["prototypes"].clone()
+        opt, st = FusedSGD(model, 1e-2, 0.9, 5e-4), StepState(C)
+        rows = []
+        for i in range(STEPS):
+            out = ssl_step(model, al, opt, st, b, 5e-3, sup_ignore_id=(S // 16) ** 2)
+            rows.append((float(out["loss_source"]), float(out["loss_target"]), out["label_t_hard"].cpu(), float(out["grad_norm"])))
+        hist[storage] = rows
+        arena, _, n = model.flat_parameters()
+        final[storage] = arena[:n].double().cpu().clone()
+        del model, opt
+    model = Deeplabv2(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    arena, _, n = model.flat_parameters()
+    w0 = arena[:n].double().cpu().clone()
+    del model
+    worst_ls = worst_lt = 0.0
+    worst_agree = 1.0
+    for i in range(STEPS):
+        a, b_ = hist["fp32"][i], hist["bf16"][i]
+        worst_ls = max(worst_ls, abs(b_[0] / a[0] - 1.0))
+        worst_lt = max(worst_lt, abs(b_[1] / a[1] - 1.0))
+        worst_agree = min(worst_agree, (a[2] == b_[2]).float().mean().item())
+    travelled = float((final["fp32"] - w0).norm()) if w0.numel() == final["fp32"].numel() else float("nan")
+    apart = float((final["bf16"] - final["fp32"]).norm())
+    rel_w = apart / float(final["fp32"].norm())
+    print("step: loss_s fp32/bf16, loss_t fp32/bf16, agreement")
+    for i in range(STEPS):
+        a, b_ = hist["fp32"][i], hist["bf16"][i]
+        print(f"  {i:2d}: {a[0]:.4f} {b_[0]:.4f}   {a[1]:.4f} {b_[1]:.4f}   {(a[2] == b_[2]).float().mean().item():.4f}")
+    print(f"30-step trajectory bf16 vs fp32 storage: worst loss_source deviation {worst_ls:.3e}, loss_target {worst_lt:.3e}, worst hard-label "
+          f"agreement {worst_agree:.5f}; final weights apart {apart:.3e} = {rel_w:.3e} of |w|, distance travelled {travelled:.3e}; "
+          f"losses first/last fp32 {hist['fp32'][0][:2]} {hist['fp32'][-1][:2]} bf16 {hist['bf16'][-1][:2]}")
+    worst_total = max(abs((b_[0] + b_[1]) / (a[0] + a[1]) - 1.0) for a, b_ in zip(hist["fp32"], hist["bf16"]))
+    worst_lt_of_total = max(abs(b_[1] - a[1]) / (a[0] + a[1]) for a, b_ in zip(hist["fp32"], hist["bf16"]))
+    print(f"worst total-loss deviation {worst_total:.3e}; worst loss_target deviation as a fraction of the total loss {worst_lt_of_total:.3e}; "
+          f"weights apart / distance travelled {apart / travelled:.3e}")
+    assert hist["fp32"][-1][0] < 0.6 * hist["fp32"][0][0] and hist["fp32"][-1][1] < 0.1 * hist["fp32"][0][1]      # it trains
+    # loss curves within 2 %: the total and the source loss relatively; the target (UVEM) loss falls from 1.73 to 0.02 over the run,
+    # where 2 % of ITSELF is 4e-4 -- it is held to 1 % of the step's total loss instead (measured 0.34 %; total 0.8 %, source 0.8 %)
+    assert worst_total < 2e-2 and worst_ls < 2e-2 and worst_lt_of_total < 1e-2, (worst_total, worst_ls, worst_lt_of_total)
+    assert worst_agree >= 0.99, worst_agree                                # measured 0.9921 at the worst step
+    assert rel_w < BF16_TRAJ_WEIGHT_TOL[0] and apart / travelled < BF16_TRAJ_WEIGHT_TOL[1], (rel_w, apart / travelled)
+
+
+# |w_bf16 - w_fp32| / |w_fp32| after 30 steps (measured 3.8e-3), and as a fraction of the distance the fp32 run travelled from the
+# initial weights
+BF16_TRAJ_WEIGHT_TOL = (1.2e-2, 0.9)              # measured 3.8e-3 and 0.57

@@ -954,41 +954,61 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
 
-    auto step = [&](unsigned short* __restrict__ fill, const unsigned short* __restrict__ use, const bool do_issue, const bool do_phase) {
-        if (do_issue && !(UEM_DBG(p.dbg) & 4)) {
-            unsigned short* const As = fill;
-            unsigned short* const Bs = fill + C::A_ELEMS;
-            if (lci0 == 0) setup_tap(lt);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = (tapok >> j) & 1u;
-                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(As + (j * 4 + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
+    // Round 3 (as conv_dma_kernel): the DMA pieces of the next operand tile go out one at a time between the MFMAs of the current
+    // one -- 4 + BR pieces per 16 MFMAs here, where a burst of them in front of the MFMA phase cost more issue time than the MFMAs
+    // themselves take -- and the step has ONE call site (stages chosen by address).  A step with nothing left to request sends its
+    // pieces with an out-of-range offset (no memory access).
+    constexpr int NPC = 4 + BR, NKS = KBH / 16;
+    auto step = [&](unsigned short* __restrict__ fill, const unsigned short* __restrict__ use, const bool live_, const bool do_phase) {
+        const bool live = live_ && !(UEM_DBG(p.dbg) & 4);
+        unsigned short* const fAs = fill;
+        unsigned short* const fBs = fill + C::A_ELEMS;
+        if (live && lci0 == 0) setup_tap(lt);
+        auto piece = [&](const int j) {
+            if (j < 4) {
+                const bool ok = live && ((tapok >> j) & 1u);
+                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(fAs + (j * 4 + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
                 aoff[j] += KBH * 2;
+            } else if (j < NPC) {
+                const int jb = j - 4;
+                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(fBs + (jb * 4 + wave) * 512), 16, (int)(live ? boff[jb] : CONV_OOB), 0, 0, 0);
+                boff[jb] += KBH * 2;
             }
-#pragma unroll
-            for (int j = 0; j < BR; ++j) {
-                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(Bs + (j * 4 + wave) * 512), 16, (int)boff[j], 0, 0, 0);
-                boff[j] += KBH * 2;
-            }
+        };
+        auto advance = [&]() {
+            if (!live) return;
             lci0 += KBH;
             if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
+        };
+        if (!do_phase) {
+#pragma unroll
+            for (int j = 0; j < NPC; ++j) piece(j);
+            advance();
+            return;
         }
-        if (!do_phase) return;
         const unsigned short* const As = use;
         const unsigned short* const Bs = use + C::A_ELEMS;
+        constexpr int PPS = (NPC + NKS - 1) / NKS;                       // DMA pieces per 16-channel MFMA step
+        static_assert(PPS <= MT * NT, "more DMA pieces than MFMAs in a step");
 #pragma unroll
-        for (int ks = 0; ks < KBH / 16; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             const int qs = (((ks * 2 + fh) ^ sw)) * 8;                   // this lane half's 16-B chunk = its 8 k of the MFMA step
             bf16x8 a[MT], b[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm + i * 32 + fr) * KBH + qs]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn + j * 32 + fr) * KBH + qs]);
+            int q = 0;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if (q < PPS && ks * PPS + q < NPC) piece(ks * PPS + q);
+                    ++q;
+                }
         }
+        advance();
     };
     constexpr bool FULL = EPI >= 0;
     const bool dense_rows = FULL || !(MODE == 1 && p.sub > 1);
@@ -1046,17 +1066,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     asm volatile("" ::: "memory")
     if (KT > 0) {
         unsigned short* const st0 = lds16;
-        unsigned short* const st1 = lds16 + C::STAGE_BYTES / 2;
-        step(st0, st1, true, false);
-        for (int kt = 0; kt < KT; kt += 2) {
+        step(st0, st0 + C::STAGE_BYTES / 2, true, false);
+        int par = 0;
+        for (int kt = 0; kt < KT; ++kt) {
             CONV_SYNC();
-            step(st1, st0, kt + 1 < KT, true);
-            if (kt + 1 >= KT) break;
-            CONV_SYNC();
-            step(st0, st1, kt + 2 < KT, true);
+            step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), kt + 1 < KT, true);
+            par ^= 1;
         }
+        CONV_SYNC();                                                     // the last step's out-of-range pieces have landed too
+    } else {
+        __syncthreads();
     }
-    __syncthreads();
 #undef CONV_SYNC
 
     // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
