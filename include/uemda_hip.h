@@ -107,10 +107,17 @@ int uem_bias_grad(const float* dy, float* db /* += */, int M, int C, int ld, voi
  *   out[n,y,x,j] = sum_d ( bias[d][j] + sum_tap G[n, y+(ky-1)*dil_d, x+(kx-1)*dil_d, (d*9+tap)*K2 + j] )
  * G is (N,h,w,R) with R >= nd*9*K2 (padded to the GEMM tile); K2 = heads*classes; dil is a HOST array.
  * bwd fills dG (all R columns; the padding gets zeros) from dout (N,h,w,K2).                         */
-int uem_aspp_gather_fwd(const float* G, const float* bias /* [nd][K2] */, float* out, int N, int h, int w, int K2,
+int uem_aspp_gather_fwd(const float* G, const float* bias /* [nd][K2] */, float* out, float* out2 /* NULL: out is (N,h,w,K2);
+                        else head 0 -> out, head 1 -> out2, each (N,h,w,K2/2) */, int N, int h, int w, int K2,
                         int R, int nd, const int* dil, void* stream);
-int uem_aspp_gather_bwd(const float* dout, float* dG, int N, int h, int w, int K2, int R, int nd, const int* dil,
-                        void* stream);
+int uem_aspp_gather_bwd(const float* dout, const float* dout2 /* as out2 */, float* dG, int N, int h, int w, int K2, int R, int nd,
+                        const int* dil, void* stream);
+/* The heads' filters <-> the GEMM's filter bank in one launch each way: w / b (HOST arrays of 2*nd device pointers, index
+ * head*nd + d) are the (C,3,3,cin) OHWI filters and (C,) biases of Classifier_Module.conv2d_list (Encoder.py:74-78).
+ * pack: wall (R,cin) row (d*9+tap)*2C + head*C + c = w[head][d][c][tap][:], rows >= nd*18*C zero; bias [nd][2][C].
+ * unpack_grad: gw[..] += the matching rows of dwall; gb[head][d][:] += db[head*C ..] (every dilation's bias sees the same gradient). */
+int uem_aspp_pack(void* const* w, void* const* b, float* wall, float* bias, int C, int cin, int nd, int R, void* stream);
+int uem_aspp_unpack_grad(const float* dwall, const float* db, void* const* gw, void* const* gb, int C, int cin, int nd, void* stream);
 
 /* ---- BatchNorm2d (training + eval), fused ReLU / residual -- _resnets.py:96-110, Encoder.py:20,37 --
  * stats: per-channel batch mean / biased var of x[M][C]; also updates running stats

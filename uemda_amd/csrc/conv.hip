@@ -1935,8 +1935,8 @@ struct AsppP {
     int dil[8];
 };
 __global__ __launch_bounds__(256) void aspp_gather_fwd_kernel(const float* __restrict__ G, const float* __restrict__ bias,
-                                                              float* __restrict__ out, const AsppP p) {
-    // one thread per (pixel, j); out is (N,h,w,K2)
+                                                              float* __restrict__ out, float* __restrict__ out2, const AsppP p) {
+    // one thread per (pixel, j); out is (N,h,w,K2), or with out2 two (N,h,w,K2/2) tensors: head 0 -> out, head 1 -> out2
     const int64_t total = (int64_t)p.N * p.h * p.w * p.K2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int j = (int)(i % p.K2);
@@ -1960,10 +1960,17 @@ __global__ __launch_bounds__(256) void aspp_gather_fwd_kernel(const float* __res
                 }
             }
         }
-        out[i] = acc;
+        if (out2 == nullptr) out[i] = acc;
+        else {
+            const int Ch = p.K2 >> 1;
+            const size_t pix = (size_t)(i / p.K2);
+            if (j < Ch) out[pix * Ch + j] = acc;
+            else out2[pix * Ch + (j - Ch)] = acc;
+        }
     }
 }
-__global__ __launch_bounds__(256) void aspp_gather_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dG, const AsppP p) {
+__global__ __launch_bounds__(256) void aspp_gather_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ dout2,
+                                                              float* __restrict__ dG, const AsppP p) {
     // one thread per (pixel q, column r): dG[q][r] = dOut[q - off][j] when that pixel exists (its tap lands on q)
     const int64_t total = (int64_t)p.N * p.h * p.w * p.R;
     const int used = p.nd * 9 * p.K2;
@@ -1977,7 +1984,11 @@ __global__ __launch_bounds__(256) void aspp_gather_bwd_kernel(const float* __res
             const int n = (int)(t / p.h);
             const int j = r % p.K2, tap = (r / p.K2) % 9, d = r / (9 * p.K2);
             const int yo = y - (tap / 3 - 1) * p.dil[d], xo = x - (tap % 3 - 1) * p.dil[d];
-            if (yo >= 0 && yo < p.h && xo >= 0 && xo < p.w) v = dout[(((size_t)n * p.h + yo) * p.w + xo) * p.K2 + j];
+            if (yo >= 0 && yo < p.h && xo >= 0 && xo < p.w) {
+                const size_t pix = ((size_t)n * p.h + yo) * p.w + xo;
+                const int Ch = p.K2 >> 1;
+                v = dout2 == nullptr ? dout[pix * p.K2 + j] : (j < Ch ? dout[pix * Ch + j] : dout2[pix * Ch + (j - Ch)]);
+            }
         }
         dG[i] = v;
     }
@@ -1989,23 +2000,95 @@ static int aspp_params(AsppP* p, int N, int h, int w, int K2, int R, int nd, con
     for (int i = 0; i < 8; ++i) p->dil[i] = i < nd ? dil[i] : 0;
     return UEM_OK;
 }
-extern "C" int uem_aspp_gather_fwd(const float* G, const float* bias, float* out, int N, int h, int w, int K2, int R,
+extern "C" int uem_aspp_gather_fwd(const float* G, const float* bias, float* out, float* out2, int N, int h, int w, int K2, int R,
                                    int nd, const int* dil, void* stream) {
-    UEM_REQUIRE(G && bias && out, "aspp_gather_fwd: null pointer");
+    UEM_REQUIRE(G && bias && out && (out2 == nullptr || K2 % 2 == 0), "aspp_gather_fwd: null pointer / odd K2 with two outputs");
     AsppP p;
     int rc = aspp_params(&p, N, h, w, K2, R, nd, dil);
     if (rc) return rc;
-    aspp_gather_fwd_kernel<<<uem_stream_grid((int64_t)N * h * w * K2, 256), 256, 0, (hipStream_t)stream>>>(G, bias, out, p);
+    aspp_gather_fwd_kernel<<<uem_stream_grid((int64_t)N * h * w * K2, 256), 256, 0, (hipStream_t)stream>>>(G, bias, out, out2, p);
     return uem_check_launch("aspp_gather_fwd");
 }
-extern "C" int uem_aspp_gather_bwd(const float* dout, float* dG, int N, int h, int w, int K2, int R, int nd, const int* dil,
-                                   void* stream) {
-    UEM_REQUIRE(dout && dG, "aspp_gather_bwd: null pointer");
+extern "C" int uem_aspp_gather_bwd(const float* dout, const float* dout2, float* dG, int N, int h, int w, int K2, int R, int nd,
+                                   const int* dil, void* stream) {
+    UEM_REQUIRE(dout && dG && (dout2 == nullptr || K2 % 2 == 0), "aspp_gather_bwd: null pointer / odd K2 with two inputs");
     AsppP p;
     int rc = aspp_params(&p, N, h, w, K2, R, nd, dil);
     if (rc) return rc;
-    aspp_gather_bwd_kernel<<<uem_stream_grid((int64_t)N * h * w * R, 256), 256, 0, (hipStream_t)stream>>>(dout, dG, p);
+    aspp_gather_bwd_kernel<<<uem_stream_grid((int64_t)N * h * w * R, 256), 256, 0, (hipStream_t)stream>>>(dout, dout2, dG, p);
     return uem_check_launch("aspp_gather_bwd");
+}
+
+// The 2 heads x nd dilations' filters <-> the GEMM's filter bank, one launch each way (round 2 did it with 16 + 24 torch copy / add
+// launches per forward / backward).  Wall row (d*9 + tap)*2C + head*C + c = W[head][d][c][tap][:]; bias [nd][2][C].
+struct AsppPtrs {
+    float* w[8];        // [head*nd + d]: (C,3,3,cin) OHWI filters (pack: read; unpack: gradient, accumulated into)
+    float* b[8];        // (C,) biases / their gradients
+};
+__global__ __launch_bounds__(256) void aspp_pack_kernel(const AsppPtrs ptrs, float* __restrict__ wall, float* __restrict__ bias,
+                                                        const int C, const int cin, const int nd, const int R) {
+    const int cq = cin / 4;
+    const int64_t total = (int64_t)R * cq;
+    const int used = nd * 9 * 2 * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cq), ci = (int)(i - (int64_t)r * cq) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                        // rows beyond the used columns: zero filters
+        if (r < used) {
+            const int c = r % C, head = (r / C) & 1, tap = (r / (2 * C)) % 9, d = r / (18 * C);
+            v = *reinterpret_cast<const float4*>(ptrs.w[head * nd + d] + ((size_t)c * 9 + tap) * cin + ci);
+        }
+        *reinterpret_cast<float4*>(wall + (size_t)r * cin + ci) = v;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < nd * 2 * C) {
+        const int t = threadIdx.x, c = t % C, head = (t / C) & 1, d = t / (2 * C);
+        bias[t] = ptrs.b[head * nd + d][c];
+    }
+}
+__global__ __launch_bounds__(256) void aspp_unpack_grad_kernel(const float* __restrict__ dwall, const float* __restrict__ db,
+                                                               const AsppPtrs ptrs, const int C, const int cin, const int nd) {
+    const int cq = cin / 4;
+    const int used = nd * 9 * 2 * C;
+    const int64_t total = (int64_t)used * cq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cq), ci = (int)(i - (int64_t)r * cq) * 4;
+        const int c = r % C, head = (r / C) & 1, tap = (r / (2 * C)) % 9, d = r / (18 * C);
+        // atomics: the two heads may be ONE module (a caller passing the same Classifier_Module twice), their rows then add into
+        // the same gradient buffer from different threads
+        float* dst = ptrs.w[head * nd + d] + ((size_t)c * 9 + tap) * cin + ci;
+        const float4 g = *reinterpret_cast<const float4*>(dwall + (size_t)r * cin + ci);
+        atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < nd * 2 * C) {                 // every dilation's bias sees the same output gradient
+        const int t = threadIdx.x, c = t % C, head = (t / C) & 1, d = t / (2 * C);
+        atomicAdd(&ptrs.b[head * nd + d][c], db[head * C + c]);
+    }
+}
+static int aspp_ptrs(AsppPtrs* q, void* const* w, void* const* b, int C, int cin, int nd, const char* what) {
+    if (!w || !b || C <= 0 || cin <= 0 || cin % 4 != 0 || nd <= 0 || nd > 4 || nd * 2 * C > 256)
+        return uem_fail(UEM_ERR_INVALID, "%s: bad arguments (nd <= 4, nd*2*C <= 256, cin %% 4 == 0)", what);
+    for (int i = 0; i < 8; ++i) {
+        q->w[i] = i < 2 * nd ? (float*)w[i] : nullptr;
+        q->b[i] = i < 2 * nd ? (float*)b[i] : nullptr;
+        if (i < 2 * nd && (!q->w[i] || !q->b[i] || ((uintptr_t)q->w[i] & 15))) return uem_fail(UEM_ERR_INVALID, "%s: null or misaligned filter pointer", what);
+    }
+    return UEM_OK;
+}
+extern "C" int uem_aspp_pack(void* const* w, void* const* b, float* wall, float* bias, int C, int cin, int nd, int R, void* stream) {
+    UEM_REQUIRE(wall && bias && R >= nd * 18 * C, "aspp_pack: bad arguments");
+    AsppPtrs q;
+    const int rc = aspp_ptrs(&q, w, b, C, cin, nd, "aspp_pack");
+    if (rc) return rc;
+    aspp_pack_kernel<<<uem_stream_grid((int64_t)R * (cin / 4), 256), 256, 0, (hipStream_t)stream>>>(q, wall, bias, C, cin, nd, R);
+    return uem_check_launch("aspp_pack");
+}
+extern "C" int uem_aspp_unpack_grad(const float* dwall, const float* db, void* const* gw, void* const* gb, int C, int cin, int nd,
+                                    void* stream) {
+    UEM_REQUIRE(dwall && db, "aspp_unpack_grad: null pointer");
+    AsppPtrs q;
+    const int rc = aspp_ptrs(&q, gw, gb, C, cin, nd, "aspp_unpack_grad");
+    if (rc) return rc;
+    aspp_unpack_grad_kernel<<<uem_stream_grid((int64_t)nd * 18 * C * (cin / 4), 256), 256, 0, (hipStream_t)stream>>>(dwall, db, q, C, cin, nd);
+    return uem_check_launch("aspp_unpack_grad");
 }
 
 // =========================================================================================================
@@ -2016,8 +2099,7 @@ static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream
     using C = ConvBf16Cfg<BN_>;
     const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
     auto k = conv_bf16_kernel<BN_, MODE, EPI>;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    (void)attr;
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;   // per device: per launch
     k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
 }
 template <int BN_, int MODE>

@@ -270,21 +270,25 @@ class InstNormFn(Function):
         return ops.instnorm_bwd(y, dy.contiguous(), invstd), None
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * 8)(*([t.data_ptr() for t in tensors] + [None] * (8 - len(tensors))))
+
+
 def _aspp_pack(head5, head6, feat):
-    """Wall (R, 1, 1, cin): row (d*9 + tap)*2C + head*C + c = W_head,d[c, tap, :]; bias (nd, 2C)."""
+    """Wall (R, 1, 1, cin): row (d*9 + tap)*2C + head*C + c = W_head,d[c, tap, :]; bias (nd, 2, C) -- one kernel launch."""
     C = head5.conv2d_list[0].weight.shape[0]
     cin = feat.shape[3]
     nd = len(head5.dilations)
     used = nd * 9 * 2 * C
     R = (used + 63) // 64 * 64                       # GEMM N tile (64) and dgrad K block (32)
-    wall = torch.zeros((R, cin), device=feat.device, dtype=torch.float32)
-    wv = wall[:used].view(nd, 9, 2, C, cin)
+    if nd > 4 or nd * 2 * C > 256:
+        raise UemError("ASPP heads: at most 4 dilations and 2 * nd * classes <= 256")
+    wall = torch.empty((R, cin), device=feat.device, dtype=torch.float32)
     bias = torch.empty((nd, 2, C), device=feat.device, dtype=torch.float32)
-    for i in range(nd):
-        for hd, head in enumerate((head5, head6)):
-            conv = head.conv2d_list[i]
-            wv[i, :, hd].copy_(ops.weight_ohwi(conv.weight).reshape(C, 9, cin).permute(1, 0, 2))
-            bias[i, hd].copy_(conv.bias.detach())
+    convs = [head.conv2d_list[i] for head in (head5, head6) for i in range(nd)]
+    ops.call("uem_aspp_pack", _ptr_array([ops.weight_ohwi(c.weight) for c in convs]), _ptr_array([c.bias.detach() for c in convs]),
+             ops.ptr(wall), ops.ptr(bias), C, cin, nd, R, ops.stream())
     return wall.view(R, 1, 1, cin), bias, C, nd, R, used
 
 
@@ -305,10 +309,9 @@ class ASPPHeadsFn(Function):
         ctx.prec = ASPPHeadsFn.prec
         with ops.conv_precision(ctx.prec):
             G = ops.conv2d(feat, wall, algo_cout=used)
-        out = torch.empty((n, h, w, 2 * C), device=feat.device, dtype=torch.float32)
-        ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(out), n, h, w, 2 * C, R, nd, dil, ops.stream())
-        x1 = out[..., 0:C].contiguous()
-        x2 = out[..., C:2 * C].contiguous()
+        x1 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32)
+        x2 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32)
+        ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(x1), ops.ptr(x2), n, h, w, 2 * C, R, nd, dil, ops.stream())
         if any(ctx.needs_input_grad):
             ctx.heads = (head5, head6)
             ctx.save_for_backward(feat, wall)
@@ -324,21 +327,27 @@ class ASPPHeadsFn(Function):
         n, h, w, cin = feat.shape
         R = wall.shape[0]
         used = nd * 9 * 2 * C
-        dout = torch.cat([d1, d2], dim=3).contiguous()
+        d1, d2 = d1.contiguous(), d2.contiguous()
         db = torch.zeros(2 * C, device=feat.device, dtype=torch.float32)
-        ops.bias_grad(dout, db, 2 * C, 2 * C)
+        ops.bias_grad(d1, db[:C], C, C)
+        ops.bias_grad(d2, db[C:], C, C)
         dG = torch.empty((n, h, w, R), device=feat.device, dtype=torch.float32)
         dil = (ctypes.c_int * nd)(*head5.dilations)
-        ops.call("uem_aspp_gather_bwd", ops.ptr(dout), ops.ptr(dG), n, h, w, 2 * C, R, nd, dil, ops.stream())
+        ops.call("uem_aspp_gather_bwd", ops.ptr(d1), ops.ptr(d2), ops.ptr(dG), n, h, w, 2 * C, R, nd, dil, ops.stream())
         dwall = torch.zeros((R, 1, 1, cin), device=feat.device, dtype=torch.float32)
         with ops.conv_precision(ctx.prec):
             ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
             dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
-        dwv = dwall.view(R, cin)[:used].view(nd, 9, 2, C, cin)
-        for i in range(nd):
-            for hd, head in enumerate((head5, head6)):
-                conv = head.conv2d_list[i]
-                g = grad_ohwi(conv.weight)                                  # (C, 3, 3, cin) contiguous
-                ops.add_(g, dwv[i, :, hd].permute(1, 0, 2).contiguous())     # (9, C, cin) -> (C, 9, cin)
-                ops.add_(grad_buffer(conv.bias), db[hd * C:(hd + 1) * C])
+        convs = [head.conv2d_list[i] for head in (head5, head6) for i in range(nd)]
+        gws, gbs = [grad_ohwi(c.weight) for c in convs], [grad_buffer(c.bias) for c in convs]
+        if all(g is not None for g in gws + gbs):
+            ops.call("uem_aspp_unpack_grad", ops.ptr(dwall), ops.ptr(db), _ptr_array(gws), _ptr_array(gbs), C, cin, nd, ops.stream())
+        else:                                              # a frozen head parameter: per-tensor adds for the trainable ones
+            dwv = dwall.view(R, cin)[:used].view(nd, 9, 2, C, cin)
+            for k, conv in enumerate(convs):
+                hd, i = divmod(k, nd)
+                if gws[k] is not None:
+                    ops.add_(gws[k], dwv[i, :, hd].permute(1, 0, 2).contiguous())
+                if gbs[k] is not None:
+                    ops.add_(gbs[k], db[hd * C:(hd + 1) * C])
         return (dfeat, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
