@@ -443,7 +443,11 @@ def main():
         key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}" + ("" if args.storage == "fp32" else " storage=bf16")
         tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
         traffic_ok = tj.get("config") == key and tj.get("kernel_source_sha256_16") == kernel_source_hash()
-        roof = roofline_of(headline_prof, peak, (lambda fam: tj.get(fam)) if traffic_ok else None)
+        def traffic_of(fam):               # HBM bytes per launch (= per convolution) of the family: PMC bytes per step / launches per step
+            per_step = (tj.get("per_step") or {}).get(fam)
+            n = headline_prof.get(fam, {}).get("launches")
+            return round(per_step / n) if per_step and n else None
+        roof = roofline_of(headline_prof, peak, traffic_of if traffic_ok else None)
         if roof is not None and not traffic_ok:
             roof["traffic_note"] = "profiles/traffic_latest.json was taken on another configuration or another build of the conv kernels"
         try:

@@ -392,7 +392,8 @@ int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream);
 int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, void* stream);
 int uem_wino_input(const float* x, const float* in_scale, const float* in_shift, int relu, float* V, int N, int H, int W, int C,
                    int dil, void* stream);
-int uem_wino_gemm(const float* V, const float* U, float* M, int T, int K, int N, void* stream);
+int uem_wino_gemm(const float* V, const float* U, float* M, int T, int K, int N, int data_gradient /* 0 forward, 1: the same product
+                  through the data-gradient kernel instantiation */, void* stream);
 int uem_wino_output(const float* M, float* y, int N, int H, int W, int C, int dil, float* tile_stats, const float* bn_z,
                     const float* bn_vec, float* tile_bnbwd, void* stream);
 int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, void* stream);

@@ -11,7 +11,7 @@ import torch
 from uemda_amd import ops
 
 SHAPES = [("l3 3x3 256", 256, 256, 1, 32), ("l4 3x3 512 d1", 512, 512, 1, 32), ("l4 3x3 512 d2", 512, 512, 2, 32),
-          ("l2 3x3 128", 128, 128, 1, 64), ("ppm 3x3 4096->512", 4096, 512, 1, 32)]
+          ("l2 3x3 128", 128, 128, 1, 64), ("l1 3x3 64", 64, 64, 1, 128), ("ppm 3x3 4096->512", 4096, 512, 1, 32)]
 
 
 def timeit(fn, reps=5):

@@ -14,11 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name):
-    if "conv_wgrad_kernel" in name or "wgrad_dma_kernel" in name:
+    """kernel name -> conv family, as ops.PROF attributes the launches (a Winograd conv is its transforms + its GEMM)"""
+    if "conv_wgrad_kernel" in name or "wgrad_dma_kernel" in name or "wino_dy_kernel" in name or "wino_filter_grad_kernel" in name:
         return "conv_wgrad"
     m = re.search(r"conv_fwd_kernel<\d+, \d+, \d+, (\d)", name) or re.search(r"conv_dma_kernel<\d+, \d+, (\d)", name)   # <BN, KB, MODE, ...>
     if m:
         return "conv_dgrad" if m.group(1) == "1" else "conv_fwd"
+    m = re.search(r"wino_input_kernel<(\w+)>", name) or re.search(r"wino_filter_kernel<(\w+)>", name)
+    if m:
+        return "conv_fwd" if m.group(1) in ("true", "1") and "wino_input" in name or m.group(1) in ("false", "0") and "wino_filter" in name else "conv_dgrad"
+    m = re.search(r"wino_output_kernel<(\d)>", name)
+    if m:
+        return "conv_dgrad" if m.group(1) == "2" else "conv_fwd"
     return None
 
 
@@ -38,18 +45,22 @@ def collect(dirname, counter):
 
 
 def main():
-    # usage: pmc_traffic.py <fetch_dir> <write_dir> "<config key>"   (key = bench.py's: "<model>-<head> <workload> B=.. size=.. prec=..")
-    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-    config = sys.argv[3] if len(sys.argv) > 3 else "resnet50-aspp ssl B=32 size=512 prec=fp32"
+    # usage: pmc_traffic.py <fetch_dir> <write_dir> <steps profiled> "<config key>"
+    #   (key = bench.py's: "<model>-<head> <workload> B=.. size=.. prec=..").  Output: HBM bytes per STEP and family (bench.py divides
+    #   by its launches per step), stamped with the hash of the conv kernel sources they were measured on.
+    sys.path.insert(0, ROOT)
+    import bench
+    fetch_dir, write_dir, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    config = sys.argv[4] if len(sys.argv) > 4 else "resnet50-aspp ssl B=32 size=512 prec=fp32"
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
-    out = {"config": config}
+    out = {"config": config, "kernel_source_sha256_16": bench.kernel_source_hash(), "steps_profiled": steps, "per_step": {}}
     for fam in fe:
         nf, vf = fe[fam]
         nw, vw = wr.get(fam, (1, 0.0))
-        fetch_b = 2.0 * vf * 1024 / nf          # gfx950: doubled (see docstring)
-        write_b = vw * 1024 / max(nw, 1)
-        out[fam] = round(fetch_b + write_b)
-        print(f"{fam:11s} launches={nf:5d}  fetch/launch={fetch_b / 1e6:9.2f} MB (corrected x2)  write/launch={write_b / 1e6:9.2f} MB")
+        fetch_b = 2.0 * vf * 1024 / steps       # gfx950: doubled (see docstring)
+        write_b = vw * 1024 / steps
+        out["per_step"][fam] = round(fetch_b + write_b)
+        print(f"{fam:11s} kernel launches/step={nf / steps:7.1f}  fetch/step={fetch_b / 1e9:8.3f} GB (corrected x2)  write/step={write_b / 1e9:8.3f} GB")
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 
 

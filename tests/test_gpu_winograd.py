@@ -21,6 +21,7 @@ def rel(a, b):
 
 
 WINO_CASES = [
+    (2, 32, 32, 128, 128, 1),        # layer2 at 512^2-tile scale: forward and weight gradient take this path, the data gradient does not
     # N, H, W, Cin, Cout, dil
     (2, 16, 16, 256, 256, 1),        # layer3 at 256^2 tiles: T = 128
     (2, 16, 16, 512, 512, 2),        # layer4 dilated at 256^2
@@ -105,7 +106,8 @@ def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(case):
 
 def test_winograd_declines_shapes_it_does_not_take():
     from uemda_amd import ops
-    assert not ops.wino_ok((2, 16, 16, 128), 128, 3, 3, 1, 1, 1)        # narrow layers stay on the direct kernels
+    assert not ops.wino_ok((2, 16, 16, 64), 64, 3, 3, 1, 1, 1)          # narrow layers stay on the direct kernels
+    assert ops.wino_ok((2, 16, 16, 128), 128, 3, 3, 1, 1, 1) and not ops.wino_dgrad_ok(128, 128)   # layer2: forward + weight gradient only
     assert not ops.wino_ok((2, 16, 16, 256), 256, 3, 3, 2, 1, 1)        # stride 2
     assert not ops.wino_ok((2, 16, 16, 256), 256, 1, 1, 1, 0, 1)        # 1x1
     assert not ops.wino_ok((2, 18, 18, 256), 256, 3, 3, 1, 2, 2)        # 18 is not a multiple of 2 * dilation

@@ -116,7 +116,7 @@ SIGNATURES = {
     "uem_cast_bf16_f32": [P, P, L, P],
     "uem_wino_filter": [P, P, I, I, I, P],
     "uem_wino_input": [P, P, P, I, P, I, I, I, I, I, P],
-    "uem_wino_gemm": [P, P, P, I, I, I, P],
+    "uem_wino_gemm": [P, P, P, I, I, I, I, P],
     "uem_wino_output": [P, P, I, I, I, I, I, P, P, P, P, P],
     "uem_wino_dy": [P, P, I, I, I, I, I, P],
     "uem_wino_wgrad_gemm": [P, P, P, I, I, I, P],

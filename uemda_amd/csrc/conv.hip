@@ -1413,7 +1413,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
 
 // The 16 element-wise products of Winograd F(2x2, 3x3) (winograd.hip) as ONE pointwise launch: V [16][T][K] x U[16][N][K]^T -> M [16][T][N];
 // GEMM row r = (position, tile) takes the filter bank of position r / T.
-extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, int K, int N, void* stream) {
+extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, int K, int N, int data_gradient, void* stream) {
     UEM_REQUIRE(V && U && Mt && T > 0 && K > 0 && N > 0, "wino_gemm: bad arguments");
     if (T % BM != 0 || K % BK != 0 || N % 64 != 0 || (((uintptr_t)V | (uintptr_t)U) & 15))
         return uem_fail(UEM_ERR_UNSUPPORTED, "wino_gemm: needs T %% 128 == 0, K %% 32 == 0, N %% 64 == 0, 16-byte aligned operands");
@@ -1428,7 +1428,10 @@ extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, i
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 1; p.tapmask = 0; p.dbg = 0;
     p.wg_rows = T; p.wg_stride = (unsigned)((size_t)N * K * 4);
     p.M = 16 * T;
-    if (!conv_dma_try<0>(p, false, (hipStream_t)stream)) return uem_fail(UEM_ERR_UNSUPPORTED, "wino_gemm: shape not taken by the LDS-DMA kernel");
+    // data_gradient: the same pointwise product through the data-gradient instantiation (MODE 1: its tile rules, and a kernel name
+    // that profiles attribute to the data-gradient family)
+    const int took = data_gradient ? conv_dma_try<1>(p, false, (hipStream_t)stream) : conv_dma_try<0>(p, false, (hipStream_t)stream);
+    if (!took) return uem_fail(UEM_ERR_UNSUPPORTED, "wino_gemm: shape not taken by the LDS-DMA kernel");
     return uem_check_launch("wino_gemm");
 }
 

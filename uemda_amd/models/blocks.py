@@ -210,7 +210,10 @@ class BottleneckFn(Function):
         del dz3
         if ctx.wino:
             ops.conv3x3_wino_wgrad(sv[-1], dz2, G(blk.conv2.weight), d)
-            if st1.training and ops.FUSE_BN_BACKWARD:
+            if not ops.wino_dgrad_ok(z1.shape[-1], dz2.shape[-1]):
+                dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose_cached(blk.conv2.weight), z1, st1, gb(blk.bn1.weight),
+                                                   gb(blk.bn1.bias), stride=s, pad=d, dil=d)
+            elif st1.training and ops.FUSE_BN_BACKWARD:
                 dz1 = ops.conv3x3_wino_dgrad_bn_backward(dz2, blk.conv2.weight, z1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), d)
             else:
                 da1, _ = ops.conv3x3_wino_dgrad(dz2, blk.conv2.weight, d)

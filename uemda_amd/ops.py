@@ -369,7 +369,10 @@ def weight_transpose_cached(param):
 # Winograd F(2x2, 3x3): the stride-1 3x3 convolutions of the deep layers (csrc/winograd.hip), exact fp32, 2.25x fewer multiplies
 # ------------------------------------------------------------------------------------------------
 WINOGRAD = os.environ.get("UEM_WINOGRAD", "1") != "0"
-WINOGRAD_MIN_CH = int(os.environ.get("UEM_WINOGRAD_MIN_CH", "256"))     # narrower layers are HBM-bound on the 4x larger transform tensors
+# narrower layers are HBM-bound on the 4x larger transform tensors (profiles/r03_d_winograd_vs_direct.txt): at 128 channels
+# (layer2) the forward still gains 7 % and the weight gradient 35 %, the data gradient loses; at 64 channels everything loses
+WINOGRAD_MIN_CH = int(os.environ.get("UEM_WINOGRAD_MIN_CH", "128"))
+WINOGRAD_MIN_CH_DGRAD = int(os.environ.get("UEM_WINOGRAD_MIN_CH_DGRAD", "256"))
 
 
 def wino_ok(x_shape, cout, kh, kw, stride, pad, dil):
@@ -381,6 +384,11 @@ def wino_ok(x_shape, cout, kh, kw, stride, pad, dil):
         return False
     t = n * h * w // 4
     return t % 128 == 0 and 16 * t * max(cin, cout) < 2 ** 30
+
+
+def wino_dgrad_ok(cin, cout):
+    """the data gradient of a conv whose forward took the Winograd path stays on the direct kernel below this width"""
+    return min(cin, cout) >= WINOGRAD_MIN_CH_DGRAD
 
 
 def wino_filter_cached(param, transposed):
@@ -405,11 +413,11 @@ def wino_input(x, dil, in_scale=None, in_shift=None, in_relu=False):
     return v
 
 
-def wino_gemm(v, u):
+def wino_gemm(v, u, data_gradient=False):
     _, t, k = v.shape
     nn = u.shape[1]
     m = torch.empty((16, t, nn), device=v.device, dtype=torch.float32)
-    call("uem_wino_gemm", ptr(v), ptr(u), ptr(m), t, k, nn, stream())
+    call("uem_wino_gemm", ptr(v), ptr(u), ptr(m), t, k, nn, 1 if data_gradient else 0, stream())
     return m
 
 
@@ -479,7 +487,7 @@ def conv3x3_wino_dgrad(dy, param, dil, bn_z=None, bn_st=None):
             raise UemError("conv3x3_wino_dgrad: BNState vectors must live in one (4, C) buffer")
 
     def run():
-        m = wino_gemm(wino_input(dy, dil), ut)
+        m = wino_gemm(wino_input(dy, dil), ut, data_gradient=True)
         call("uem_wino_output", ptr(m), ptr(dx), n, h, w, cin, dil, None, ptr(bn_z), ptr(vec), ptr(tp), stream())
 
     PROF.run("conv_dgrad", 2.0 * M * cout * 9 * cin, run, executed=2.0 * M * cout * 4 * cin)
