@@ -14,9 +14,10 @@ from uemda_amd.utils.tools import tta_predict
 C = 6
 cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
            use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
-model = Deeplabv2(cfg).cuda().eval()
 img = torch.randn(1, 3, 512, 512, device="cuda")
-with torch.no_grad():
+for storage in ("fp32", "bf16"):
+  model = Deeplabv2(cfg).cuda().set_storage(storage).eval()
+  with torch.no_grad():
     for batched in (False, True):
         for _ in range(3):
             tta_predict(model, img, batched=batched)
@@ -27,4 +28,4 @@ with torch.no_grad():
             tta_predict(model, img, batched=batched)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        print(f"tta_predict 512x512, {'one batch of 8' if batched else '8 forwards   '}: {1e3 * dt:.2f} ms per tile ({1 / dt:.1f} tiles/s)")
+        print(f"tta_predict 512x512, {storage} storage, {'one batch of 8' if batched else '8 forwards   '}: {1e3 * dt:.2f} ms per tile ({1 / dt:.1f} tiles/s)")

@@ -42,7 +42,8 @@ class BottleneckBf16Fn(Function):
         else:
             zd, std = None, None
             y, bits = ob.affine_act(z3, st3, res=x, want_bits=True)
-        blk._nbt_add()
+        if blk.bn1.training:
+            blk._nbt_add()
         if any(ctx.needs_input_grad):
             ctx.blk, ctx.has_ds = blk, has_ds
             saved = [x, bits, z1, a1, z2, a2, z3, _st_tensor(st1), _st_tensor(st2), _st_tensor(st3)]

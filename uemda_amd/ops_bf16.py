@@ -194,10 +194,17 @@ def conv2d_bn(x, w_b, bn, stride=1, pad=0, dil=1):
     n, h, w, _ = x.shape
     ho, wo = conv_out_size(h, w_b.shape[1], stride, pad, dil), conv_out_size(w, w_b.shape[2], stride, pad, dil)
     M = n * ho * wo
+    if not (bn.training or bn.running_mean is None):
+        # eval mode (round 3: the offline pseudo-label pass and evaluation are pure inference and gain the most from bf16
+        # storage): scale / shift from the running statistics, no statistics pass, any number of output pixels.  Inference only:
+        # a training graph through a frozen BatchNorm (batchnorm_trainable=False) stays on the fp32 storage path.
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise UemError("bf16 storage with eval-mode BatchNorm is an inference path (run it under torch.no_grad()); "
+                           "training through frozen BatchNorm statistics runs in fp32 storage")
+        z = conv2d(x, w_b, stride=stride, pad=pad, dil=dil)
+        return z, ops.bn_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, False, bn.eps)
     if M % 128 != 0:
         raise UemError(f"bf16 storage: conv outputs need a multiple of 128 pixels per batch (got {M}); use fp32 storage")
-    if not (bn.training or bn.running_mean is None):
-        raise UemError("bf16 storage is a training path (batch statistics); eval mode runs in fp32")
     z, ts = conv2d(x, w_b, stride=stride, pad=pad, dil=dil, want_stats=True)
     st = ops.BNState()
     st.training = True

@@ -186,8 +186,10 @@ class ResNetEncoder(nn.Module):
     def forward_nhwc(self, x):
         r = self.resnet
         params = [r.conv1.weight, r.bn1.weight, r.bn1.bias]
-        bf16 = self.storage == "bf16" and self.training
-        blocks.StemFn.prec = "bf16" if bf16 else None          # bf16 storage: bf16 operands for the stem conv too (fp32 in memory)
+        # bf16 storage: the training step, and (round 3) inference under torch.no_grad() -- the offline pseudo-label pass and
+        # evaluation; an eval-mode forward that records a graph stays fp32
+        bf16 = self.storage == "bf16" and (self.training or not torch.is_grad_enabled())
+        blocks.StemFn.prec = "bf16" if (bf16 and self.training) else None   # bf16 operands for the stem conv in training (fp32 in memory)
         try:
             y = blocks.StemFn.apply(x, r, *params)
         finally:
