@@ -307,6 +307,7 @@ def main():
                     help="bf16: activations / weight copies of the encoder stored in bf16, bf16 matrix cores (BASELINE config 5)")
     ap.add_argument("--no-other-precisions", action="store_true",
                     help="skip the short extra legs that time the same step in the opt-in operand precisions (N=1 only)")
+    ap.add_argument("--no-hipgraph", action="store_true", help="skip the short leg that replays the step as one hipGraph (N=1 only)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configurations (bf16 storage, PPM head, R101 1024^2; N=1 only)")
     args = ap.parse_args()
@@ -431,6 +432,39 @@ def main():
             note(f"other precision {prec}: {others[prec]}")
         ops.set_conv_precision(args.conv_prec)
 
+    graph_leg = None
+    if world == 1 and wrapper is None and not args.no_hipgraph:           # (the data-parallel step holds RCCL calls: not captured)
+        # the same step captured in ONE hipGraph and replayed (uemda_amd.step.GraphedStep): device time per step and what the host
+        # spends per step; `value` above stays the eager run
+        try:
+            from uemda_amd.step import GraphedStep, ssl_step as _ssl, src_step as _src
+            kw = dict(sup_ignore_id=s.sup_ignore) if args.workload == "ssl" else {}
+            gs = GraphedStep(_ssl if args.workload == "ssl" else _src, model, aligner if args.workload == "ssl" else None, s.opt, s.state,
+                             s.batch, warmup=1, lr=s.lr_at(args.warmup + args.steps), **kw)
+            gs(s.lr_at(args.warmup + args.steps))
+            barrier()
+            t1 = time.perf_counter()
+            nrep = 5
+            for i in range(nrep):
+                gs(s.lr_at(args.warmup + args.steps + 1 + i))
+            t_host = (time.perf_counter() - t1) / nrep
+            barrier()
+            dt = (time.perf_counter() - t1) / nrep
+            gs.check()
+            graph_leg = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=nrep,
+                             host_ms_per_step=round(1e3 * t_host, 3),
+                             note="the whole step (2 forwards, mining, losses, backward, clip + SGD) as ONE hipGraph launch per step; lr "
+                                  "travels as a device scalar")
+            del gs
+            s.opt.lr_device = None
+            gc.collect()
+            torch.cuda.empty_cache()
+        except Exception as e:                    # noqa: BLE001  (an extra leg must never cost the headline line)
+            graph_leg = dict(error=repr(e)[:300])
+            s.opt.lr_device = None
+        if rank == 0:
+            note(f"hipGraph replay: {graph_leg}")
+
     peak = BF16_MATRIX_PEAK_TFLOPS if (args.conv_prec == "bf16" or args.storage == "bf16") else F32_MATRIX_PEAK_TFLOPS
     prec_text = {"fp32": "fp32 (f32 MFMA)", "bf16x3": "fp32 storage, 3xbf16 split MFMA with fp32 accumulate",
                  "mixed": "fp32 (f32 MFMA) forward, 3xbf16 split MFMA data/weight gradients",
@@ -494,6 +528,8 @@ def main():
                                  "alloc_retries": int(ms.get("num_alloc_retries", 0))}
         if others:
             line["other_precisions"] = others
+        if graph_leg:
+            line["hipgraph"] = graph_leg
     if args.dump_params:
         arena, _, n = model.flat_parameters()
         with open(f"{args.dump_params}.rank{rank}", "w") as f:

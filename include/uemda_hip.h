@@ -327,7 +327,8 @@ int uem_negate(const float* a, float* b, int n, void* stream);
 int uem_grad_sqnorm(const float* grad, int64_t n, float* partial, float* norm_out, void* stream);
 int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n, const float* norm /* device */,
                       float max_norm, float lr, float momentum, float weight_decay, int first_step,
-                      float grad_prescale, void* stream);
+                      float grad_prescale, const float* lr_dev /* NULL, or the learning rate as a device scalar (overrides lr):
+                      what a step captured in a hipGraph needs, by-value arguments being baked into the capture */, void* stream);
 
 /* ---- bf16 STORAGE (BASELINE config 5: "bf16 weights, CDNA4 bf16 MFMA") -------------------------------------------
  * Activations and weights bf16 in HBM (uint16_t = the raw bf16 bits, NHWC / OHWI as above), fp32 accumulation on

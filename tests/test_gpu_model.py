@@ -560,6 +560,48 @@ def test_reference_optimizer_lines_torch_sgd_and_clip_grad_norm_on_the_arena_mod
     assert (p1.cpu() - out["pred_s1"].cpu()).abs().max() > 1e-4          # and they did move
 
 
+def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate():
+    """the whole train_ssl_uem step captured in one hipGraph (uemda_amd.step.GraphedStep) must BE the eager step.
+    Before each of three replays -- with a learning rate that changes 10x from step to step, so that a rate baked into the capture
+    would show -- the complete training state (weights, BatchNorm buffers, momentum, prototypes) is copied into a second model that
+    takes the same step eagerly: same losses, same hard labels, same updated weights to fp32-atomic order.  (Whole trajectories
+    cannot be compared on this network: two EAGER runs of it drift apart by 4e-4 in the loss within three steps.)"""
+    from oracle import synth
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, GraphedStep, StepState, ssl_step
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
+
+    def fresh():
+        model = _model(False)
+        al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+        al.prototypes = batch["prototypes"].clone()
+        return model, al, FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4), StepState(C)
+    m1, a1, o1, s1 = fresh()
+    gs = GraphedStep(ssl_step, m1, a1, o1, s1, batch, warmup=2, lr=1e-3, sup_ignore_id=256)      # 2 eager warm-up steps, then the capture
+    m2, a2, o2, s2 = fresh()
+    for lr in (3e-3, 3e-4, 3e-2):
+        m2.load_state_dict({k: v.detach().clone() for k, v in m1.state_dict().items()})
+        o2.momentum_buffer.copy_(o1.momentum_buffer)
+        o2._steps = o1._steps
+        a2.prototypes = a1.prototypes.clone()
+        n = m1.flat_parameters()[2]
+        w_before = m1.flat_parameters()[0][:n].clone()
+        out = gs(lr)
+        ref = ssl_step(m2, a2, o2, s2, batch, lr, sup_ignore_id=256)
+        torch.cuda.synchronize()
+        assert float(out["loss_source"]) == pytest.approx(float(ref["loss_source"]), rel=2e-6)
+        assert float(out["loss_target"]) == pytest.approx(float(ref["loss_target"]), rel=2e-5, abs=1e-7)
+        assert torch.equal(out["label_t_hard"], ref["label_t_hard"])
+        assert float(out["grad_norm"]) == pytest.approx(float(ref["grad_norm"]), rel=1e-4)
+        w1, w2 = m1.flat_parameters()[0][:n], m2.flat_parameters()[0][:n]
+        moved = float((w1 - w_before).norm())
+        assert float((w1 - w2).norm()) < 2e-3 * moved, (float((w1 - w2).norm()), moved)            # the same update, at THIS learning rate
+        torch.testing.assert_close(a1.prototypes, a2.prototypes, rtol=1e-5, atol=1e-6)
+    gs.check()
+    assert int(m1.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == int(m2.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == 10
+
+
 @pytest.mark.parametrize("affine_trainable", [True, False])
 @pytest.mark.parametrize("shape", ["stride2_downsample", "stride1_downsample", "identity_dilated"])
 def test_bottleneck_eval_mode_batchnorm_backward_vs_torch(shape, affine_trainable):

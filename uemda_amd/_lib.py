@@ -126,7 +126,7 @@ SIGNATURES = {
     "uem_allreduce_flat": [P, P, L, P],
     "uem_comm_destroy": [P],
     "uem_grad_sqnorm": [P, L, P, P, P],
-    "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P],
+    "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P, P],
 }
 _RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64,
             "uem_label_refine_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64,

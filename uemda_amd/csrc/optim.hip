@@ -39,7 +39,11 @@ extern "C" int uem_grad_sqnorm(const float* grad, int64_t n, float* partial, flo
 
 __global__ __launch_bounds__(256) void sgd_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                        int64_t n, const float* __restrict__ norm, float max_norm, float lr,
-                                                       float momentum, float wd, int first, float prescale) {
+                                                       float momentum, float wd, int first, float prescale,
+                                                       const float* __restrict__ lr_dev) {
+    // lr_dev (optional): the learning rate as a DEVICE scalar -- a step captured in a hipGraph bakes by-value arguments in, the
+    // schedule then writes this word before every replay
+    if (lr_dev) lr = lr_dev[0];
     // clip coefficient exactly as torch.nn.utils.clip_grad_norm_: min(max_norm / (total_norm + 1e-6), 1)
     float coef = 1.0f;
     if (norm) { coef = max_norm / (norm[0] * prescale + 1e-6f); coef = coef > 1.0f ? 1.0f : coef; }
@@ -54,9 +58,10 @@ __global__ __launch_bounds__(256) void sgd_clip_kernel(float* __restrict__ p, fl
     }
 }
 extern "C" int uem_sgd_clip_step(float* param, float* grad, float* momentum_buf, int64_t n, const float* norm, float max_norm,
-                                 float lr, float momentum, float weight_decay, int first_step, float grad_prescale, void* stream) {
+                                 float lr, float momentum, float weight_decay, int first_step, float grad_prescale,
+                                 const float* lr_dev, void* stream) {
     UEM_REQUIRE(param && grad && momentum_buf && n > 0, "sgd_clip_step: bad arguments");
     sgd_clip_kernel<<<uem_stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(param, grad, momentum_buf, n, norm, max_norm, lr,
-                                                                             momentum, weight_decay, first_step, grad_prescale);
+                                                                             momentum, weight_decay, first_step, grad_prescale, lr_dev);
     return uem_check_launch("sgd_clip_step");
 }

@@ -156,6 +156,11 @@ class Aligner:
         return S
 
     def _report_superpixel_range(self, oor, S):
+        if torch.cuda.is_current_stream_capturing():
+            # under hipGraph capture no event of ours may be recorded and nothing may be read on the host: the flag stays on the
+            # device (`last_superpixel_range_flag`) for the caller to look at after a replay
+            self.last_superpixel_range_flag, self._oor_pending = oor, None
+            return
         host = torch.empty((), dtype=torch.int32, pin_memory=True)
         host.copy_(oor, non_blocking=True)
         ev = torch.cuda.Event()

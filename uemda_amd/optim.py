@@ -68,6 +68,10 @@ class FusedSGD(torch.optim.Optimizer):
                 runs.append((off, cnt))
         return runs
 
+    # learning rate as a device scalar (None: by value from param_groups): set by uemda_amd.step.GraphedStep, whose captured
+    # optimizer launch would otherwise keep the learning rate of the capture
+    lr_device = None
+
     @torch.no_grad()
     def step(self, closure=None, max_norm=None, grad_prescale=1.0):
         g = self.param_groups[0]
@@ -81,6 +85,6 @@ class FusedSGD(torch.optim.Optimizer):
             # torch.optim.SGD skips a parameter whose .grad is None -- no weight decay, no momentum
             call("uem_sgd_clip_step", ptr(arena) + 4 * off, ptr(garena) + 4 * off, ptr(self.momentum_buffer) + 4 * off, cnt, ptr(norm),
                  float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(g["momentum"]),
-                 float(g["weight_decay"]), 1 if self._steps == 0 else 0, float(grad_prescale), stream())
+                 float(g["weight_decay"]), 1 if self._steps == 0 else 0, float(grad_prescale), ptr(self.lr_device), stream())
         self._steps += 1
         ops.weights_changed()
