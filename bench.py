@@ -301,6 +301,7 @@ def main():
                     "data-parallel test: the gradient rank r contributes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dump-conv-events", default=None, help="write the per-launch conv timings of the last timed step to this JSON file")
     ap.add_argument("--conv-prec", default="fp32", choices=["fp32", "mixed", "bf16x3", "bf16"],
                     help="matrix-core operand precision of the convolutions (fp32 = exact f32 MFMA, the parity default)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
@@ -407,6 +408,9 @@ def main():
     if rank == 0:
         note(f"headline: {value:.1f} tiles/s, {1e3 * elapsed / args.steps:.2f} ms/step")
     headline_prof = ops.PROF.summary()
+    if args.dump_conv_events and rank == 0:
+        with open(args.dump_conv_events, "w") as f:
+            json.dump(ops.PROF.per_call(), f)
     ops.PROF.records = []
 
     others = None

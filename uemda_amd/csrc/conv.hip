@@ -83,6 +83,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // EPI fixes the epilogue's options at compile time where the launcher knows them (conv_dma_go): 0 = full dense tiles, plain
 // store; 1 = full dense tiles with BatchNorm tile statistics (forward) / the residual-tail and BatchNorm-backward options
 // (data gradient); -1 = everything tested at run time (bias, ragged tiles, strided rows, forward accumulate).
+#ifndef EPI_RB
+#define EPI_RB 8
+#endif
 template <int BN, int WM, int WN, int MODE, int EPI = -1>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                               const int m0, const int n0) {
@@ -133,14 +136,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                             stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
             }
             __syncthreads();
-            // global loads of the epilogue (the tensor being accumulated into, the z of the fused BatchNorm backward) are
-            // issued in batches of up to 4 rows before their consumers: written row by row they compiled to
-            // load - s_waitcnt vmcnt(0) - use, 8 to 16 serialised memory latencies per block
-            constexpr int NRP = 64 / RPP, RB = NRP < 4 ? NRP : 4;
+            // global loads of the epilogue (the tensor being accumulated into, its gate bits, the z of the fused BatchNorm backward
+            // and its mask bits) are issued together, in batches of EPI_RB rows, before their consumers: written row by row they
+            // compiled to load - s_waitcnt vmcnt(0) - use, 8 to 16 serialised memory latencies per block; with the z loads in a
+            // second loop behind the store loop (round 2) a half still waited four times, and on the residual tails of layer1-3 --
+            // three 4C-wide streams around a K <= 256 product -- the kernel moved bytes at 1.7-3.0 TB/s
+            constexpr int NRP = 64 / RPP, RBW = (MODE == 1 && EPI == 1) ? EPI_RB : 4, RB = NRP < RBW ? NRP : RBW;
+            float4 sc, sh, mu, is;
+            if (bnbwd_on) {
+                sc = *reinterpret_cast<const float4*>(p.bn_vec + n0 + sc4);
+                sh = *reinterpret_cast<const float4*>(p.bn_vec + p.Cout + n0 + sc4);
+                mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.Cout + n0 + sc4);
+                is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.Cout + n0 + sc4);
+            }
 #pragma unroll
             for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
-                float4 o[RB];
-                uint32_t ob[RB];
+                float4 o[RB], zz[RB];
+                uint32_t ob[RB], zb[RB];
                 if (acc_on) {
                     const float* const asrc = p.acc_src ? p.acc_src : p.y;
 #pragma unroll
@@ -148,6 +160,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                         const size_t off = row_off(m0 + hm * 64 + srow + (rp0 + u) * RPP) + n0 + sc4;
                         o[u] = *reinterpret_cast<const float4*>(asrc + off);
                         if (p.acc_bits) ob[u] = p.acc_bits[off >> 5] >> (off & 31);
+                    }
+                }
+                if (bnbwd_on) {                         // dense rows whenever bn_z is given
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const size_t off = (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4;
+                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + off);
+                        if (p.bn_bits) zb[u] = p.bn_bits[off >> 5] >> (off & 31);
                     }
                 }
 #pragma unroll
@@ -162,41 +182,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                             o[u].z = (m & 4u) ? o[u].z : 0.f; o[u].w = (m & 8u) ? o[u].w : 0.f;
                         }
                         v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w;
-                        // the fused BatchNorm reduction below works on the FINAL gradient
-                        if (bnbwd_on) *reinterpret_cast<float4*>(&stg[row * LDW + sc4]) = v;
                     }
                     *reinterpret_cast<float4*>(p.y + row_off(m0 + hm * 64 + row) + n0 + sc4) = v;
                     if (stats_on) {
                         bb.x += v.x; bb.y += v.y; bb.z += v.z; bb.w += v.w;
                         bg.x = fmaf(v.x, v.x, bg.x); bg.y = fmaf(v.y, v.y, bg.y); bg.z = fmaf(v.z, v.z, bg.z); bg.w = fmaf(v.w, v.w, bg.w);
                     }
-                }
-            }
-            if (bnbwd_on) {
-                // each thread owns 4 columns x (64/RPP) rows of this half: accumulate dbeta / dgamma partials
-                const float4 sc = *reinterpret_cast<const float4*>(p.bn_vec + n0 + sc4);
-                const float4 sh = *reinterpret_cast<const float4*>(p.bn_vec + p.Cout + n0 + sc4);
-                const float4 mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.Cout + n0 + sc4);
-                const float4 is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.Cout + n0 + sc4);
-#pragma unroll
-                for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
-                    float4 zz[RB];
-                    uint32_t zb[RB];
-#pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const size_t off = (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4;
-                        zz[u] = *reinterpret_cast<const float4*>(p.bn_z + off);
-                        if (p.bn_bits) zb[u] = p.bn_bits[off >> 5] >> (off & 31);
-                    }
-#pragma unroll
-                    for (int u = 0; u < RB; ++u) {
-                        const int row = srow + (rp0 + u) * RPP;
-                        const float4 d = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
+                    if (bnbwd_on) {
+                        // dbeta / dgamma partials of the BatchNorm(+ReLU) behind this tensor, over the FINAL gradient v: each
+                        // thread owns 4 columns x (64/RPP) rows of this half
                         const float4 z = zz[u];
                         bool kx, ky, kz, kw;
                         if (p.bn_bits) { const uint32_t m = zb[u]; kx = m & 1u; ky = m & 2u; kz = m & 4u; kw = m & 8u; }
                         else { kx = z.x * sc.x + sh.x > 0.f; ky = z.y * sc.y + sh.y > 0.f; kz = z.z * sc.z + sh.z > 0.f; kw = z.w * sc.w + sh.w > 0.f; }
-                        const float dx_ = kx ? d.x : 0.f, dy_ = ky ? d.y : 0.f, dz_ = kz ? d.z : 0.f, dw_ = kw ? d.w : 0.f;
+                        const float dx_ = kx ? v.x : 0.f, dy_ = ky ? v.y : 0.f, dz_ = kz ? v.z : 0.f, dw_ = kw ? v.w : 0.f;
                         bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
                         bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
                         bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
@@ -1249,7 +1248,12 @@ static int conv_dma_try(const ConvP& p, bool affine, hipStream_t st) {
     const double groups = p.wg_rows > 0 ? (double)uem_cdiv(p.M, p.wg_rows) : 1.0;
     const double xb = (double)p.N * p.H * p.W * p.x_ld * 4.0, wb = groups * (double)p.Cout * p.KH * p.KW * p.Cin * 4.0;
     if (xb >= 4294967280.0 || wb >= 4294967280.0) return 0;
-    const bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64;
+    // the residual tails (conv1 of a bottleneck backwards: K = C/4 channels in, C out, with the identity gradient and the previous
+    // bn3's reduction streaming through the epilogue) take 64-wide tiles: three resident blocks per CU instead of two cover each
+    // other's epilogues (layer1 0.51 -> 0.41 ms, layer2 0.33 -> 0.27, layer3 0.22 -> 0.19, layer4 0.65 -> 0.63:
+    // scripts/bench_dgrad_tail.py), and with K this small the second read of dy costs little
+    const bool wide_tail = MODE == 1 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout;
+    const bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64 && !(wide_tail && g_conv_dma_bn == 0);
     if constexpr (MODE != 2) {
         static const int penv = getenv("UEM_CONV_PERSIST") ? atoi(getenv("UEM_CONV_PERSIST")) : -1;
         const int pset = g_conv_persist >= 0 ? g_conv_persist : penv;

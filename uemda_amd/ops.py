@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import CONV_ACCUMULATE, CONV_IN_AFFINE, CONV_IN_RELU, CONV_TRANSPOSED, ConvShape, UemError, call
 
 import os
+import sys
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -85,13 +86,20 @@ class _Profiler:
         s.record()
         out = launch()
         e.record()
-        self.records.append((family, flops, s, e, flops if executed is None else executed))
+        fr = sys._getframe(1)
+        t = fr.f_locals.get("dy", fr.f_locals.get("x"))               # label for per_call(): calling op + its input's shape
+        who = fr.f_code.co_name + ("" if t is None else " " + "x".join(str(d) for d in t.shape))
+        self.records.append((family, flops, s, e, flops if executed is None else executed, who))
         return out
+
+    def per_call(self):
+        """[(family, calling op, algorithmic flops, executed flops, ms)] in launch order; call after torch.cuda.synchronize()."""
+        return [(fam, who, fl, ex, s.elapsed_time(e)) for fam, fl, s, e, ex, who in self.records]
 
     def summary(self):
         """family -> dict(launches, flops, executed, ms); call after torch.cuda.synchronize()."""
         agg = {}
-        for fam, fl, s, e, ex in self.records:
+        for fam, fl, s, e, ex, _ in self.records:
             a = agg.setdefault(fam, dict(launches=0, flops=0.0, executed=0.0, ms=0.0))
             a["launches"] += 1
             a["flops"] += fl
