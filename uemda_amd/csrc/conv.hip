@@ -2196,7 +2196,10 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
             }
             if (p.ntaps == 0 && p.accumulate) continue;
             p.M = s->N * p.Hs * p.Ws;
-            if (p.Cout % 128 == 0) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            // the residual tails on 64-wide tiles, as in the fp32 kernel (conv_dma_try): dgrad family 10.71 -> 10.38 ms per step; the
+            // forward's wide, small-K layers lose on them (8.48 -> 8.87 ms)
+            const bool wide_tail = (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout;
+            if (p.Cout % 128 == 0 && !wide_tail) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
             else conv_bf16_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);
         }
     }
