@@ -45,7 +45,7 @@ class BottleneckBf16Fn(Function):
         if blk.bn1.training:
             blk._nbt_add()
         if any(ctx.needs_input_grad):
-            ctx.blk, ctx.has_ds = blk, has_ds
+            ctx.blk, ctx.has_ds, ctx.training = blk, has_ds, st1.training
             saved = [x, bits, z1, a1, z2, a2, z3, _st_tensor(st1), _st_tensor(st2), _st_tensor(st3)]
             if has_ds:
                 saved += [zd, _st_tensor(std)]
@@ -53,8 +53,10 @@ class BottleneckBf16Fn(Function):
             # bn3's reduction pass rides in the next block's last data-gradient epilogue, the previous block's in ours
             # (blocks._Link, same protocol as the fp32 node)
             ctx.link_in = getattr(x, "_uem_link", None)
-            ctx.link_out = _Link(z3, bits, _st_tensor(st3))
-            y._uem_link = ctx.link_out
+            ctx.link_out = None
+            if st3.training:                        # frozen statistics (batchnorm_trainable=False): no reduction pass to hand on
+                ctx.link_out = _Link(z3, bits, _st_tensor(st3))
+                y._uem_link = ctx.link_out
         return y
 
     @staticmethod
@@ -62,7 +64,7 @@ class BottleneckBf16Fn(Function):
         blk = ctx.blk
         sv = ctx.saved_tensors
         x, bits, z1, a1, z2, a2, z3 = sv[:7]
-        st1, st2, st3 = (_st_from(b) for b in sv[7:10])
+        st1, st2, st3 = (_st_from(b, ctx.training) for b in sv[7:10])
         s, d = blk.stride, blk.dilation
         G, gb = grad_ohwi, grad_buffer
         dy = dy.contiguous()
@@ -95,7 +97,7 @@ class BottleneckBf16Fn(Function):
         bn_args = dict(bn_z=li.z3, bn_vec=li.vec, bn_bits=li.bits) if fuse else {}
         tp = None
         if ctx.has_ds:
-            zd, std = sv[10], _st_from(sv[11])
+            zd, std = sv[10], _st_from(sv[11], ctx.training)
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
             dzd = ob.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=2, bits=bits, dx=dy if own else None)
             ob.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s)

@@ -90,7 +90,7 @@ def conv2d_dgrad_bn_backward(dy, w_t, z, st, gamma_grad, beta_grad, stride=1, pa
     """dA = dgrad(dy) for the conv that consumed relu(bn(z)), then that BatchNorm+ReLU's backward -> dz (in dA's buffer); the
     reduction pass rides in the data-gradient epilogue when the conv has stride 1 and full tiles."""
     cin, kh, kw, cout = w_t.shape
-    if stride != 1 or not dgrad_tail_ok(z.shape, cin):
+    if stride != 1 or not dgrad_tail_ok(z.shape, cin) or not st.training:
         da = conv2d_dgrad(dy, w_t, z.shape, stride=stride, pad=pad, dil=dil)
         return bn_backward(z, da, st, gamma_grad, beta_grad, relu=1, dx=da)
     vec = st.scale._base
@@ -195,12 +195,9 @@ def conv2d_bn(x, w_b, bn, stride=1, pad=0, dil=1):
     ho, wo = conv_out_size(h, w_b.shape[1], stride, pad, dil), conv_out_size(w, w_b.shape[2], stride, pad, dil)
     M = n * ho * wo
     if not (bn.training or bn.running_mean is None):
-        # eval mode (round 3: the offline pseudo-label pass and evaluation are pure inference and gain the most from bf16
-        # storage): scale / shift from the running statistics, no statistics pass, any number of output pixels.  Inference only:
-        # a training graph through a frozen BatchNorm (batchnorm_trainable=False) stays on the fp32 storage path.
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise UemError("bf16 storage with eval-mode BatchNorm is an inference path (run it under torch.no_grad()); "
-                           "training through frozen BatchNorm statistics runs in fp32 storage")
+        # eval mode: scale / shift from the running statistics, no statistics pass, any number of output pixels -- the offline
+        # pseudo-label pass and evaluation under torch.no_grad(), and the frozen-statistics training graph of
+        # ResNetEncoder(batchnorm_trainable=False) (reference resnet.py:112-117,183-190), whose backward is bn_backward below
         z = conv2d(x, w_b, stride=stride, pad=pad, dil=dil)
         return z, ops.bn_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, False, bn.eps)
     if M % 128 != 0:
@@ -232,9 +229,15 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, relu, bits=None, want_dres=Fal
     C = x.shape[-1]
     M = x.numel() // C
     tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
-    ws = torch.empty(ops._lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
-    call("uem_bn_bwd_reduce_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), M, C,
-         int(relu), ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws), stream())
+    if st.training or gamma_grad is not None or beta_grad is not None:
+        ws = torch.empty(ops._lib.load().uem_bn_workspace_floats(M, C), device=x.device, dtype=torch.float32)
+        call("uem_bn_bwd_reduce_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd), M, C,
+             int(relu), ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws), stream())
+    if not st.training:
+        # frozen statistics (eval-mode BatchNorm inside a training graph): y = x*scale + shift with constant scale / shift, so
+        # dx = dp*scale -- the apply pass with both batch sums zero; gamma / beta, when still trainable, took sum dp*xhat / sum dp
+        # (xhat from the running statistics) in the reduce above
+        tmp.zero_()
     dx = torch.empty_like(x) if dx is None else dx
     dres = torch.empty_like(x) if want_dres else None
     call("uem_bn_bwd_apply_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),

@@ -171,8 +171,6 @@ class ResNetEncoder(nn.Module):
                 t = blk(t)
             return t
         if with_cp and y.requires_grad:
-            if y.dtype != torch.float32:
-                raise UemError("with_cp runs on the fp32 storage path")
             import torch.utils.checkpoint as cp
             return cp.checkpoint(run, y, use_reentrant=True)
         for blk in layer:
