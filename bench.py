@@ -252,6 +252,36 @@ def roofline_of(prof, peak, traffic_for=None):
                          "(algorithmic / 2.25 on those layers) and is what the matrix pipe's utilisation is")
 
 
+def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
+    """The same step captured in ONE hipGraph and replayed (uemda_amd.step.GraphedStep): device time per step and what the host
+    spends per step.  An extra leg: never the headline `value`, and never allowed to cost the line."""
+    try:
+        from uemda_amd.step import GraphedStep, ssl_step as _ssl, src_step as _src
+        kw = dict(sup_ignore_id=s.sup_ignore) if workload == "ssl" else {}
+        gs = GraphedStep(_ssl if workload == "ssl" else _src, s.model, s.aligner if workload == "ssl" else None, s.opt, s.state,
+                         s.batch, warmup=1, lr=s.lr_at(step0), **kw)
+        gs(s.lr_at(step0))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nrep):
+            gs(s.lr_at(step0 + 1 + i))
+        t_host = (time.perf_counter() - t1) / nrep
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / nrep
+        gs.check()
+        leg = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=nrep,
+                   host_ms_per_step=round(1e3 * t_host, 3),
+                   note="the whole step (2 forwards, mining, losses, backward, clip + SGD) as ONE hipGraph launch per step; lr "
+                        "travels as a device scalar")
+        del gs
+    except Exception as e:                    # noqa: BLE001
+        leg = dict(error=repr(e)[:300])
+    s.opt.lr_device = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    return leg
+
+
 def short_leg(cfg, steps=3, warmup=2):
     """One of the `other_configs`: fresh model, `warmup` untimed + `steps` timed steps, per-launch events on the last one."""
     from uemda_amd import ops
@@ -276,6 +306,8 @@ def short_leg(cfg, steps=3, warmup=2):
                roofline=roofline_of(ops.PROF.summary(), BF16_MATRIX_PEAK_TFLOPS if bf16 else F32_MATRIX_PEAK_TFLOPS),
                peak_allocated_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     ops.PROF.records = []
+    if cfg.storage == "bf16" and cfg.size <= 512 and not getattr(cfg, "no_hipgraph", False):
+        out["hipgraph"] = replay_leg(s, cfg.workload, warmup + steps, s.tiles_per_step)     # where the host's share was largest (16 of 45 ms)
     del s
     gc.collect()
     torch.cuda.empty_cache()
@@ -438,34 +470,7 @@ def main():
 
     graph_leg = None
     if world == 1 and wrapper is None and not args.no_hipgraph:           # (the data-parallel step holds RCCL calls: not captured)
-        # the same step captured in ONE hipGraph and replayed (uemda_amd.step.GraphedStep): device time per step and what the host
-        # spends per step; `value` above stays the eager run
-        try:
-            from uemda_amd.step import GraphedStep, ssl_step as _ssl, src_step as _src
-            kw = dict(sup_ignore_id=s.sup_ignore) if args.workload == "ssl" else {}
-            gs = GraphedStep(_ssl if args.workload == "ssl" else _src, model, aligner if args.workload == "ssl" else None, s.opt, s.state,
-                             s.batch, warmup=1, lr=s.lr_at(args.warmup + args.steps), **kw)
-            gs(s.lr_at(args.warmup + args.steps))
-            barrier()
-            t1 = time.perf_counter()
-            nrep = 5
-            for i in range(nrep):
-                gs(s.lr_at(args.warmup + args.steps + 1 + i))
-            t_host = (time.perf_counter() - t1) / nrep
-            barrier()
-            dt = (time.perf_counter() - t1) / nrep
-            gs.check()
-            graph_leg = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=nrep,
-                             host_ms_per_step=round(1e3 * t_host, 3),
-                             note="the whole step (2 forwards, mining, losses, backward, clip + SGD) as ONE hipGraph launch per step; lr "
-                                  "travels as a device scalar")
-            del gs
-            s.opt.lr_device = None
-            gc.collect()
-            torch.cuda.empty_cache()
-        except Exception as e:                    # noqa: BLE001  (an extra leg must never cost the headline line)
-            graph_leg = dict(error=repr(e)[:300])
-            s.opt.lr_device = None
+        graph_leg = replay_leg(s, args.workload, args.warmup + args.steps, tiles_per_step)
         if rank == 0:
             note(f"hipGraph replay: {graph_leg}")
 

@@ -560,7 +560,8 @@ def test_reference_optimizer_lines_torch_sgd_and_clip_grad_norm_on_the_arena_mod
     assert (p1.cpu() - out["pred_s1"].cpu()).abs().max() > 1e-4          # and they did move
 
 
-def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate():
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage):
     """the whole train_ssl_uem step captured in one hipGraph (uemda_amd.step.GraphedStep) must BE the eager step.
     Before each of three replays -- with a learning rate that changes 10x from step to step, so that a rate baked into the capture
     would show -- the complete training state (weights, BatchNorm buffers, momentum, prototypes) is copied into a second model that
@@ -573,7 +574,7 @@ def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate():
     batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
 
     def fresh():
-        model = _model(False)
+        model = _model(False).set_storage(storage)                      # (bf16 storage: the 45 ms step, where the host's share was largest)
         al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
         al.prototypes = batch["prototypes"].clone()
         return model, al, FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4), StepState(C)
