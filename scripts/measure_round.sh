@@ -11,7 +11,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 STEPS=3
-ARGS="--steps $STEPS --warmup 2 --no-cpu-baseline --no-other-precisions --no-other-configs"
+ARGS="--steps $STEPS --warmup 2 --no-cpu-baseline --no-other-precisions --no-other-configs --no-hipgraph"
 echo "[measure] bench"; timeout -k 10 600 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || exit 1
 echo "[measure] kernel trace"; timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o step -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1
 python3 scripts/kernel_stats.py "$(find "$OUT/trace" -name '*.db' | head -1)" > "$OUT/kernel_stats.csv"
