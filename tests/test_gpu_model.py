@@ -600,6 +600,11 @@ def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage
         assert float((w1 - w2).norm()) < 2e-3 * moved, (float((w1 - w2).norm()), moved)            # the same update, at THIS learning rate
         torch.testing.assert_close(a1.prototypes, a2.prototypes, rtol=1e-5, atol=1e-6)
     gs.check()
+    if storage == "fp32":
+        from uemda_amd.ops import UemError
+        ppm = _model(True)                                              # Dropout2d(0.1) in the heads: the mask seed is a launch argument
+        with pytest.raises(UemError, match="Dropout2d"):
+            GraphedStep(ssl_step, ppm, a2, FusedSGD(ppm, lr=1e-2, momentum=0.9, weight_decay=5e-4), StepState(C), batch, sup_ignore_id=256)
     assert int(m1.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == int(m2.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == 10
 
 
