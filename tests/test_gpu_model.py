@@ -601,10 +601,19 @@ def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage
         torch.testing.assert_close(a1.prototypes, a2.prototypes, rtol=1e-5, atol=1e-6)
     gs.check()
     if storage == "fp32":
-        from uemda_amd.ops import UemError
-        ppm = _model(True)                                              # Dropout2d(0.1) in the heads: the mask seed is a launch argument
-        with pytest.raises(UemError, match="Dropout2d"):
-            GraphedStep(ssl_step, ppm, a2, FusedSGD(ppm, lr=1e-2, momentum=0.9, weight_decay=5e-4), StepState(C), batch, sup_ignore_id=256)
+        # PPM heads: Dropout2d(0.1).  A host-side seed would be frozen into the captured launch; while capturing the mask comes from
+        # torch's graph-safe generator instead: with the learning rate at 0 and no momentum the weights stand still, so two replays
+        # differ through their masks only -- and must differ.
+        ppm = _model(True)
+        ap = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+        ap.prototypes = batch["prototypes"].clone()
+        gp = GraphedStep(ssl_step, ppm, ap, FusedSGD(ppm, lr=0.0, momentum=0.0, weight_decay=0.0), StepState(C), batch, warmup=1, lr=0.0,
+                         sup_ignore_id=256)
+        p1 = gp(0.0)["pred_s1"].clone()
+        p2 = gp(0.0)["pred_s1"].clone()
+        p3 = gp(0.0)["pred_s1"].clone()
+        assert torch.isfinite(p1).all() and not torch.equal(p1, p2) and not torch.equal(p2, p3)
+        assert float((p1 - p2).norm() / p1.norm()) < 0.5            # a tenth of the channels moved, not the prediction as a whole
     assert int(m1.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == int(m2.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == 10
 
 

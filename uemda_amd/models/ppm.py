@@ -118,9 +118,16 @@ class PPMHeadFn(Function):
         a = ops.affine_act(zc, stc, relu=True)
         mask = None
         if training and drop.p > 0:
-            mask = torch.empty((n, 512), device=feat.device, dtype=torch.float32)
-            seed = dropout_seed(next(_drop_counter))
-            call("uem_dropout2d", ptr(a), ptr(a), ptr(mask), n, h * w, 512, float(drop.p), seed, stream())
+            if torch.cuda.is_current_stream_capturing():
+                # inside a hipGraph capture (step.GraphedStep) a host-side seed would be frozen into the launch and every replay
+                # would draw the same mask: torch's generator is graph-safe (its Philox offset advances per replay), so the
+                # per-(image, channel) keep mask comes from it and the kernel only applies it (seed 0 = mask given)
+                mask = (torch.rand((n, 512), device=feat.device) >= drop.p).to(torch.float32).mul_(1.0 / (1.0 - drop.p))
+                call("uem_dropout2d", ptr(a), ptr(a), ptr(mask), n, h * w, 512, 0.0, 0, stream())
+            else:
+                mask = torch.empty((n, 512), device=feat.device, dtype=torch.float32)
+                seed = dropout_seed(next(_drop_counter))
+                call("uem_dropout2d", ptr(a), ptr(a), ptr(mask), n, h * w, 512, float(drop.p), seed, stream())
         C = conv4.weight.shape[0]
         w4 = torch.zeros((32, 1, 1, 512), device=feat.device, dtype=torch.float32)
         w4[:C].copy_(ops.weight_ohwi(conv4.weight))

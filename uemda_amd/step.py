@@ -131,8 +131,8 @@ class GraphedStep:
     Requirements: inputs are the same device tensors every step (copy new data INTO `batch`), single process (the gradient
     collective is not captured), FusedSGD, at least one optimizer step taken before (the first step initialises the momentum buffer
     through a by-value flag).  The superpixel-table overflow flag stays on the device while capturing
-    (`aligner.last_superpixel_range_flag`); `check()` reads it (a host sync: call it now and then, not every step).  Models with an
-    active Dropout2d (the PPM heads) are refused: their mask seed is a host-side launch argument."""
+    (`aligner.last_superpixel_range_flag`); `check()` reads it (a host sync: call it now and then, not every step).  The PPM heads'
+    Dropout2d draws its masks from torch's graph-safe generator while capturing (models/ppm.py), a fresh mask per replay."""
 
     def __init__(self, step_fn, model, aligner, optimizer, state, batch, warmup=2, lr=1e-3, **kw):
         import torch
@@ -142,11 +142,6 @@ class GraphedStep:
             raise UemError("GraphedStep needs uemda_amd.optim.FusedSGD (the learning rate travels as a device scalar)")
         if kw.get("dp") is not None:
             raise UemError("GraphedStep captures a single-process step (the gradient all-reduce is not captured)")
-        if any(isinstance(m, torch.nn.Dropout2d) and m.p > 0 for m in model.modules()) and model.training:
-            # the Dropout2d seed of the PPM heads is a launch argument drawn on the host per call (models/ppm.py::dropout_seed):
-            # a replay would draw the captured step's mask again, every step
-            raise UemError("GraphedStep: this model draws Dropout2d masks (PPM heads) from a host-side seed, which a captured step "
-                           "would freeze; run it eagerly (it is device-bound) or set the heads' Dropout2d p to 0")
         self.aligner, self.optimizer = aligner, optimizer
         self.lr = torch.full((1,), float(lr), device=next(model.parameters()).device, dtype=torch.float32)
         optimizer.lr_device = self.lr
