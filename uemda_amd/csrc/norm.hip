@@ -372,7 +372,7 @@ extern "C" int uem_affine_act(const float* x, const float* scale, const float* s
     UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act: relu_bits needs C %% 32 == 0 (C=%d)", C);
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act: bad residual affine");
     const int64_t nvec = M * C / 4;
-    affine_act_kernel<float><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    affine_act_kernel<float><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     return uem_check_launch("affine_act");
 }
 extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* res,
@@ -383,12 +383,12 @@ extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const 
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act_bf16: bad residual affine");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {       // with bits: C % 32 == 0, whole lane quads
         const int64_t nvec8 = M * C / 8;
-        affine_act_bf16x8_kernel<<<uem_stream_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y,
+        affine_act_bf16x8_kernel<<<uem_flat_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y,
                                                                                                nvec8, C, relu, relu_bits);
         return uem_check_launch("affine_act_bf16");
     }
     const int64_t nvec = M * C / 4;
-    affine_act_kernel<bf16_t><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    affine_act_kernel<bf16_t><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     return uem_check_launch("affine_act_bf16");
 }
 
@@ -616,7 +616,7 @@ extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* yma
     UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad shape");
     UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "bn_bwd_apply: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = (int64_t)M * C / 4;
-    bn_bwd_apply_kernel<float><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
+    bn_bwd_apply_kernel<float><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
         x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
     return uem_check_launch("bn_bwd_apply");
 }
@@ -628,12 +628,12 @@ extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, cons
     UEM_REQUIRE(relu == 0 || (relu == 1 && !relu_bits) || (relu == UEM_RELU_BITS && relu_bits && C % 32 == 0), "bn_bwd_apply_bf16: bad relu mode");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0) {
         const int64_t nvec8 = (int64_t)M * C / 8;
-        bn_bwd_apply_bf16x8_kernel<<<uem_stream_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(
+        bn_bwd_apply_bf16x8_kernel<<<uem_flat_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(
             x, dy, relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec8, C, 1.0f / (float)M, relu, dx, dres);
         return uem_check_launch("bn_bwd_apply_bf16");
     }
     const int64_t nvec = (int64_t)M * C / 4;
-    bn_bwd_apply_kernel<bf16_t><<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
+    bn_bwd_apply_kernel<bf16_t><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
         x, dy, (const float*)relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
     return uem_check_launch("bn_bwd_apply_bf16");
 }
@@ -799,12 +799,12 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
 }
 extern "C" int uem_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
     UEM_REQUIRE(x && y && n > 0 && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 7) == 0), "cast_f32_bf16: bad arguments");
-    cast_f32_bf16_kernel<<<uem_stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, n);
+    cast_f32_bf16_kernel<<<uem_flat_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, n);
     return uem_check_launch("cast_f32_bf16");
 }
 extern "C" int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream) {
     UEM_REQUIRE(x && y && n > 0 && (((uintptr_t)x & 7) == 0) && (((uintptr_t)y & 15) == 0), "cast_bf16_f32: bad arguments");
-    cast_bf16_f32_kernel<<<uem_stream_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, n);
+    cast_bf16_f32_kernel<<<uem_flat_grid(n / 4 + 1, 256), 256, 0, (hipStream_t)stream>>>(x, y, n / 4, n);
     return uem_check_launch("cast_bf16_f32");
 }
 __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -827,7 +827,7 @@ extern "C" int uem_affine_act_bwd(const float* x, const float* dy, const float* 
     UEM_REQUIRE(x && dy && scale && shift && dx && M > 0 && C > 0 && (C % 4) == 0, "affine_act_bwd: bad arguments");
     UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "affine_act_bwd: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = M * C / 4;
-    affine_act_bwd_kernel<<<uem_stream_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, dy, ymask, scale, shift, nvec, C, relu, dx, dres);
+    affine_act_bwd_kernel<<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, dy, ymask, scale, shift, nvec, C, relu, dx, dres);
     return uem_check_launch("affine_act_bwd");
 }
 
@@ -883,7 +883,7 @@ extern "C" int uem_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int 
     UEM_REQUIRE(x && y && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_fwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
-    maxpool_fwd_kernel<false><<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, nullptr, nullptr, y, idx, N, H, W, C, Ho, Wo);
+    maxpool_fwd_kernel<false><<<uem_flat_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, nullptr, nullptr, y, idx, N, H, W, C, Ho, Wo);
     return uem_check_launch("maxpool_fwd");
 }
 extern "C" int uem_maxpool3x3s2_affine_fwd(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, int N, int H,
@@ -891,7 +891,7 @@ extern "C" int uem_maxpool3x3s2_affine_fwd(const float* x, const float* scale, c
     UEM_REQUIRE(x && scale && shift && y && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_affine_fwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
-    maxpool_fwd_kernel<true><<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, idx, N, H, W, C, Ho, Wo);
+    maxpool_fwd_kernel<true><<<uem_flat_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, idx, N, H, W, C, Ho, Wo);
     return uem_check_launch("maxpool_affine_fwd");
 }
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
@@ -913,7 +913,7 @@ extern "C" int uem_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* 
     UEM_REQUIRE(dy && idx && dx && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_bwd: bad arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int64_t total = (int64_t)N * H * W * (C / 4);
-    maxpool_bwd_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dy, idx, dx, N, H, W, C, Ho, Wo);
+    maxpool_bwd_kernel<<<uem_flat_grid(total, 256), 256, 0, (hipStream_t)stream>>>(dy, idx, dx, N, H, W, C, Ho, Wo);
     return uem_check_launch("maxpool_bwd");
 }
 
@@ -1286,7 +1286,7 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
 }
 extern "C" int uem_add_inplace(float* a, const float* b, int64_t n, void* stream) {
     UEM_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
-    add_inplace_kernel<<<uem_stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n);
+    add_inplace_kernel<<<uem_flat_grid(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n);
     return uem_check_launch("add_inplace");
 }
 
