@@ -374,32 +374,34 @@ int uem_weight_transpose_bf16(const float* w /* [Cout][KH][KW][Cin] fp32 master 
 int uem_cast_f32_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream);
 
-/* ---- Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the deep layers (csrc/winograd.hip) ---------------------
+/* ---- Winograd F(2x2, 3x3) and F(4x4, 3x3) for the stride-1 3x3 convolutions of the deep layers (csrc/winograd.hip) ------
  * Same cuDNN call sites as uem_conv2d_fwd for the 3x3 convs (reference uemda/_resnets.py:100-103 -- conv2 of a Bottleneck,
- * dilation 1 or 2 under output stride 16 -- and Encoder.py:35, the PPM head's 4096 -> 512 conv).  Exact fp32, 2.25x fewer
- * multiplies: Y = A^T [(G g G^T) (.) (B^T d B)] A.  Transform-domain tensors are [16][T][C] fp32, T = N * H * W / 4 tiles of 2x2
- * outputs (dilation d: tiles of the d*d interleaved sub-images).  Needs H, W % (2*dil) == 0, C % 64 == 0, T % 32 == 0.
- *   uem_wino_filter      U[16][Cout][Cin] = G w G^T from w (Cout,3,3,Cin); transposed != 0: U'[16][Cin][Cout] of the flipped taps,
- *                        the filter bank of the data gradient dX = conv(dY, W'), W'[ci][ky][kx][co] = W[co][2-ky][2-kx][ci]
+ * dilation 1 or 2 under output stride 16 -- and Encoder.py:35, the PPM head's 4096 -> 512 conv).  Exact fp32 arithmetic:
+ * Y = A^T [(G g G^T) (.) (B^T d B)] A.  `m` is the output tile edge: 2 = F(2x2,3x3), 16 positions, 2.25x fewer multiplies, 4e-7
+ * relative L2 against float64; 4 = F(4x4,3x3) on the points (0, 1, -1, 1/2, -2, inf), 36 positions, 4x fewer multiplies, 1.4e-6.
+ * Transform-domain tensors are [npos][T][C] fp32, npos = (m+2)^2, T = N * H * W / m^2 tiles (dilation d: tiles of the d*d
+ * interleaved sub-images).  Needs H, W % (m*dil) == 0, C % 64 == 0, T % 32 == 0 (the GEMMs: T % 128 == 0).
+ *   uem_wino_filter      U[npos][Cout][Cin] = G w G^T from w (Cout,3,3,Cin); transposed != 0: U'[npos][Cin][Cout] of the flipped
+ *                        taps, the filter bank of the data gradient dX = conv(dY, W'), W'[ci][ky][kx][co] = W[co][2-ky][2-kx][ci]
  *   uem_wino_input       V = B^T d B of x (N,H,W,C), optionally through relu(x*in_scale + in_shift) first (the producer's
  *                        BatchNorm, as the conv kernels' operand prologue; zero padding applies AFTER it)
- *   uem_wino_gemm        M[16][T][N] = V[16][T][K] x U[16][N][K]^T: the 16 products as one launch of the f32-MFMA 1x1 kernel
+ *   uem_wino_gemm        M[npos][T][N] = V[npos][T][K] x U[npos][N][K]^T: the npos products as one launch of the f32-MFMA 1x1 kernel
  *   uem_wino_output      y (N,H,W,C) = A^T M A; tile_stats [2][C][N*H*W/128]: per-128-pixel sums of y and y*y (forward; for
  *                        uem_bn_stats_from_tiles), OR bn_z / bn_vec (4,C) / tile_bnbwd [2][C][N*H*W/128]: per-group sums of
  *                        dp = y*[bn_z*scale + shift > 0] and dp*xhat (data gradient; for uem_bn_bwd_from_tiles); all may be NULL
- *   uem_wino_dy          dM[16][T][C] = A dY A^T (weight gradient)
- *   uem_wino_wgrad_gemm  dU[16][N][K] += sum_tiles dM[pos][tile][n] * V[pos][tile][k] (split-K fp32 atomics: zero dU first)
+ *   uem_wino_dy          dM[npos][T][C] = A dY A^T (weight gradient)
+ *   uem_wino_wgrad_gemm  dU[npos][N][K] += sum_tiles dM[pos][tile][n] * V[pos][tile][k] (split-K fp32 atomics: zero dU first)
  *   uem_wino_filter_grad dw (Cout,3,3,Cin) += G^T dU G                                                                   */
-int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, void* stream);
+int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, int m, void* stream);
 int uem_wino_input(const float* x, const float* in_scale, const float* in_shift, int relu, float* V, int N, int H, int W, int C,
-                   int dil, void* stream);
-int uem_wino_gemm(const float* V, const float* U, float* M, int T, int K, int N, int data_gradient /* 0 forward, 1: the same product
-                  through the data-gradient kernel instantiation */, void* stream);
-int uem_wino_output(const float* M, float* y, int N, int H, int W, int C, int dil, float* tile_stats, const float* bn_z,
+                   int dil, int m, void* stream);
+int uem_wino_gemm(const float* V, const float* U, float* M, int T, int K, int N, int npos /* 16 or 36 */,
+                  int data_gradient /* 0 forward, 1: the same product through the data-gradient kernel instantiation */, void* stream);
+int uem_wino_output(const float* M, float* y, int N, int H, int W, int C, int dil, int m, float* tile_stats, const float* bn_z,
                     const float* bn_vec, float* tile_bnbwd, void* stream);
-int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, void* stream);
-int uem_wino_wgrad_gemm(const float* V, const float* dM, float* dU, int T, int K, int N, void* stream);
-int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, void* stream);
+int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, int m, void* stream);
+int uem_wino_wgrad_gemm(const float* V, const float* dM, float* dU, int T, int K, int N, int npos, void* stream);
+int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, int m, void* stream);
 
 /* ---- data parallel (new relative to the reference, which is single-GPU: SURVEY 2a, 8e) --------------------------
  * all-reduce(sum, in place) of a flat fp32 buffer -- the gradient arena, 98 MB for R50-ASPP -- over RCCL on `stream`:

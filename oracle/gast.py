@@ -153,6 +153,19 @@ def update_prototype(feat, label, prototypes, n_classes, decay=0.996, ignore_lab
     return (1.0 - decay) * local + decay * prototypes, label_ds
 
 
+def update_avg(feat, label, data_sum, data_cnt, n_classes, ignore_label=-1):
+    """Aligner.update_avg (alignment.py:107-120; caller tools/init_prototypes.py:101-109): running per-class feature sums (c, k) and
+    pixel counts (c, 1) over the down-scaled labels -> (data_sum', data_cnt').  Pinned by tests/golden/aligner_avg.npz."""
+    label_ds = downscale_label(label, n_classes, 16, ignore_label, 0.75)
+    _, sums, n_c = local_prototypes(feat.detach(), label_ds, torch.zeros_like(data_sum), n_classes, ignore_label)
+    return data_sum + sums, data_cnt + n_c.unsqueeze(1)
+
+
+def init_avg(data_sum, data_cnt):
+    """Aligner.init_avg (alignment.py:122-123): prototypes = sum / (count + eps); an unseen class gets 0 / eps = 0."""
+    return data_sum / (data_cnt + EPS)
+
+
 # ------------------------------------------------------------------------------------------------
 # losses  (tools.py:240-260, balance.py:81-101, 345-457)
 # ------------------------------------------------------------------------------------------------

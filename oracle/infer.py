@@ -2,7 +2,9 @@
   pre_slide    reference uemda/utils/tools.py:61-97 (pinned by tests/golden/pre_slide.npz)
   tta_predict  reference tools.py:132-152 over `ttach` (third-party, absent: restated from its documented
                HorizontalFlip / Rotate90 semantics -- parity unpinned)
-  confusion / per-class metrics: uemda/utils/eval.py:41-50 + ever's PixelMetric (third-party, absent)."""
+  pseudo_prob_map   the `<fname>.pt` tensor of gener_target_pseudo, uemda/gast/pseudo_generation.py:128-136 (pinned, slide=False leg)
+  evaluate_pairs    what evaluate feeds the metric, uemda/utils/eval.py:39-47 (pinned by tests/golden/evaluate_pairs.npz)
+  confusion / per-class metrics: uemda/utils/eval.py:41-50 + ever's PixelMetric (third-party, absent: formulas unpinned)."""
 from math import ceil
 
 import numpy as np
@@ -39,6 +41,26 @@ def pre_slide(model, image, num_classes=7, tile_size=(512, 512), tta=False):
             full[:, :, y1:y2, x1:x2] += out[:, :, :y2 - y1, :x2 - x1]
             cnt[:, :, y1:y2, x1:x2] += 1
     return full / cnt
+
+
+def pseudo_prob_map(model, image, size, num_classes, slide=True, tta=True):
+    """The tensor gener_target_pseudo writes as `<fname>.pt` with save_prob=True (uemda/gast/pseudo_generation.py:128-136): the
+    model's (sliding-window) probability map resized to `size` with bilinear align_corners=True, batch dimension squeezed.
+    Pinned by tests/golden/gener_pseudo.npz on the slide=False leg (the TTA leg needs `ttach`: unpinned)."""
+    with torch.no_grad():
+        cls = pre_slide(model, image, num_classes=num_classes, tta=tta) if slide else model(image)
+        return F.interpolate(cls, size, mode="bilinear", align_corners=True).squeeze(dim=0)
+
+
+def evaluate_pairs(model, image, gt, num_classes, slide=True, tta=False, tile_size=(512, 512)):
+    """What `evaluate` hands the metric for one batch (uemda/utils/eval.py:39-47): argmax of the (sliding-window) map and the labels,
+    both restricted to pixels with label >= 0 -> (y_true, y_pred) int arrays.  Pinned by tests/golden/evaluate_pairs.npz."""
+    with torch.no_grad():
+        cls = pre_slide(model, image, num_classes=num_classes, tile_size=tile_size, tta=tta) if slide else model(image)
+    pred = cls.argmax(dim=1).cpu().numpy()
+    g = gt.cpu().numpy().astype(np.int32)
+    mask = g >= 0
+    return g[mask].ravel(), pred[mask].ravel()
 
 
 def confusion(prob, gt, num_classes):

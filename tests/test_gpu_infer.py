@@ -155,3 +155,67 @@ def test_tta_d4_batched_equals_sequential(hw):
     torch.testing.assert_close(a, b, rtol=5e-5, atol=5e-6)
     assert (a.argmax(1) == b.argmax(1)).float().mean() > 0.9999
     assert ((a.sum(1) - 1).abs() < 1e-5).all()
+
+
+# ---------------- round 4: the "next" rows against outputs of the reference itself (tests/golden/make_golden_r4.py) ------------
+CLOSED_FORM_W = [[0.5, 1.0, 0.0], [-1.0, 0.0, 1.0], [0.25, 0.25, 0.25], [0.0, -0.75, 0.5], [1.0, -1.0, 0.3], [-0.2, 0.6, -0.9]]
+
+
+class ClosedFormModel(torch.nn.Module):
+    """the deterministic stand-in network of the inference fixtures: the caller's model, so plain torch on the device"""
+
+    def forward(self, x):
+        w = torch.tensor(CLOSED_FORM_W, dtype=x.dtype, device=x.device)
+        return torch.softmax(torch.einsum("kc,bchw->bkhw", w, x), dim=1)
+
+
+def test_aligner_update_avg_init_avg_reference_golden():
+    """Aligner.update_avg x2 + init_avg (reference uemda/gast/alignment.py:107-126) on the HIP path against the reference's own
+    running sums, counts and prototypes (an empty class, a class only the second batch sees)"""
+    from uemda_amd.gast.alignment import Aligner
+    g = load_golden("aligner_avg")
+    al = Aligner(None, 64, C, -1, 0.996)
+    for feat, lab in zip(g["feats"], g["labels"]):
+        al.update_avg(feat.cuda(), lab.cuda())
+    torch.testing.assert_close(al._data_sum.cpu(), g["data_sum"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(al._data_cnt.cpu().reshape(-1), g["data_cnt"].reshape(-1))
+    al.init_avg()
+    torch.testing.assert_close(al.prototypes.cpu(), g["prototypes"], rtol=1e-5, atol=1e-6)
+    assert float(al.prototypes[5].abs().max()) == 0.0
+
+
+def test_gener_target_pseudo_pt_file_reference_golden(tmp_path):
+    """gener_target_pseudo(slide=False, save_prob=True, size=...) writes the tensor the reference writes for the same model and
+    image (uemda/gast/pseudo_generation.py:128-136); the sliding-window map of a two-window image equals the reference's"""
+    from types import SimpleNamespace
+    from uemda_amd.gast.pseudo_generation import gener_target_pseudo
+    from uemda_amd.utils.tools import pre_slide
+    g = load_golden("gener_pseudo")
+    model = ClosedFormModel()
+    cfg = SimpleNamespace(DATASETS="IsprsDA", SNAPSHOT_DIR=None, CUTOFF_TOP=0.8, CUTOFF_LOW=0.6, PSEUDO_SELECT=True)
+    out_dir = os.path.join(str(tmp_path), "pseudo")
+    gener_target_pseudo(cfg, model, [(g["image"], {"fname": ["tile_a"]})], out_dir, slide=False, save_prob=True, size=(64, 96))
+    assert sorted(os.listdir(out_dir)) == ["tile_a.pt"]
+    saved = torch.load(os.path.join(out_dir, "tile_a.pt"))
+    assert saved.shape == (C, 64, 96) and saved.dtype == torch.float32 and not saved.is_cuda
+    torch.testing.assert_close(saved, g["pt_file"], rtol=1e-5, atol=1e-6)
+    slide = pre_slide(model, g["image2"].cuda(), num_classes=C, tile_size=(32, 32), tta=False)
+    torch.testing.assert_close(slide.cpu(), g["slide2"], rtol=1e-5, atol=1e-6)
+
+
+def test_evaluate_confusion_counts_reference_golden(monkeypatch):
+    """`evaluate` (uemda/utils/eval.py:14-56): the device argmax + confusion matrix holds exactly the (label, prediction) pairs the
+    reference's loop hands its metric; per-class formulas are `ever`'s and stay unpinned"""
+    import uemda_amd.utils.eval as ev
+    g = load_golden("evaluate_pairs")
+    orig = ev.pre_slide
+    monkeypatch.setattr(ev, "pre_slide", lambda m, x, num_classes, tta=False: orig(m, x, num_classes=num_classes, tile_size=(32, 32), tta=tta))
+    batches = [(g[f"image{k}"].cuda(), g[f"label{k}"].cuda()) for k in range(int(g["n_images"]))]
+    res, miou = ev.evaluate(ClosedFormModel(), batches, C, ignore_labels=[0], slide=True, tta=False)
+    assert np.array_equal(res["confusion"].astype(np.int64), g["confusion"].numpy())
+    # and per image: the prediction on the labelled pixels
+    for k, (img, lab) in enumerate(batches):
+        meter = ev.ConfusionMeter(C)
+        pred = meter.update(orig(ClosedFormModel(), img, num_classes=C, tile_size=(32, 32)), lab)
+        mask = lab.cpu().numpy() >= 0
+        assert np.array_equal(pred.cpu().numpy()[mask].ravel(), g[f"y_pred{k}"].numpy())

@@ -453,6 +453,48 @@ def test_full_model_aspp_ssl_step_matches_reference_golden(conv_precision):
     _check_updates(model, g, False)
 
 
+def test_full_model_aspp_ssl_step_b8_512_matches_reference_golden():
+    """The reference's own operating point: 8 source + 8 target tiles (configs/ToPotsdam.py:58, configs/st/uemda/2potsdam.py:31,43) of
+    512 x 512, the benchmark's tile -- where layer3 / layer4 run 32 x 32 maps (Winograd on 512 / 2048 tiles per conv, F(4x4,3x3) in the
+    backward pass), the persistent kernels walk several tiles per block and layer1 / layer2 take their large-map dispatch branches.
+    One train_ssl_uem step against the reference's outputs (tests/golden/make_golden_r4.py step512): north_star's bars on the
+    forward, every tensor's first update against ITS noise floor."""
+    from oracle import synth
+    from uemda_amd import ops
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    g = load_golden("model_aspp_r50_b8_512")
+    model = _model(False)
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=8, H=512, W=512, C=C, k=2048, seed=2333).items()}
+    plan = ops.wino_plan((8, 32, 32, 512), 512, 3, 3, 1, 2, 2)                    # the tile sizes this fixture exercises on layer4
+    assert (plan.mf, plan.mb) == (4 if ops.WINOGRAD_F4_FWD else 2, 4 if ops.WINOGRAD_F4_BWD else 2)
+    al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+    al.prototypes = batch["prototypes"].clone()
+    opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    out = ssl_step(model, al, opt, StepState(C), batch, float(g["lr"]))
+    worst = 0.0
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        ref = g[k]
+        err = float((out[k].cpu() - ref).abs().max() / ref.abs().max())
+        worst = max(worst, err)
+        assert err < 1e-3, (k, err)                      # north_star: fp logits within 1e-3 rel of the reference CPU path
+    agree = (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item()
+    print(f"512x512 B=8+8: worst logit error {worst:.2e} (the reference against itself: {float(g['ref_logit_floor']):.2e}), hard labels "
+          f"{agree:.6f} (reference against itself: {float(g['ref_hard_agreement_floor']):.6f})")
+    assert agree >= 0.9995, agree
+    torch.testing.assert_close(out["feat_t"].cpu().reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out["label_t_soft"][:, :, ::16, ::16].cpu(), g["soft_sample"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(al.prototypes.cpu(), g["prototypes"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=5e-3, atol=1e-4)
+    sd = model.state_dict()
+    torch.testing.assert_close(sd["encoder.resnet.bn1.running_mean"].cpu(), g["post_bn1_running_mean"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(sd["encoder.resnet.layer4.2.bn3.running_var"].cpu(), g["post_l4_bn3_running_var"], rtol=1e-3, atol=1e-5)
+    _check_updates(model, g, False)
+
+
 def _check_updates(model, g, use_ppm, num_classes=C):
     """One optimizer step seen through the UPDATE of EVERY parameter tensor (256 strided samples each).  The fixture holds
     the reference's update -lr * (clipped grad + wd * w) in float64 (w_post - w_pre itself is quantised to the weights' last

@@ -1,5 +1,5 @@
-"""GPU parity of the Winograd F(2x2, 3x3) path (csrc/winograd.hip; reference call sites uemda/_resnets.py:100-103, Encoder.py:35)
-against torch-CPU float64 convolutions and against the direct f32-MFMA kernels it replaces, through the C ABI."""
+"""GPU parity of the Winograd F(2x2, 3x3) / F(4x4, 3x3) paths (csrc/winograd.hip; reference call sites uemda/_resnets.py:100-103,
+Encoder.py:35) against torch-CPU float64 convolutions and against the direct f32-MFMA kernels they replace, through the C ABI."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -30,12 +30,23 @@ WINO_CASES = [
     (2, 16, 16, 1024, 512, 1),       # wide input (the PPM head's conv_last is 4096 -> 512)
     (4, 16, 8, 256, 320, 1),         # non-square map, Cout a multiple of 64 only
 ]
+# F(4x4,3x3): 4x4 output tiles, T = N*H*W/16 a multiple of 128
+WINO4_CASES = [
+    (2, 32, 32, 128, 128, 1),
+    (2, 32, 32, 512, 256, 1),
+    (2, 32, 32, 256, 512, 2),        # dilated: four interleaved 16x16 sub-images
+    (8, 16, 16, 1024, 512, 1),
+    (16, 16, 8, 256, 320, 1),        # non-square map, Cout a multiple of 64 only
+]
+# relative L2 bounds against float64 (forward, data gradient, weight gradient) and against the direct kernel, per tile edge
+TOL = {2: (1.5e-6, 1.5e-6, 3e-6, 2e-6), 4: (5e-6, 5e-6, 8e-6, 6e-6)}
 
 
-@pytest.mark.parametrize("case", WINO_CASES)
-def test_winograd_forward_dgrad_wgrad_vs_float64(case):
+@pytest.mark.parametrize("m,case", [(2, c) for c in WINO_CASES] + [(4, c) for c in WINO4_CASES])
+def test_winograd_forward_dgrad_wgrad_vs_float64(m, case):
     from uemda_amd import ops
     N, H, W, Cin, Cout, d = case
+    tf, td, tw, tdir = TOL[m]
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(N, Cin, H, W, generator=g)
     sc, sh = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
@@ -46,25 +57,32 @@ def test_winograd_forward_dgrad_wgrad_vs_float64(case):
     gy = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(gy.double())
     assert ops.wino_ok((N, H, W, Cin), Cout, 3, 3, 1, d, d)
+    if m == 4:
+        assert (N * H * W // 16) % 128 == 0 and H % (4 * d) == 0 and W % (4 * d) == 0
     wp = w.cuda().contiguous(memory_format=torch.channels_last)
     # forward with the BatchNorm-affine + ReLU prologue (zero padding after it)
-    y, v = ops.conv3x3_wino(nhwc(x), wp, d, in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True, want_v=True)
-    assert rel(nchw(y), y_ref.detach()) < 1.5e-6
+    y, v = ops.conv3x3_wino(nhwc(x), wp, d, in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True, want_v=True, m=m)
+    assert v.shape[0] == (m + 2) ** 2
+    assert rel(nchw(y), y_ref.detach()) < tf
     # the direct kernel on the same operands: both are fp32 sums of the same products
     y_dir = ops.conv2d(nhwc(x), ops.weight_ohwi(wp), None, pad=d, dil=d, in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True)
-    assert rel(y, y_dir) < 2e-6
+    assert rel(y, y_dir) < tdir
     # data gradient (with respect to the post-activation input)
-    dx, tp = ops.conv3x3_wino_dgrad(nhwc(gy), wp, d)
-    assert tp is None and rel(nchw(dx), xa.grad) < 1.5e-6
+    dx, tp = ops.conv3x3_wino_dgrad(nhwc(gy), wp, d, m=m)
+    assert tp is None and rel(nchw(dx), xa.grad) < td
     # weight gradient, accumulated into a non-zero buffer
     dw0 = torch.randn(Cout, 3, 3, Cin, generator=g).cuda()
     dw = dw0.clone()
     ops.conv3x3_wino_wgrad(v, nhwc(gy), dw, d)
-    assert rel((dw - dw0).permute(0, 3, 1, 2), wr.grad) < 3e-6
+    assert rel((dw - dw0).permute(0, 3, 1, 2), wr.grad) < tw
+    # the weight gradient that recomputes V from the conv input (forward and backward on different tile sizes)
+    dw2 = dw0.clone()
+    ops.conv3x3_wino_wgrad(None, nhwc(gy), dw2, d, x=nhwc(x), in_scale=sc.cuda(), in_shift=sh.cuda(), in_relu=True, m=m)
+    assert rel(dw2 - dw0, dw - dw0) < 1e-6          # same products; only the split-K atomics' order differs
 
 
-@pytest.mark.parametrize("case", WINO_CASES[:4])
-def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(case):
+@pytest.mark.parametrize("m,case", [(2, c) for c in WINO_CASES[:4]] + [(4, c) for c in WINO4_CASES[:3]])
+def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(m, case):
     """forward: BatchNorm statistics out of the output transform; backward: the BatchNorm+ReLU reduction pass of the producer's
     bn inside the data gradient's output transform -- against the direct kernels' fused epilogues on the same tensors."""
     from uemda_amd import ops
@@ -83,9 +101,9 @@ def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(case):
     st_in = ops.bn_stats(z, bn_in.weight.detach(), bn_in.bias.detach(), None, None, True)
     bn_a, bn_b = bn(Cout), bn(Cout)
     bn_b.load_state_dict(bn_a.state_dict())
-    y1, st1, v = ops.conv3x3_wino_bn(z, w, bn_a, d, in_scale=st_in.scale, in_shift=st_in.shift, in_relu=True)
+    y1, st1, v = ops.conv3x3_wino_bn(z, w, bn_a, d, in_scale=st_in.scale, in_shift=st_in.shift, in_relu=True, m=m)
     y2, st2 = ops.conv2d_bn(z, ops.weight_ohwi(w), bn_b, pad=d, dil=d, in_scale=st_in.scale, in_shift=st_in.shift, in_relu=True)
-    assert rel(y1, y2) < 2e-6
+    assert rel(y1, y2) < TOL[m][3]
     for a, b in ((st1.mean, st2.mean), (st1.invstd, st2.invstd), (st1.scale, st2.scale), (st1.shift, st2.shift),
                  (bn_a.running_mean, bn_b.running_mean), (bn_a.running_var, bn_b.running_var)):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
@@ -93,7 +111,7 @@ def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(case):
     dy = nhwc(torch.randn(N, Cout, H, W, generator=g))
     gg1, gb1 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
     gg2, gb2 = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
-    dz1 = ops.conv3x3_wino_dgrad_bn_backward(dy, w, z, st_in, gg1, gb1, d)
+    dz1 = ops.conv3x3_wino_dgrad_bn_backward(dy, w, z, st_in, gg1, gb1, d, m=m)
     dz2 = ops.conv2d_dgrad_bn_backward(dy, ops.weight_transpose(ops.weight_ohwi(w)), z, st_in, gg2, gb2, pad=d, dil=d)
     assert rel(dz1, dz2) < 2e-5
     torch.testing.assert_close(gg1, gg2, rtol=2e-4, atol=2e-4)
@@ -101,16 +119,25 @@ def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(case):
     dwa, dwb = torch.zeros(Cout, 3, 3, Cin, device="cuda"), torch.zeros(Cout, 3, 3, Cin, device="cuda")
     ops.conv3x3_wino_wgrad(v, dy, dwa, d)
     ops.conv2d_wgrad(z, dy, dwb, pad=d, dil=d, in_scale=st_in.scale, in_shift=st_in.shift, in_relu=True)
-    assert rel(dwa, dwb) < 5e-6
+    assert rel(dwa, dwb) < (5e-6 if m == 2 else 1e-5)
 
 
-def test_winograd_declines_shapes_it_does_not_take():
+def test_winograd_plans_and_declined_shapes():
     from uemda_amd import ops
-    assert not ops.wino_ok((2, 16, 16, 64), 64, 3, 3, 1, 1, 1)          # narrow layers stay on the direct kernels
-    assert ops.wino_ok((2, 16, 16, 128), 128, 3, 3, 1, 1, 1) and not ops.wino_dgrad_ok(128, 128)   # layer2: forward + weight gradient only
-    assert not ops.wino_ok((2, 16, 16, 256), 256, 3, 3, 2, 1, 1)        # stride 2
-    assert not ops.wino_ok((2, 16, 16, 256), 256, 1, 1, 1, 0, 1)        # 1x1
-    assert not ops.wino_ok((2, 18, 18, 256), 256, 3, 3, 1, 2, 2)        # 18 is not a multiple of 2 * dilation
-    assert not ops.wino_ok((1, 8, 8, 256), 256, 3, 3, 1, 1, 1)          # T = 16 tiles: not a multiple of 128
+    f4f, f4b = ops.WINOGRAD_F4_FWD, ops.WINOGRAD_F4_BWD
+    assert ops.wino_plan((2, 16, 16, 64), 64, 3, 3, 1, 1, 1) is None               # narrow layer, too few 4x4 tiles: direct kernels
+    p = ops.wino_plan((2, 16, 16, 128), 128, 3, 3, 1, 1, 1)                       # layer2 at 256^2 tiles: F(2x2) forward + weight gradient
+    assert (p.mf, p.mb, p.dgrad, p.keep_v) == (2, 2, False, True)
+    p = ops.wino_plan((32, 128, 128, 64), 64, 3, 3, 1, 1, 1)                      # layer1 at the benchmark's size: F(4x4) or nothing
+    assert (p.mf, p.mb, p.dgrad) == (4 if f4f else 0, 4 if f4b else 0, f4b) if (f4f or f4b) else p is None
+    p = ops.wino_plan((8, 32, 32, 512), 512, 3, 3, 1, 2, 2)                       # layer4 (dilated) of the 512^2 fixture
+    assert (p.mf, p.mb, p.dgrad, p.keep_v) == (4 if f4f else 2, 4 if f4b else 2, True, f4f == f4b)
+    assert ops.wino_plan((2, 16, 16, 256), 256, 3, 3, 2, 1, 1) is None            # stride 2
+    assert ops.wino_plan((2, 16, 16, 256), 256, 1, 1, 1, 0, 1) is None            # 1x1
+    assert ops.wino_plan((2, 18, 18, 256), 256, 3, 3, 1, 2, 2) is None            # 18 is not a multiple of 2 * dilation
+    assert ops.wino_plan((1, 8, 8, 256), 256, 3, 3, 1, 1, 1) is None              # 16 tiles: not a multiple of 128
+    assert not ops.wino_ok((2, 16, 16, 256), 256, 3, 3, 2, 1, 1) and ops.wino_ok((2, 16, 16, 256), 256, 3, 3, 1, 1, 1)
     with pytest.raises(ops.UemError):
         ops.wino_input(torch.zeros(1, 6, 6, 64, device="cuda"), 1)           # the C ABI refuses too (T % 32)
+    with pytest.raises(ops.UemError):
+        ops.wino_input(torch.zeros(2, 18, 16, 64, device="cuda"), 1, m=4)    # 18 is not a multiple of 4

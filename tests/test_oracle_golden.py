@@ -384,3 +384,73 @@ def test_c7_full_model_ppm_ssl_step():
     torch.testing.assert_close(out["loss_target"], g["loss_target"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(out["prototypes"], g["prototypes"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(out["grad_norm"], g["grad_norm"], rtol=1e-3, atol=1e-5)
+
+
+# ---------------- round 4: prototype initialisation, offline pseudo labels, evaluation, the 512x512 operating point ------------
+CLOSED_FORM_W = [[0.5, 1.0, 0.0], [-1.0, 0.0, 1.0], [0.25, 0.25, 0.25], [0.0, -0.75, 0.5], [1.0, -1.0, 0.3], [-0.2, 0.6, -0.9]]
+
+
+def closed_form_model(x):
+    """the deterministic stand-in network of the inference fixtures (tests/golden/make_golden_r4.py ClosedFormModel)"""
+    w = torch.tensor(CLOSED_FORM_W, dtype=x.dtype, device=x.device)
+    return torch.softmax(torch.einsum("kc,bchw->bkhw", w, x), dim=1)
+
+
+def test_aligner_update_avg_init_avg_golden():
+    """Aligner.update_avg x2 + init_avg (reference uemda/gast/alignment.py:107-126, tools/init_prototypes.py:101-111)"""
+    g = load_golden("aligner_avg")
+    s, n = torch.zeros(C, 64), torch.zeros(C, 1)
+    for feat, lab in zip(g["feats"], g["labels"]):
+        s, n = gast.update_avg(feat, lab, s, n, C)
+    torch.testing.assert_close(s, g["data_sum"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(n, g["data_cnt"])
+    assert float(n[5]) == 0.0 and float(n[4]) > 0.0                      # an empty class, and one only the second batch sees
+    protos = gast.init_avg(s, n)
+    torch.testing.assert_close(protos, g["prototypes"], rtol=1e-5, atol=1e-6)
+    assert float(protos[5].abs().max()) == 0.0
+
+
+def test_gener_target_pseudo_pt_tensor_golden():
+    """the `<fname>.pt` tensor of gener_target_pseudo(save_prob=True) (reference uemda/gast/pseudo_generation.py:128-136) and the
+    sliding-window map of a two-window image"""
+    from oracle import infer
+    g = load_golden("gener_pseudo")
+    assert np.allclose(g["model_w"].numpy(), np.array(CLOSED_FORM_W, dtype=np.float32))
+    out = infer.pseudo_prob_map(closed_form_model, g["image"], (64, 96), C, slide=False)
+    assert out.shape == g["pt_file"].shape == (C, 64, 96)
+    torch.testing.assert_close(out, g["pt_file"], rtol=1e-6, atol=1e-7)
+    slide = infer.pre_slide(closed_form_model, g["image2"], num_classes=C, tile_size=(32, 32), tta=False)
+    torch.testing.assert_close(slide, g["slide2"], rtol=1e-6, atol=1e-7)
+
+
+def test_evaluate_feeds_the_metric_golden():
+    """what `evaluate` hands the metric (reference uemda/utils/eval.py:39-47): argmax of the sliding-window map on the labelled pixels"""
+    from oracle import infer
+    g = load_golden("evaluate_pairs")
+    cm = np.zeros((C, C), dtype=np.int64)
+    for k in range(int(g["n_images"])):
+        yt, yp = infer.evaluate_pairs(closed_form_model, g[f"image{k}"], g[f"label{k}"], C, slide=True, tta=False, tile_size=(32, 32))
+        assert np.array_equal(yt, g[f"y_true{k}"].numpy()) and np.array_equal(yp, g[f"y_pred{k}"].numpy())
+        cm += infer.confusion(infer.pre_slide(closed_form_model, g[f"image{k}"], C, (32, 32)), g[f"label{k}"], C)
+    assert np.array_equal(cm, g["confusion"].numpy())
+
+
+def test_full_model_ssl_step_b8_512():
+    """One train_ssl_uem step of R50-ASPP at the reference's own batch (8 + 8, configs/ToPotsdam.py:58) and the benchmark's tile
+    (512 x 512): the oracle against the reference's outputs, bounds scaled by how far the reference moves against itself."""
+    g = load_golden("model_aspp_r50_b8_512")
+    model = OracleDeeplabv2(det_state_dict("resnet50", C, False, seed=2333), "resnet50", C, False)
+    batch = synth.make_batch(B=8, H=512, W=512, C=C, k=2048, seed=2333)
+    opt = SGDState(model.parameters(), HYPER["momentum"], HYPER["weight_decay"])
+    out = ssl_step(model, opt, batch["prototypes"], batch, float(g["lr"]), HYPER, dropout=False)
+    for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
+        err = float((out[k] - g[k]).abs().max() / g[k].abs().max())
+        assert err < 1e-3, (k, err)
+    torch.testing.assert_close(out["label_t_soft"][:, :, ::16, ::16], g["soft_sample"], rtol=1e-3, atol=1e-5)
+    assert (out["label_t_hard"] == g["hard"].long()).float().mean().item() >= 0.9995
+    torch.testing.assert_close(out["loss_source"], g["loss_source"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["loss_target"], g["loss_target"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out["prototypes"], g["prototypes"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["grad_norm"], g["grad_norm"], rtol=2e-3, atol=1e-5)
+    torch.testing.assert_close(model.p["encoder.resnet.bn1.running_mean"], g["post_bn1_running_mean"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(model.p["encoder.resnet.layer4.2.bn3.running_var"], g["post_l4_bn3_running_var"], rtol=1e-4, atol=1e-6)

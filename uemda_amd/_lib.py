@@ -114,13 +114,13 @@ SIGNATURES = {
     "uem_weight_transpose_bf16": [P, P, I, I, I, I, P],
     "uem_cast_f32_bf16": [P, P, L, P],
     "uem_cast_bf16_f32": [P, P, L, P],
-    "uem_wino_filter": [P, P, I, I, I, P],
-    "uem_wino_input": [P, P, P, I, P, I, I, I, I, I, P],
-    "uem_wino_gemm": [P, P, P, I, I, I, I, P],
-    "uem_wino_output": [P, P, I, I, I, I, I, P, P, P, P, P],
-    "uem_wino_dy": [P, P, I, I, I, I, I, P],
-    "uem_wino_wgrad_gemm": [P, P, P, I, I, I, P],
-    "uem_wino_filter_grad": [P, P, I, I, P],
+    "uem_wino_filter": [P, P, I, I, I, I, P],
+    "uem_wino_input": [P, P, P, I, P, I, I, I, I, I, I, P],
+    "uem_wino_gemm": [P, P, P, I, I, I, I, I, P],
+    "uem_wino_output": [P, P, I, I, I, I, I, I, P, P, P, P, P],
+    "uem_wino_dy": [P, P, I, I, I, I, I, I, P],
+    "uem_wino_wgrad_gemm": [P, P, P, I, I, I, I, P],
+    "uem_wino_filter_grad": [P, P, I, I, I, P],
     "uem_comm_unique_id": [P],
     "uem_comm_init": [POINTER(c_void_p), P, I, I],
     "uem_allreduce_flat": [P, P, L, P],

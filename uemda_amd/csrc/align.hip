@@ -125,11 +125,9 @@ extern "C" int uem_pcl_loss(const float* protos, const float* feat, const int64_
     if (grid > UEM_PCL_BLOCKS) grid = UEM_PCL_BLOCKS;
     const size_t lds = (size_t)C * k * sizeof(float);
     if (C <= 8) {
-        hipFuncSetAttribute((const void*)pcl_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        pcl_kernel<8><<<grid, 256, lds, st>>>(feat, pn, labels, cnt, dfeat, partial, n, k, C, 1.0f / temperature, ignore_label);
+        if (uem_allow_lds((const void*)pcl_kernel<8>, lds)) pcl_kernel<8><<<grid, 256, lds, st>>>(feat, pn, labels, cnt, dfeat, partial, n, k, C, 1.0f / temperature, ignore_label);
     } else {
-        hipFuncSetAttribute((const void*)pcl_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        pcl_kernel<16><<<grid, 256, lds, st>>>(feat, pn, labels, cnt, dfeat, partial, n, k, C, 1.0f / temperature, ignore_label);
+        if (uem_allow_lds((const void*)pcl_kernel<16>, lds)) pcl_kernel<16><<<grid, 256, lds, st>>>(feat, pn, labels, cnt, dfeat, partial, n, k, C, 1.0f / temperature, ignore_label);
     }
     pcl_finalize_kernel<<<1, 256, 0, st>>>(partial, grid, cnt, loss_out);
     return uem_check_launch("pcl_loss");

@@ -12,6 +12,7 @@
 
 int uem_fail(int code, const char* fmt, ...);
 int uem_check_launch(const char* what);
+bool uem_allow_lds(const void* kernel, size_t dynamic_lds_bytes);    // api.cpp: once per (kernel, device); false = do not launch
 
 #define UEM_REQUIRE(cond, ...)                                  \
     do {                                                        \

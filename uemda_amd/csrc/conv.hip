@@ -1190,12 +1190,10 @@ static void conv_go(const ConvP& p, bool affine, int grid, hipStream_t st) {
     if (occ2 && BN_ == 128 && PREC == 0 && NBUF == 1 && grid > 768 && grid <= 1024 && lds < 56 * 1024) lds = 56 * 1024;
     if (affine) {
         auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, true, NBUF, PREC>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        k<<<grid, 256, lds, st>>>(p);
+        if (uem_allow_lds((const void*)k, lds)) k<<<grid, 256, lds, st>>>(p);
     } else {
         auto k = conv_fwd_kernel<BN_, WM_, WN_, MODE, false, NBUF, PREC>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        k<<<grid, 256, lds, st>>>(p);
+        if (uem_allow_lds((const void*)k, lds)) k<<<grid, 256, lds, st>>>(p);
     }
 }
 
@@ -1219,8 +1217,7 @@ static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, h
     // strided 1x1 layers, so that the unpadded affine variant can assume output pixel m reads input pixel m
     const bool padded = p.KH * p.KW > 1 || p.stride != 1 || p.pad != 0;
     auto go = [&](auto k) {
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        k<<<grid, 256, lds, st>>>(p, xb, wb, ntiles);
+        if (uem_allow_lds((const void*)k, lds)) k<<<grid, 256, lds, st>>>(p, xb, wb, ntiles);
     };
     const bool full = p.M % BM == 0 && (MODE == 0 || p.sub == 1) && p.bias == nullptr && !(MODE == 0 && p.accumulate);
     const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
@@ -1253,11 +1250,20 @@ static int conv_dma_try(const ConvP& p, bool affine, hipStream_t st) {
     // other's epilogues (layer1 0.51 -> 0.41 ms, layer2 0.33 -> 0.27, layer3 0.22 -> 0.19, layer4 0.65 -> 0.63:
     // scripts/bench_dgrad_tail.py), and with K this small the second read of dy costs little
     const bool wide_tail = MODE == 1 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout;
-    const bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64 && !(wide_tail && g_conv_dma_bn == 0);
+    bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64 && !(wide_tail && g_conv_dma_bn == 0);
     if constexpr (MODE != 2) {
         static const int penv = getenv("UEM_CONV_PERSIST") ? atoi(getenv("UEM_CONV_PERSIST")) : -1;
         const int pset = g_conv_persist >= 0 ? g_conv_persist : penv;
         const int ntiles128 = (int)uem_cdiv(p.M, BM) * (p.Cout / 128), ntiles64 = (int)uem_cdiv(p.M, BM) * (p.Cout / 64);
+        // Winograd GEMMs (grouped pointwise launches, row counts 16 / 36 x the tile count): blocks of a launch run in rounds of the
+        // chip's resident-block slots, so the tile width is the one whose grid fills whole rounds -- 64-wide tiles cost ~8 % per
+        // flop (the A tile is read twice as often) and win when the 128-wide grid leaves a quarter of its last round empty
+        // (F(4x4,3x3) on layer3 at B = 32: 1152 tiles of 128 on 768 / 512 slots, 93 / 103 TFLOP/s; 2304 tiles of 64 on 768)
+        if (p.wg_rows > 0 && bn128 && g_conv_dma_bn == 0 && g_conv_dma_kb == 0 && pset < 0) {
+            auto fill = [](int tiles, int slots) { return (double)tiles / ((double)uem_cdiv(tiles, slots) * slots); };
+            const int slots128 = MODE == 0 ? 768 : 512;                  // forward: 16-channel k-steps, 3 blocks per CU; else 2
+            if (0.92 * fill(ntiles64, 768) > fill(ntiles128, slots128) + 0.02) bn128 = false;
+        }
         // persistent blocks (profiles/r03_a_conv_persist_sweep.txt): the data gradient wherever a block gets at least two tiles;
         // the forward on the 64-wide tiles and the 64-channel pointwise layers (elsewhere its 16-channel k-steps with three
         // resident blocks per CU do as well or better)
@@ -1415,23 +1421,23 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     return UEM_OK;
 }
 
-// The 16 element-wise products of Winograd F(2x2, 3x3) (winograd.hip) as ONE pointwise launch: V [16][T][K] x U[16][N][K]^T -> M [16][T][N];
-// GEMM row r = (position, tile) takes the filter bank of position r / T.
-extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, int K, int N, int data_gradient, void* stream) {
-    UEM_REQUIRE(V && U && Mt && T > 0 && K > 0 && N > 0, "wino_gemm: bad arguments");
+// The npos (16: F(2x2,3x3), 36: F(4x4,3x3)) element-wise products of Winograd (winograd.hip) as ONE pointwise launch:
+// V [npos][T][K] x U[npos][N][K]^T -> M [npos][T][N]; GEMM row r = (position, tile) takes the filter bank of position r / T.
+extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, int K, int N, int npos, int data_gradient, void* stream) {
+    UEM_REQUIRE(V && U && Mt && T > 0 && K > 0 && N > 0 && (npos == 16 || npos == 36), "wino_gemm: bad arguments");
     if (T % BM != 0 || K % BK != 0 || N % 64 != 0 || (((uintptr_t)V | (uintptr_t)U) & 15))
         return uem_fail(UEM_ERR_UNSUPPORTED, "wino_gemm: needs T %% 128 == 0, K %% 32 == 0, N %% 64 == 0, 16-byte aligned operands");
-    if ((double)16 * T * K * 4.0 >= 4294967280.0 || (double)16 * T * N * 4.0 >= 4294967280.0 || (double)16 * N * K * 4.0 >= 4294967280.0)
+    if ((double)npos * T * K * 4.0 >= 4294967280.0 || (double)npos * T * N * 4.0 >= 4294967280.0 || (double)npos * N * K * 4.0 >= 4294967280.0)
         return uem_fail(UEM_ERR_UNSUPPORTED, "wino_gemm: tensor beyond 32-bit byte offsets (split the batch)");
     ConvP p;
     p.x = V; p.w = U; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = Mt;
-    p.N = 1; p.H = 1; p.W = 16 * T; p.Cin = K; p.Ho = 1; p.Wo = 16 * T; p.Cout = N;
+    p.N = 1; p.H = 1; p.W = npos * T; p.Cin = K; p.Ho = 1; p.Wo = npos * T; p.Cout = N;
     p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.x_ld = K; p.y_ld = N;
     p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr;
     p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 1; p.tapmask = 0; p.dbg = 0;
     p.wg_rows = T; p.wg_stride = (unsigned)((size_t)N * K * 4);
-    p.M = 16 * T;
+    p.M = npos * T;
     // data_gradient: the same pointwise product through the data-gradient instantiation (MODE 1: its tile rules, and a kernel name
     // that profiles attribute to the data-gradient family)
     const int took = data_gradient ? conv_dma_try<1>(p, false, (hipStream_t)stream) : conv_dma_try<0>(p, false, (hipStream_t)stream);
@@ -2106,8 +2112,7 @@ static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream
     using C = ConvBf16Cfg<BN_>;
     const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
     auto k = conv_bf16_kernel<BN_, MODE, EPI>;
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;   // per device: per launch
-    k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
+    if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
 }
 template <int BN_, int MODE>
 static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {

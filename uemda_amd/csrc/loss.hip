@@ -280,7 +280,7 @@ static void loss_launch(const float* l1, const float* l2, const int64_t* label, 
     float* inv_valid = partial + (size_t)bands * 4;
     const size_t lds = (size_t)(4 + 4 * LOSS_WAVES) * w * CMAX * sizeof(float);
     auto k = loss_band_kernel<CMAX, MODE>;
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!uem_allow_lds((const void*)k, lds)) return;
     k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
     loss_finalize_kernel<<<1, 256, 0, st>>>(partial, bands, MODE, nheads, ce_denominator, loss_out, MODE ? inv_valid : nullptr);
     const int64_t n = (int64_t)B * h * w * C;

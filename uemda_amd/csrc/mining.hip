@@ -106,9 +106,8 @@ static int pearson_launch(const float* a, const float* b, float* out, float* scr
     if (grid < 1) grid = 1;
 #define LAUNCH_P(CM, INV)                                                                                \
     do {                                                                                                 \
-        hipFuncSetAttribute((const void*)pearson_kernel<CM, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds);                                                                   \
-        pearson_kernel<CM, INV><<<grid, 256, lds, st>>>(a, pc, pstd, out, n, k, m);                       \
+        if (uem_allow_lds((const void*)pearson_kernel<CM, INV>, lds))                                    \
+            pearson_kernel<CM, INV><<<grid, 256, lds, st>>>(a, pc, pstd, out, n, k, m);                   \
     } while (0)
     if (m <= 8) {
         if (invert) LAUNCH_P(8, true); else LAUNCH_P(8, false);
@@ -440,12 +439,10 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
     dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)H, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (C <= 8) {
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)label_refine_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        label_refine_kernel<8><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
+        if (uem_allow_lds((const void*)label_refine_kernel<8>, lds)) label_refine_kernel<8><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
                                                        workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);
     } else {
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void*)label_refine_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        label_refine_kernel<16><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
+        if (uem_allow_lds((const void*)label_refine_kernel<16>, lds)) label_refine_kernel<16><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
                                                         workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);
     }
     blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(workspace, plane_max, (int)(grid.x * grid.y), C, cmax);

@@ -509,14 +509,10 @@ static void wg_go(WgP p, bool affine, hipStream_t st) {
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
     if (affine) {
         auto k = wgrad_dma_kernel<BK, TM, TN, NTAP, S, D, true, LINEAR>;
-        // per launch, not once per process: the attribute is per device and the C ABI takes streams of any device
-        if (C::LDS_BYTES > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;
-        k<<<grid, 256, C::LDS_BYTES, st>>>(p);
+        if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p);
     } else {
         auto k = wgrad_dma_kernel<BK, TM, TN, NTAP, S, D, false, LINEAR>;
-        // per launch, not once per process: the attribute is per device and the C ABI takes streams of any device
-        if (C::LDS_BYTES > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;
-        k<<<grid, 256, C::LDS_BYTES, st>>>(p);
+        if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p);
     }
 }
 
@@ -573,19 +569,19 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
     return ok ? 1 : 0;
 }
 
-// Winograd weight gradient (winograd.hip): dU[pos][n][k] += sum over the T tiles of dM[pos][tile][n] * V[pos][tile][k], the 16 positions
-// as ONE batched launch of the linear (1x1) kernel; dU (16, N, K) must be zeroed by the caller (split-K atomics land in it).
-extern "C" int uem_wino_wgrad_gemm(const float* V, const float* dM, float* dU, int T, int K, int N, void* stream) {
-    UEM_REQUIRE(V && dM && dU && T > 0 && K > 0 && N > 0, "wino_wgrad_gemm: bad arguments");
+// Winograd weight gradient (winograd.hip): dU[pos][n][k] += sum over the T tiles of dM[pos][tile][n] * V[pos][tile][k], the npos (16 / 36)
+// positions as ONE batched launch of the linear (1x1) kernel; dU (npos, N, K) must be zeroed by the caller (split-K atomics land in it).
+extern "C" int uem_wino_wgrad_gemm(const float* V, const float* dM, float* dU, int T, int K, int N, int npos, void* stream) {
+    UEM_REQUIRE(V && dM && dU && T > 0 && K > 0 && N > 0 && (npos == 16 || npos == 36), "wino_wgrad_gemm: bad arguments");
     if (T % 32 != 0 || K % 64 != 0 || N % 64 != 0 || (((uintptr_t)V | (uintptr_t)dM) & 15))
         return uem_fail(UEM_ERR_UNSUPPORTED, "wino_wgrad_gemm: needs T %% 32 == 0, K %% 64 == 0, N %% 64 == 0, 16-byte aligned operands");
-    const double xb = 16.0 * T * K * 4.0, db = 16.0 * T * N * 4.0;
+    const double xb = (double)npos * T * K * 4.0, db = (double)npos * T * N * 4.0;
     if (xb >= 4294967280.0 || db >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "wino_wgrad_gemm: tensor beyond 32-bit byte offsets");
     WgP p;
     p.x = V; p.dy = dM; p.in_scale = p.in_shift = nullptr; p.dw = dU;
     p.M = T; p.N = 1; p.H = 1; p.W = T; p.Cin = K; p.Ho = 1; p.Wo = T; p.Cout = N;
     p.KH = p.KW = 1; p.pad = 0; p.x_ld = K; p.dy_ld = N;
-    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db; p.nbatch = 16;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db; p.nbatch = npos;
     hipStream_t st = (hipStream_t)stream;
     if (N % 128 == 0) wg_go<32, 128, 64, 1, 1, 0, true>(p, false, st);
     else wg_go<32, 64, 64, 1, 1, 0, true>(p, false, st);
@@ -616,8 +612,7 @@ static void wgb_go(WgP p, hipStream_t st) {
     splits = (int)uem_cdiv(p.steps_total, p.steps_per_split);
     const unsigned grid = (unsigned)tiles * (unsigned)splits;
     auto k = wgrad_bf16_kernel<TM, TN, NTAP, S, D, LINEAR, BK_>;
-    if (C::LDS_BYTES > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) return;
-    k<<<grid, 256, C::LDS_BYTES, st>>>(p);
+    if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p);
 }
 template <int TM, int TN>
 static bool wgb_dispatch(const WgP& p, const uem_conv_shape* s, hipStream_t st) {

@@ -34,6 +34,7 @@ struct WinoP {
     float* tile_bnbwd;         // [2][C][M/128]: sum dp, sum dp*xhat
 };
 
+// tile -> (image, sub-image row / column, tile row / column); th / tw are tiles per sub-image for the launch's tile edge (2 or 4)
 __device__ __forceinline__ void wino_tile(const WinoP& p, const int tile, int& n, int& ry, int& rx, int& ty, int& tx) {
     tx = tile % p.tw;
     int r = tile / p.tw;
@@ -305,73 +306,393 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(const float* __re
     }
 }
 
-static int wino_geometry(WinoP& p, int N, int H, int W, int C, int d, const char* what) {
+
+// =====================================================================================================================
+// F(4x4, 3x3): 36 multiplies per 4x4 output block and channel pair instead of 144 (4x fewer MFMA flops, 1.78x fewer than F(2x2,3x3)),
+// transform-domain tensors [36][T][C] with T = N*H*W/16 -- 2.25x the activation instead of 4x.  Interpolation points
+// (0, 1, -1, 1/2, -2, inf): against float64 a Cin = 512 convolution comes out at 1.4e-6 relative L2 (the textbook points 0, +-1, +-2:
+// 2.1e-6; F(2x2,3x3): 3e-7; the direct fmaf chain: 2e-7), every entry of B^T and A^T an exact binary fraction.
+//   B^T = [1 -3/2 -2 3/2 1 0; 0 -1 1/2 5/2 1 0; 0 1 -5/2 1/2 1 0; 0 -2 -1 2 1 0; 0 1/2 -1 -1/2 1 0; 0 1 -3/2 -2 3/2 1]
+//   G   = [1 0 0; 1/3 1/3 1/3; -1/3 1/3 -1/3; -16/15 -8/15 -4/15; 1/15 -2/15 4/15; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 0; 0 1 -1 1/8 -8 1]
+// Used where the gradient noise floor (2-3 % per encoder tensor) dwarfs the transform error: data and weight gradients;
+// the forward takes it only when ops.WINOGRAD_F4_FWD says so.
+// =====================================================================================================================
+struct W4 {
+    __device__ static constexpr float bt(const int r, const int c) {
+        constexpr float t[6][6] = {{1.f, -1.5f, -2.f, 1.5f, 1.f, 0.f}, {0.f, -1.f, 0.5f, 2.5f, 1.f, 0.f}, {0.f, 1.f, -2.5f, 0.5f, 1.f, 0.f},
+                                   {0.f, -2.f, -1.f, 2.f, 1.f, 0.f},   {0.f, 0.5f, -1.f, -0.5f, 1.f, 0.f}, {0.f, 1.f, -1.5f, -2.f, 1.5f, 1.f}};
+        return t[r][c];
+    }
+    __device__ static constexpr float at(const int r, const int c) {
+        constexpr float t[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 0.5f, -2.f, 0.f}, {0.f, 1.f, 1.f, 0.25f, 4.f, 0.f},
+                                   {0.f, 1.f, -1.f, 0.125f, -8.f, 1.f}};
+        return t[r][c];
+    }
+    __device__ static constexpr float g(const int r, const int c) {
+        constexpr float t[6][3] = {{1.f, 0.f, 0.f}, {1.f / 3.f, 1.f / 3.f, 1.f / 3.f}, {-1.f / 3.f, 1.f / 3.f, -1.f / 3.f},
+                                   {-16.f / 15.f, -8.f / 15.f, -4.f / 15.f}, {1.f / 15.f, -2.f / 15.f, 4.f / 15.f}, {0.f, 0.f, 1.f}};
+        return t[r][c];
+    }
+};
+
+// acc (+)= k * a with the compile-time constant k folded: 0 skips, +-1 adds / subtracts, anything else is one fma per component
+__device__ __forceinline__ void f4mac(float4& acc, bool& first, const float k, const float4 a) {
+    if (k == 0.f) return;
+    if (first) {
+        acc = k == 1.f ? a : (k == -1.f ? f4neg(a) : make_float4(k * a.x, k * a.y, k * a.z, k * a.w));
+        first = false;
+    } else if (k == 1.f) acc = f4add(acc, a);
+    else if (k == -1.f) acc = f4sub(acc, a);
+    else acc = make_float4(__builtin_fmaf(k, a.x, acc.x), __builtin_fmaf(k, a.y, acc.y), __builtin_fmaf(k, a.z, acc.z), __builtin_fmaf(k, a.w, acc.w));
+}
+
+// V = B^T d B; block = 16 channel quads (64 channels) x 16 tiles; grid = (T / 16, C / 64).  A window column is transformed as soon as
+// it is loaded, so 36 (not 72) float4 stay live.
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void wino4_input_kernel(const WinoP p) {
+    const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int tile = blockIdx.x * 16 + tl;
+    const int c = blockIdx.y * 64 + q * 4;
+    if (tile >= p.T) return;
+    int n, ry, rx, ty, tx;
+    wino_tile(p, tile, n, ry, rx, ty, tx);
+    const int Hs = p.H / p.d, Ws = p.W / p.d;
+    float4 sc, sh;
+    if (AFFINE) { sc = *reinterpret_cast<const float4*>(p.scale + c); sh = *reinterpret_cast<const float4*>(p.shift + c); }
+    float4 t[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int X = 4 * tx - 1 + j;
+        float4 dcol[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int Y = 4 * ty - 1 + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (Y >= 0 && Y < Hs && X >= 0 && X < Ws) {
+                v = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + (size_t)(Y * p.d + ry)) * p.W + (size_t)(X * p.d + rx)) * p.C + c);
+                if (AFFINE) {
+                    v.x = __builtin_fmaf(v.x, sc.x, sh.x); v.y = __builtin_fmaf(v.y, sc.y, sh.y);
+                    v.z = __builtin_fmaf(v.z, sc.z, sh.z); v.w = __builtin_fmaf(v.w, sc.w, sh.w);
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+            }
+            dcol[i] = v;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) f4mac(acc, first, W4::bt(a, i), dcol[i]);
+            t[a][j] = acc;
+        }
+    }
+    const size_t pos_stride = (size_t)p.T * p.C;
+    float* const out = p.v + (size_t)tile * p.C + c;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) f4mac(acc, first, W4::bt(b, j), t[a][j]);
+            *reinterpret_cast<float4*>(out + (size_t)(a * 6 + b) * pos_stride) = acc;
+        }
+}
+
+// dM = A dY A^T (A = (A^T)^T, 6x4): the weight gradient's transform of a 4x4 block of dY
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const WinoP p) {
+    const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int tile = blockIdx.x * 16 + tl;
+    const int c = blockIdx.y * 64 + q * 4;
+    if (tile >= p.T) return;
+    int n, ry, rx, ty, tx;
+    wino_tile(p, tile, n, ry, rx, ty, tx);
+    float4 u[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float4 gcol[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            gcol[r] = *reinterpret_cast<const float4*>(p.x + (((size_t)n * p.H + (size_t)((4 * ty + r) * p.d + ry)) * p.W + (size_t)((4 * tx + s) * p.d + rx)) * p.C + c);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f4mac(acc, first, W4::at(r, a), gcol[r]);
+            u[a][s] = acc;
+        }
+    }
+    const size_t pos_stride = (size_t)p.T * p.C;
+    float* const out = p.v + (size_t)tile * p.C + c;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f4mac(acc, first, W4::at(s, b), u[a][s]);
+            *reinterpret_cast<float4*>(out + (size_t)(a * 6 + b) * pos_stride) = acc;
+        }
+}
+
+// y = A^T M A; block = 16 channel quads x 16 tiles of 16 pixels = two 128-pixel statistics groups; grid = (T / 16, C / 64).
+// EXTRA as in wino_output_kernel.
+template <int EXTRA>
+__global__ __launch_bounds__(256) void wino4_output_kernel(const WinoP p) {
+    __shared__ float red[2][16][64];
+    const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + q * 4;
+    const size_t pos_stride = (size_t)p.T * p.C;
+    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), bg = bb;
+    float4 sc, sh, mu, is;
+    if (EXTRA == 2) {
+        sc = *reinterpret_cast<const float4*>(p.bn_vec + c);
+        sh = *reinterpret_cast<const float4*>(p.bn_vec + p.C + c);
+        mu = *reinterpret_cast<const float4*>(p.bn_vec + 2 * p.C + c);
+        is = *reinterpret_cast<const float4*>(p.bn_vec + 3 * p.C + c);
+    }
+    const int tile = blockIdx.x * 16 + tl;                       // T is a multiple of 16 (wino_geometry)
+    int n, ry, rx, ty, tx;
+    wino_tile(p, tile, n, ry, rx, ty, tx);
+    const float* const in = p.v + (size_t)tile * p.C + c;
+    float4 t[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float4 mc[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) mc[a] = *reinterpret_cast<const float4*>(in + (size_t)(a * 6 + b) * pos_stride);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) f4mac(acc, first, W4::at(r, a), mc[a]);
+            t[r][b] = acc;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) f4mac(v, first, W4::at(s, b), t[r][b]);
+            const size_t off = (((size_t)n * p.H + (size_t)((4 * ty + r) * p.d + ry)) * p.W + (size_t)((4 * tx + s) * p.d + rx)) * p.C + c;
+            *reinterpret_cast<float4*>(const_cast<float*>(p.x) + off) = v;
+            if (EXTRA == 1) {
+                bb = f4add(bb, v);
+                bg.x = fmaf(v.x, v.x, bg.x); bg.y = fmaf(v.y, v.y, bg.y); bg.z = fmaf(v.z, v.z, bg.z); bg.w = fmaf(v.w, v.w, bg.w);
+            }
+            if (EXTRA == 2) {
+                const float4 z = *reinterpret_cast<const float4*>(p.bn_z + off);
+                const float dx_ = z.x * sc.x + sh.x > 0.f ? v.x : 0.f, dy_ = z.y * sc.y + sh.y > 0.f ? v.y : 0.f;
+                const float dz_ = z.z * sc.z + sh.z > 0.f ? v.z : 0.f, dw_ = z.w * sc.w + sh.w > 0.f ? v.w : 0.f;
+                bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
+                bg.x += dx_ * ((z.x - mu.x) * is.x); bg.y += dy_ * ((z.y - mu.y) * is.y);
+                bg.z += dz_ * ((z.z - mu.z) * is.z); bg.w += dw_ * ((z.w - mu.w) * is.w);
+            }
+        }
+    if (EXTRA == 0) return;
+    *reinterpret_cast<float4*>(&red[0][tl][q * 4]) = bb;
+    *reinterpret_cast<float4*>(&red[1][tl][q * 4]) = bg;
+    __syncthreads();
+    {
+        const int which = threadIdx.x >> 7, grp = (threadIdx.x >> 6) & 1, col = threadIdx.x & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a += red[which][grp * 8 + r][col];
+        float* const out = EXTRA == 1 ? p.tile_stats : p.tile_bnbwd;
+        out[((size_t)which * p.C + blockIdx.y * 64 + col) * (size_t)(2 * gridDim.x) + 2 * blockIdx.x + grp] = a;
+    }
+}
+
+// U = G g G^T, 36 positions; TRANSPOSED as in wino_filter_kernel (flipped taps, U'[pos][ci][co] through LDS, one U row at a time)
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin) {
+    __shared__ float tile[TRANSPOSED ? 6 : 1][16][65];
+    const int q = threadIdx.x & 15, col = threadIdx.x >> 4;
+    const int co = blockIdx.y * 16 + col, ci = blockIdx.x * 64 + q * 4;
+    float4 r[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float4 gcol[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int ky = TRANSPOSED ? 2 - a : a, kx = TRANSPOSED ? 2 - b : b;
+            gcol[a] = *reinterpret_cast<const float4*>(w + (((size_t)co * 3 + ky) * 3 + kx) * Cin + ci);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) f4mac(acc, first, W4::g(i, a), gcol[a]);
+            r[i][b] = acc;
+        }
+    }
+    const size_t pos_stride = (size_t)Cout * Cin;
+    const int wco = threadIdx.x & 15, wci0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) f4mac(u, first, W4::g(j, b), r[i][b]);
+            if (!TRANSPOSED) {
+                *reinterpret_cast<float4*>(U + (size_t)(i * 6 + j) * pos_stride + (size_t)co * Cin + ci) = u;
+            } else {
+                float* t = &tile[j][col][q * 4];
+                t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w;
+            }
+        }
+        if (TRANSPOSED) {
+            __syncthreads();
+#pragma unroll
+            for (int pl = 0; pl < 6; ++pl)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cil = wci0 + 16 * k;
+                    U[(size_t)(i * 6 + pl) * pos_stride + (size_t)(blockIdx.x * 64 + cil) * Cout + blockIdx.y * 16 + wco] = tile[pl][wco][cil];
+                }
+            __syncthreads();
+        }
+    }
+}
+
+// dW[co][ky][kx][ci] += (G^T dU G)[ky][kx], dU[36][co][ci]; one thread per (co, ci quad)
+__global__ __launch_bounds__(256) void wino4_filter_grad_kernel(const float* __restrict__ dU, float* __restrict__ dw, const int Cout, const int Cin) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int cq = Cin / 4;
+    if (idx >= Cout * cq) return;
+    const int co = idx / cq, ci = (idx - co * cq) * 4;
+    const size_t pos_stride = (size_t)Cout * Cin;
+    float4 s[3][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float4 mc[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) mc[a] = *reinterpret_cast<const float4*>(dU + (size_t)(a * 6 + b) * pos_stride + (size_t)co * Cin + ci);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) f4mac(acc, first, W4::g(a, k), mc[a]);
+            s[k][b] = acc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool first = true;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) f4mac(o, first, W4::g(b, l), s[k][b]);
+            float4* dst = reinterpret_cast<float4*>(dw + (((size_t)co * 3 + k) * 3 + l) * Cin + ci);
+            *dst = f4add(*dst, o);
+        }
+}
+
+static int wino_geometry(WinoP& p, int N, int H, int W, int C, int d, int m, const char* what) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || d <= 0 || d > 4) return uem_fail(UEM_ERR_INVALID, "%s: bad shape", what);
-    if (H % (2 * d) != 0 || W % (2 * d) != 0 || C % 64 != 0)
-        return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs H, W multiples of 2*dilation and C a multiple of 64", what);
+    if (m != 2 && m != 4) return uem_fail(UEM_ERR_INVALID, "%s: output tile edge must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3))", what);
+    if (H % (m * d) != 0 || W % (m * d) != 0 || C % 64 != 0)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs H, W multiples of tile*dilation and C a multiple of 64", what);
     p.N = N; p.H = H; p.W = W; p.C = C; p.d = d;
-    p.th = H / d / 2; p.tw = W / d / 2;
+    p.th = H / d / m; p.tw = W / d / m;
     const int64_t T = (int64_t)N * d * d * p.th * p.tw;
-    if (T * 16 * C >= ((int64_t)1 << 30) || T % 32 != 0)                 // 32-bit byte offsets into the transform-domain tensor
-        return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs N*H*W/4 a multiple of 32 and 16*T*C < 2^30 elements (split the batch)", what);
+    const int64_t npos = (m + 2) * (m + 2);
+    if (T * npos * C >= ((int64_t)1 << 30) || T % 32 != 0)               // 32-bit byte offsets into the transform-domain tensor
+        return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs the tile count a multiple of 32 and positions*T*C < 2^30 elements (split the batch)", what);
     p.T = (int)T;
     p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.scale = p.shift = nullptr; p.relu = 0;
     return UEM_OK;
 }
 
 extern "C" int uem_wino_input(const float* x, const float* in_scale, const float* in_shift, int relu, float* V, int N, int H, int W,
-                              int C, int dil, void* stream) {
+                              int C, int dil, int m, void* stream) {
     UEM_REQUIRE(x && V, "wino_input: null pointer");
     UEM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_input: scale and shift go together");
     WinoP p;
-    const int rc = wino_geometry(p, N, H, W, C, dil, "wino_input");
+    const int rc = wino_geometry(p, N, H, W, C, dil, m, "wino_input");
     if (rc) return rc;
     p.x = x; p.v = V; p.scale = in_scale; p.shift = in_shift; p.relu = relu;
     const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
-    if (in_scale) wino_input_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else wino_input_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 2) {
+        if (in_scale) wino_input_kernel<true><<<grid, 256, 0, st>>>(p);
+        else wino_input_kernel<false><<<grid, 256, 0, st>>>(p);
+    } else {
+        if (in_scale) wino4_input_kernel<true><<<grid, 256, 0, st>>>(p);
+        else wino4_input_kernel<false><<<grid, 256, 0, st>>>(p);
+    }
     return uem_check_launch("wino_input");
 }
 
-extern "C" int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, void* stream) {
+extern "C" int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, int m, void* stream) {
     UEM_REQUIRE(dy && dM, "wino_dy: null pointer");
     WinoP p;
-    const int rc = wino_geometry(p, N, H, W, C, dil, "wino_dy");
+    const int rc = wino_geometry(p, N, H, W, C, dil, m, "wino_dy");
     if (rc) return rc;
     p.x = dy; p.v = dM;
     const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
-    wino_dy_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    if (m == 2) wino_dy_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else wino4_dy_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
     return uem_check_launch("wino_dy");
 }
 
-extern "C" int uem_wino_output(const float* Mt, float* y, int N, int H, int W, int C, int dil, float* tile_stats, const float* bn_z,
+extern "C" int uem_wino_output(const float* Mt, float* y, int N, int H, int W, int C, int dil, int m, float* tile_stats, const float* bn_z,
                                const float* bn_vec, float* tile_bnbwd, void* stream) {
     UEM_REQUIRE(Mt && y, "wino_output: null pointer");
     UEM_REQUIRE((bn_z == nullptr) == (bn_vec == nullptr) && (bn_z == nullptr) == (tile_bnbwd == nullptr), "wino_output: bn_z, bn_vec and tile_bnbwd go together");
     UEM_REQUIRE(!(tile_stats && tile_bnbwd), "wino_output: either forward statistics or backward partials");
     WinoP p;
-    const int rc = wino_geometry(p, N, H, W, C, dil, "wino_output");
+    const int rc = wino_geometry(p, N, H, W, C, dil, m, "wino_output");
     if (rc) return rc;
     p.x = y; p.v = const_cast<float*>(Mt); p.tile_stats = tile_stats; p.bn_z = bn_z; p.bn_vec = bn_vec; p.tile_bnbwd = tile_bnbwd;
-    const dim3 grid((unsigned)(p.T / 32), (unsigned)(C / 64));
-    if (tile_stats) wino_output_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else if (tile_bnbwd) wino_output_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
-    else wino_output_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 2) {
+        const dim3 grid((unsigned)(p.T / 32), (unsigned)(C / 64));
+        if (tile_stats) wino_output_kernel<1><<<grid, 256, 0, st>>>(p);
+        else if (tile_bnbwd) wino_output_kernel<2><<<grid, 256, 0, st>>>(p);
+        else wino_output_kernel<0><<<grid, 256, 0, st>>>(p);
+    } else {
+        const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
+        if (tile_stats) wino4_output_kernel<1><<<grid, 256, 0, st>>>(p);
+        else if (tile_bnbwd) wino4_output_kernel<2><<<grid, 256, 0, st>>>(p);
+        else wino4_output_kernel<0><<<grid, 256, 0, st>>>(p);
+    }
     return uem_check_launch("wino_output");
 }
 
-extern "C" int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, void* stream) {
-    UEM_REQUIRE(w_ohwi && U && Cout > 0 && Cin > 0, "wino_filter: bad arguments");
+extern "C" int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, int m, void* stream) {
+    UEM_REQUIRE(w_ohwi && U && Cout > 0 && Cin > 0 && (m == 2 || m == 4), "wino_filter: bad arguments");
     if (Cout % 16 != 0 || Cin % 64 != 0) return uem_fail(UEM_ERR_UNSUPPORTED, "wino_filter: needs Cout %% 16 == 0 and Cin %% 64 == 0");
     const dim3 grid((unsigned)(Cin / 64), (unsigned)(Cout / 16));
-    if (transposed) wino_filter_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(w_ohwi, U, Cout, Cin);
-    else wino_filter_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(w_ohwi, U, Cout, Cin);
+    hipStream_t st = (hipStream_t)stream;
+    if (m == 2) {
+        if (transposed) wino_filter_kernel<true><<<grid, 256, 0, st>>>(w_ohwi, U, Cout, Cin);
+        else wino_filter_kernel<false><<<grid, 256, 0, st>>>(w_ohwi, U, Cout, Cin);
+    } else {
+        if (transposed) wino4_filter_kernel<true><<<grid, 256, 0, st>>>(w_ohwi, U, Cout, Cin);
+        else wino4_filter_kernel<false><<<grid, 256, 0, st>>>(w_ohwi, U, Cout, Cin);
+    }
     return uem_check_launch("wino_filter");
 }
 
-extern "C" int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, void* stream) {
-    UEM_REQUIRE(dU && dw_ohwi && Cout > 0 && Cin > 0 && Cin % 4 == 0, "wino_filter_grad: bad arguments");
+extern "C" int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, int m, void* stream) {
+    UEM_REQUIRE(dU && dw_ohwi && Cout > 0 && Cin > 0 && Cin % 4 == 0 && (m == 2 || m == 4), "wino_filter_grad: bad arguments");
     const int64_t n = (int64_t)Cout * (Cin / 4);
-    wino_filter_grad_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(dU, dw_ohwi, Cout, Cin);
+    if (m == 2) wino_filter_grad_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(dU, dw_ohwi, Cout, Cin);
+    else wino4_filter_grad_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(dU, dw_ohwi, Cout, Cin);
     return uem_check_launch("wino_filter_grad");
 }

@@ -136,18 +136,21 @@ class BottleneckFn(Function):
         W = ops.weight_ohwi
         s, d = blk.stride, blk.dilation
         z1, st1 = ops.conv2d_bn(x, W(blk.conv1.weight), blk.bn1)
-        # the stride-1 3x3 convs of the deep layers take the Winograd path (2.25x fewer multiplies, ops.wino_ok); its transformed
-        # input V is what the weight gradient reduces over, so it is kept for backward
+        # the stride-1 3x3 convs take the Winograd paths (2.25x / 4x fewer multiplies, ops.wino_plan); the transformed input V is
+        # what the weight gradient reduces over: kept for backward when both directions share a tile size and V fits the byte cap,
+        # else recomputed there from z1
         v2 = None
-        wino = ops.wino_ok(z1.shape, blk.conv2.weight.shape[0], 3, 3, s, d, d) and tuple(blk.conv2.weight.shape[2:]) == (3, 3)
-        if wino and (blk.bn2.training or blk.bn2.running_mean is None) and ops.FUSE_BN_STATS:
-            z2, st2, v2 = ops.conv3x3_wino_bn(z1, blk.conv2.weight, blk.bn2, d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
-        elif wino:
-            z2, v2 = ops.conv3x3_wino(z1, blk.conv2.weight, d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, want_v=True)
+        plan = ops.wino_plan(z1.shape, blk.conv2.weight.shape[0], blk.conv2.weight.shape[2], blk.conv2.weight.shape[3], s, d, d)
+        if plan is not None and plan.mf and (blk.bn2.training or blk.bn2.running_mean is None) and ops.FUSE_BN_STATS:
+            z2, st2, v2 = ops.conv3x3_wino_bn(z1, blk.conv2.weight, blk.bn2, d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, m=plan.mf)
+        elif plan is not None and plan.mf:
+            z2, v2 = ops.conv3x3_wino(z1, blk.conv2.weight, d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, want_v=True, m=plan.mf)
             st2 = _BN.stats(z2, blk.bn2)
         else:
             z2, st2 = ops.conv2d_bn(z1, W(blk.conv2.weight), blk.bn2, stride=s, pad=d, dil=d, in_scale=st1.scale,
                                     in_shift=st1.shift, in_relu=True)
+        if plan is None or not plan.keep_v:
+            v2 = None
         z3, st3 = ops.conv2d_bn(z2, W(blk.conv3.weight), blk.bn3, in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
         has_ds = blk.downsample is not None
         need_bwd = any(ctx.needs_input_grad) and ops.RELU_BITS
@@ -168,7 +171,7 @@ class BottleneckFn(Function):
             saved = [x, ybits if ybits is not None else y, z1, z2, z3, _st_tensor(st1), _st_tensor(st2), _st_tensor(st3)]
             if has_ds:
                 saved += [zd, _st_tensor(std)]
-            ctx.wino = v2 is not None
+            ctx.wino = plan
             if v2 is not None:
                 saved.append(v2)
             ctx.save_for_backward(*saved)
@@ -208,15 +211,20 @@ class BottleneckFn(Function):
         dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose_cached(blk.conv3.weight), z2, st2, gb(blk.bn2.weight),
                                            gb(blk.bn2.bias))
         del dz3
-        if ctx.wino:
-            ops.conv3x3_wino_wgrad(sv[-1], dz2, G(blk.conv2.weight), d)
-            if not ops.wino_dgrad_ok(z1.shape[-1], dz2.shape[-1]):
+        plan = ctx.wino
+        if plan is not None and plan.mb:
+            mb = plan.mb
+            if plan.keep_v:
+                ops.conv3x3_wino_wgrad(sv[-1], dz2, G(blk.conv2.weight), d)
+            else:
+                ops.conv3x3_wino_wgrad(None, dz2, G(blk.conv2.weight), d, x=z1, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, m=mb)
+            if not plan.dgrad:
                 dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose_cached(blk.conv2.weight), z1, st1, gb(blk.bn1.weight),
                                                    gb(blk.bn1.bias), stride=s, pad=d, dil=d)
             elif st1.training and ops.FUSE_BN_BACKWARD:
-                dz1 = ops.conv3x3_wino_dgrad_bn_backward(dz2, blk.conv2.weight, z1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), d)
+                dz1 = ops.conv3x3_wino_dgrad_bn_backward(dz2, blk.conv2.weight, z1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), d, m=mb)
             else:
-                da1, _ = ops.conv3x3_wino_dgrad(dz2, blk.conv2.weight, d)
+                da1, _ = ops.conv3x3_wino_dgrad(dz2, blk.conv2.weight, d, m=mb)
                 dz1 = ops.bn_backward(z1, da1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), None, True, dx=da1)
         else:
             ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)

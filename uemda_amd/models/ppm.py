@@ -105,11 +105,11 @@ class PPMHeadFn(Function):
         conv0, bn0, drop, conv4 = head.conv_last[0], head.conv_last[1], head.conv_last[3], head.conv_last[4]
         # the 4096 -> 512 3x3 conv (99.7 % of the head's FLOPs) takes the Winograd path when the shape allows (ops.wino_ok)
         vcat = None
-        wino = ops.wino_ok(cat.shape, conv0.weight.shape[0], 3, 3, 1, 1, 1) and tuple(conv0.weight.shape[2:]) == (3, 3)
-        if wino and (bn0.training or bn0.running_mean is None) and ops.FUSE_BN_STATS:
-            zc, stc, vcat = ops.conv3x3_wino_bn(cat, conv0.weight, bn0, 1)
-        elif wino:
-            zc, vcat = ops.conv3x3_wino(cat, conv0.weight, 1, want_v=True)
+        plan = ops.wino_plan(cat.shape, conv0.weight.shape[0], conv0.weight.shape[2], conv0.weight.shape[3], 1, 1, 1)
+        if plan is not None and plan.mf and (bn0.training or bn0.running_mean is None) and ops.FUSE_BN_STATS:
+            zc, stc, vcat = ops.conv3x3_wino_bn(cat, conv0.weight, bn0, 1, m=plan.mf)
+        elif plan is not None and plan.mf:
+            zc, vcat = ops.conv3x3_wino(cat, conv0.weight, 1, want_v=True, m=plan.mf)
             stc = _BN.stats(zc, bn0)
         else:
             zc = ops.conv2d(cat, ops.weight_ohwi(conv0.weight), pad=1)
@@ -138,9 +138,11 @@ class PPMHeadFn(Function):
         if any(ctx.needs_input_grad):
             ctx.head, ctx.training, ctx.C = head, stc.training, C
             ctx.has_mask = mask is not None
-            ctx.wino = vcat is not None
-            # Winograd: the weight gradient reduces over the transformed input, cat itself is not needed again
-            ctx.save_for_backward(feat, vcat if vcat is not None else cat, zc, _st_tensor(stc), a, w4,
+            ctx.wino = plan
+            keep_v = plan is not None and plan.keep_v
+            # Winograd: the weight gradient reduces over the transformed input; where the forward keeps it (same tile size both ways,
+            # under the byte cap) cat itself is not needed again
+            ctx.save_for_backward(feat, vcat if keep_v else cat, zc, _st_tensor(stc), a, w4,
                                   mask if mask is not None else a.new_empty(0), *saved_branch)
         return out
 
@@ -163,9 +165,16 @@ class PPMHeadFn(Function):
             call("uem_dropout2d", ptr(da), ptr(da), ptr(mask), n, h * w, 512, 0.0, 0, stream())   # seed 0: reuse mask
         stc = _st_from(stcb, ctx.training)
         dzc = ops.bn_backward(zc, da, stc, grad_buffer(bn0.weight), grad_buffer(bn0.bias), None, True, dx=da)
-        if ctx.wino:
-            ops.conv3x3_wino_wgrad(cat, dzc, grad_ohwi(conv0.weight), 1)        # `cat` is the saved transformed input here
-            dcat, _ = ops.conv3x3_wino_dgrad(dzc, conv0.weight, 1)
+        plan = ctx.wino
+        if plan is not None and plan.mb:
+            if plan.keep_v:
+                ops.conv3x3_wino_wgrad(cat, dzc, grad_ohwi(conv0.weight), 1)        # `cat` is the saved transformed input here
+            else:
+                ops.conv3x3_wino_wgrad(None, dzc, grad_ohwi(conv0.weight), 1, x=cat, m=plan.mb)
+            if plan.dgrad:
+                dcat, _ = ops.conv3x3_wino_dgrad(dzc, conv0.weight, 1, m=plan.mb)
+            else:
+                dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose_cached(conv0.weight), (n, h, w, ctot), pad=1)
         else:
             ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
             dcat = ops.conv2d_dgrad(dzc, ops.weight_transpose_cached(conv0.weight), cat.shape, pad=1)

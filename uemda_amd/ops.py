@@ -374,68 +374,119 @@ def weight_transpose_cached(param):
 
 
 # ------------------------------------------------------------------------------------------------
-# Winograd F(2x2, 3x3): the stride-1 3x3 convolutions of the deep layers (csrc/winograd.hip), exact fp32, 2.25x fewer multiplies
+# Winograd F(2x2, 3x3) / F(4x4, 3x3): the stride-1 3x3 convolutions of the deep layers (csrc/winograd.hip), exact fp32 arithmetic,
+# 2.25x / 4x fewer multiplies
 # ------------------------------------------------------------------------------------------------
 WINOGRAD = os.environ.get("UEM_WINOGRAD", "1") != "0"
-# narrower layers are HBM-bound on the 4x larger transform tensors (profiles/r03_d_winograd_vs_direct.txt): at 128 channels
-# (layer2) the forward still gains 7 % and the weight gradient 35 %, the data gradient loses; at 64 channels everything loses
+# Narrower layers are HBM-bound on the larger transform tensors.  F(2x2,3x3), whose V / M tensors are 4x the activation
+# (profiles/r03_d_winograd_vs_direct.txt): at 128 channels (layer2) the forward still gains 7 % and the weight gradient 35 %, the data
+# gradient loses; at 64 channels everything loses.  F(4x4,3x3), 2.25x the activation and 4x fewer multiplies
+# (profiles/r04_a_winograd_vs_direct.txt): wins forward, data gradient and weight gradient down to the 64 channels of layer1
+# (0.36 / 0.41 / 0.24 ms against 0.42 / 0.48 / 0.38 direct at B = 32).
 WINOGRAD_MIN_CH = int(os.environ.get("UEM_WINOGRAD_MIN_CH", "128"))
 WINOGRAD_MIN_CH_DGRAD = int(os.environ.get("UEM_WINOGRAD_MIN_CH_DGRAD", "256"))
+WINOGRAD_MIN_CH_F4 = int(os.environ.get("UEM_WINOGRAD_MIN_CH_F4", "64"))
+# F(4x4,3x3) where the tile count allows.  Its rounding error is 1.7-2.5e-6 per convolution against float64 where F(2x2,3x3) has
+# 4-6e-7 and the direct fmaf chain 6-9e-7 (scripts/bench_winograd.py, WINO_ERR=1).  Backward: far below the 2-3 % noise floor of the
+# encoder's gradients.  Forward: the logits of the 512x512 reference fixture stay within north_star's 1e-3 with a margin
+# (tests/test_gpu_model.py::test_full_model_aspp_ssl_step_b8_512_matches_reference_golden prints it; UEM_WINOGRAD_F4_FWD=0 keeps
+# the forward on F(2x2,3x3)).
+WINOGRAD_F4_BWD = os.environ.get("UEM_WINOGRAD_F4_BWD", "1") != "0"
+WINOGRAD_F4_FWD = os.environ.get("UEM_WINOGRAD_F4_FWD", "1") != "0"
+# V (the transformed input the weight gradient reduces over) is kept by the forward only up to this many bytes per convolution
+# (it is 4x / 2.25x the conv input); above it, and whenever forward and backward use different tile sizes, the backward
+# recomputes it from the saved conv input
+WINOGRAD_SAVE_V_BYTES = int(float(os.environ.get("UEM_WINOGRAD_SAVE_V_GB", "3")) * 2 ** 30)
+
+
+class WinoPlan:
+    """How one stride-1 3x3 conv runs: mf / mb = output tile edge of the forward / backward pass (0 = direct kernel, 2 = F(2x2,3x3),
+    4 = F(4x4,3x3)), dgrad = the data gradient is on the Winograd path too (the weight gradient always is when mb > 0), keep_v = the
+    forward keeps its transformed input for the weight gradient."""
+    __slots__ = ("mf", "mb", "dgrad", "keep_v")
+
+    def __init__(self, mf, mb, dgrad, keep_v):
+        self.mf, self.mb, self.dgrad, self.keep_v = mf, mb, dgrad, keep_v
+
+
+def _wino_edge(x_shape, cout, dil, want4):
+    """largest usable tile edge for one direction: 4, 2 or 0 (direct)"""
+    n, h, w, cin = x_shape
+    lo, hi = min(cin, cout), max(cin, cout)
+    t4 = n * h * w // 16
+    if want4 and lo >= WINOGRAD_MIN_CH_F4 and h % (4 * dil) == 0 and w % (4 * dil) == 0 and t4 % 128 == 0 and 36 * t4 * hi < 2 ** 30:
+        return 4
+    t2 = n * h * w // 4
+    if lo >= WINOGRAD_MIN_CH and h % (2 * dil) == 0 and w % (2 * dil) == 0 and t2 % 128 == 0 and 16 * t2 * hi < 2 ** 30:
+        return 2
+    return 0
+
+
+def wino_plan(x_shape, cout, kh, kw, stride, pad, dil):
+    """WinoPlan of a conv, or None when neither pass takes the Winograd path.  Exact fp32 only (the opt-in operand precisions stay on
+    the direct kernels)."""
+    n, h, w, cin = x_shape
+    if not (WINOGRAD and CONV_PREC == 0 and CONV_PREC_BWD == 0 and kh == 3 and kw == 3 and stride == 1 and pad == dil and dil in (1, 2)):
+        return None
+    if cin % 64 or cout % 64:
+        return None
+    mf, mb = _wino_edge(x_shape, cout, dil, WINOGRAD_F4_FWD), _wino_edge(x_shape, cout, dil, WINOGRAD_F4_BWD)
+    if mf == 0 and mb == 0:
+        return None
+    dgrad = mb == 4 or (mb == 2 and min(cin, cout) >= WINOGRAD_MIN_CH_DGRAD)
+    vbytes = 4 * (mf + 2) ** 2 * (n * h * w // (mf * mf)) * cin if mf else 0
+    return WinoPlan(mf, mb, dgrad, mf != 0 and mf == mb and vbytes <= WINOGRAD_SAVE_V_BYTES)
 
 
 def wino_ok(x_shape, cout, kh, kw, stride, pad, dil):
-    """Does the Winograd path take this conv?  Exact fp32 only (the opt-in operand precisions stay on the direct kernels)."""
-    n, h, w, cin = x_shape
-    if not (WINOGRAD and CONV_PREC == 0 and CONV_PREC_BWD == 0 and kh == 3 and kw == 3 and stride == 1 and pad == dil and dil in (1, 2)):
-        return False
-    if h % (2 * dil) or w % (2 * dil) or cin % 64 or cout % 64 or min(cin, cout) < WINOGRAD_MIN_CH:
-        return False
-    t = n * h * w // 4
-    return t % 128 == 0 and 16 * t * max(cin, cout) < 2 ** 30
+    """Does the forward of this conv take a Winograd path?"""
+    plan = wino_plan(x_shape, cout, kh, kw, stride, pad, dil)
+    return plan is not None and plan.mf != 0
 
 
-def wino_dgrad_ok(cin, cout):
-    """the data gradient of a conv whose forward took the Winograd path stays on the direct kernel below this width"""
-    return min(cin, cout) >= WINOGRAD_MIN_CH_DGRAD
-
-
-def wino_filter_cached(param, transposed):
+def wino_filter_cached(param, transposed, m=2):
     """U = G w G^T of a 3x3 conv weight (transposed: the data gradient's flipped bank), kept until the weights change."""
     key = (WEIGHT_EPOCH, param._version, param.data_ptr())
-    name = "_uem_wino_ut" if transposed else "_uem_wino_u"
+    name = f"_uem_wino{m}_ut" if transposed else f"_uem_wino{m}_u"
     hit = getattr(param, name, None)
     if hit is None or hit[0] != key:
         w = weight_ohwi(param)
         cout, _, _, cin = w.shape
-        u = torch.empty((16, cin, cout) if transposed else (16, cout, cin), device=w.device, dtype=torch.float32)
-        call("uem_wino_filter", ptr(w), ptr(u), cout, cin, 1 if transposed else 0, stream())
+        npos = (m + 2) ** 2
+        u = torch.empty((npos, cin, cout) if transposed else (npos, cout, cin), device=w.device, dtype=torch.float32)
+        call("uem_wino_filter", ptr(w), ptr(u), cout, cin, 1 if transposed else 0, m, stream())
         hit = (key, u)
         setattr(param, name, hit)
     return hit[1]
 
 
-def wino_input(x, dil, in_scale=None, in_shift=None, in_relu=False):
+def wino_input(x, dil, in_scale=None, in_shift=None, in_relu=False, m=2):
     n, h, w, c = x.shape
-    v = torch.empty((16, n * h * w // 4, c), device=x.device, dtype=torch.float32)
-    call("uem_wino_input", ptr(x), ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, ptr(v), n, h, w, c, dil, stream())
+    v = torch.empty(((m + 2) ** 2, n * h * w // (m * m), c), device=x.device, dtype=torch.float32)
+    call("uem_wino_input", ptr(x), ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, ptr(v), n, h, w, c, dil, m, stream())
     return v
 
 
 def wino_gemm(v, u, data_gradient=False):
-    _, t, k = v.shape
+    npos, t, k = v.shape
     nn = u.shape[1]
-    m = torch.empty((16, t, nn), device=v.device, dtype=torch.float32)
-    call("uem_wino_gemm", ptr(v), ptr(u), ptr(m), t, k, nn, 1 if data_gradient else 0, stream())
+    m = torch.empty((npos, t, nn), device=v.device, dtype=torch.float32)
+    call("uem_wino_gemm", ptr(v), ptr(u), ptr(m), t, k, nn, npos, 1 if data_gradient else 0, stream())
     return m
 
 
-def conv3x3_wino_bn(x, param, bn, dil, in_scale=None, in_shift=None, in_relu=False):
+def _wino_flops(M, cout, cin, m):
+    """(algorithmic, executed) flops of a 3x3 conv on the Winograd path: (m+2)^2 multiplies per m^2 outputs and channel pair"""
+    return 2.0 * M * cout * 9 * cin, 2.0 * M * cout * cin * (m + 2) ** 2 / (m * m)
+
+
+def conv3x3_wino_bn(x, param, bn, dil, in_scale=None, in_shift=None, in_relu=False, m=2):
     """3x3 stride-1 conv (pad = dil) + training-mode BatchNorm statistics on the Winograd path -> (y, BNState, V); V (the
-    transformed input, 4x the input's bytes) is what the weight gradient reduces over."""
+    transformed input, 4x / 2.25x the input's bytes) is what the weight gradient reduces over."""
     need_gpu(x)
     _f32c(x, "conv3x3 x")
     n, h, w, cin = x.shape
-    u = wino_filter_cached(param, False)
+    u = wino_filter_cached(param, False, m)
     cout = u.shape[1]
     M = n * h * w
     y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
@@ -443,11 +494,12 @@ def conv3x3_wino_bn(x, param, bn, dil, in_scale=None, in_shift=None, in_relu=Fal
     box = {}
 
     def run():
-        box["v"] = wino_input(x, dil, in_scale, in_shift, in_relu)
-        m = wino_gemm(box["v"], u)
-        call("uem_wino_output", ptr(m), ptr(y), n, h, w, cout, dil, ptr(ts), None, None, None, stream())
+        box["v"] = wino_input(x, dil, in_scale, in_shift, in_relu, m)
+        mt = wino_gemm(box["v"], u)
+        call("uem_wino_output", ptr(mt), ptr(y), n, h, w, cout, dil, m, ptr(ts), None, None, None, stream())
 
-    PROF.run("conv_fwd", 2.0 * M * cout * 9 * cin, run, executed=2.0 * M * cout * 4 * cin)
+    alg, exe = _wino_flops(M, cout, cin, m)
+    PROF.run("conv_fwd", alg, run, executed=exe)
     st = BNState()
     st.training = True
     buf = torch.empty((4, cout), device=x.device, dtype=torch.float32)
@@ -458,32 +510,33 @@ def conv3x3_wino_bn(x, param, bn, dil, in_scale=None, in_shift=None, in_relu=Fal
     return y, st, box["v"]
 
 
-def conv3x3_wino(x, param, dil, in_scale=None, in_shift=None, in_relu=False, want_v=False):
+def conv3x3_wino(x, param, dil, in_scale=None, in_shift=None, in_relu=False, want_v=False, m=2):
     """plain Winograd forward (no statistics) -> y or (y, V)"""
     need_gpu(x)
     _f32c(x, "conv3x3 x")
     n, h, w, cin = x.shape
-    u = wino_filter_cached(param, False)
+    u = wino_filter_cached(param, False, m)
     cout = u.shape[1]
     y = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
     box = {}
 
     def run():
-        box["v"] = wino_input(x, dil, in_scale, in_shift, in_relu)
-        m = wino_gemm(box["v"], u)
-        call("uem_wino_output", ptr(m), ptr(y), n, h, w, cout, dil, None, None, None, None, stream())
+        box["v"] = wino_input(x, dil, in_scale, in_shift, in_relu, m)
+        mt = wino_gemm(box["v"], u)
+        call("uem_wino_output", ptr(mt), ptr(y), n, h, w, cout, dil, m, None, None, None, None, stream())
 
-    PROF.run("conv_fwd", 2.0 * n * h * w * cout * 9 * cin, run, executed=2.0 * n * h * w * cout * 4 * cin)
+    alg, exe = _wino_flops(n * h * w, cout, cin, m)
+    PROF.run("conv_fwd", alg, run, executed=exe)
     return (y, box["v"]) if want_v else y
 
 
-def conv3x3_wino_dgrad(dy, param, dil, bn_z=None, bn_st=None):
+def conv3x3_wino_dgrad(dy, param, dil, bn_z=None, bn_st=None, m=2):
     """dx of the 3x3 stride-1 conv on the Winograd path: dx = conv(dy, flipped transposed filters).  With bn_z / bn_st also the
     per-128-pixel partial sums of the BatchNorm+ReLU backward of the layer dx feeds -> (dx, partials or None)."""
     need_gpu(dy)
     _f32c(dy, "dgrad dy")
     n, h, w, cout = dy.shape
-    ut = wino_filter_cached(param, True)                  # (16, cin, cout)
+    ut = wino_filter_cached(param, True, m)                  # (npos, cin, cout)
     cin = ut.shape[1]
     M = n * h * w
     dx = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
@@ -495,19 +548,20 @@ def conv3x3_wino_dgrad(dy, param, dil, bn_z=None, bn_st=None):
             raise UemError("conv3x3_wino_dgrad: BNState vectors must live in one (4, C) buffer")
 
     def run():
-        m = wino_gemm(wino_input(dy, dil), ut, data_gradient=True)
-        call("uem_wino_output", ptr(m), ptr(dx), n, h, w, cin, dil, None, ptr(bn_z), ptr(vec), ptr(tp), stream())
+        mt = wino_gemm(wino_input(dy, dil, m=m), ut, data_gradient=True)
+        call("uem_wino_output", ptr(mt), ptr(dx), n, h, w, cin, dil, m, None, ptr(bn_z), ptr(vec), ptr(tp), stream())
 
-    PROF.run("conv_dgrad", 2.0 * M * cout * 9 * cin, run, executed=2.0 * M * cout * 4 * cin)
+    alg, exe = _wino_flops(M, cout, cin, m)
+    PROF.run("conv_dgrad", alg, run, executed=exe)
     return dx, tp
 
 
-def conv3x3_wino_dgrad_bn_backward(dy, param, z, st, gamma_grad, beta_grad, dil):
+def conv3x3_wino_dgrad_bn_backward(dy, param, z, st, gamma_grad, beta_grad, dil, m=2):
     """Winograd twin of conv2d_dgrad_bn_backward: dA = dgrad(dy), then the BatchNorm+ReLU backward of the bn that produced the
     conv's input (reduction pass inside the output transform) -> dz in dA's buffer."""
     cin = z.shape[-1]
     M = z.numel() // cin
-    da, tp = conv3x3_wino_dgrad(dy, param, dil, bn_z=z, bn_st=st)
+    da, tp = conv3x3_wino_dgrad(dy, param, dil, bn_z=z, bn_st=st, m=m)
     tmp = torch.empty((2, cin), device=dy.device, dtype=torch.float32)
     call("uem_bn_bwd_from_tiles", ptr(tp), M // 128, cin, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
     call("uem_bn_bwd_apply", ptr(z), ptr(da), None, ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
@@ -515,23 +569,31 @@ def conv3x3_wino_dgrad_bn_backward(dy, param, z, st, gamma_grad, beta_grad, dil)
     return da
 
 
-def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil):
-    """dw (Cout,3,3,Cin) += weight gradient from the saved transformed input V (16, T, Cin) and dy (N,H,W,Cout)."""
+def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None, in_relu=False, m=None):
+    """dw (Cout,3,3,Cin) += weight gradient from dy (N,H,W,Cout) and the transformed input V (npos, T, Cin) the forward saved; with
+    v None, V is recomputed from the conv input x (through the producer's BatchNorm affine + ReLU) at tile edge m."""
     if dw_ohwi is None:
         return
-    need_gpu(v, dy, dw_ohwi)
+    need_gpu(dy, dw_ohwi)
     _f32c(dy, "wgrad dy"), _f32c(dw_ohwi, "wgrad dw")
     n, h, w, cout = dy.shape
-    _, t, cin = v.shape
+    if v is not None:
+        m = {16: 2, 36: 4}[v.shape[0]]
+        cin = v.shape[2]
+    else:
+        cin = x.shape[-1]
 
     def run():
-        dm = torch.empty((16, t, cout), device=dy.device, dtype=torch.float32)
-        call("uem_wino_dy", ptr(dy), ptr(dm), n, h, w, cout, dil, stream())
-        du = torch.zeros((16, cout, cin), device=dy.device, dtype=torch.float32)
-        call("uem_wino_wgrad_gemm", ptr(v), ptr(dm), ptr(du), t, cin, cout, stream())
-        call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, stream())
+        vv = v if v is not None else wino_input(x, dil, in_scale, in_shift, in_relu, m)
+        npos, t, _ = vv.shape
+        dm = torch.empty((npos, t, cout), device=dy.device, dtype=torch.float32)
+        call("uem_wino_dy", ptr(dy), ptr(dm), n, h, w, cout, dil, m, stream())
+        du = torch.zeros((npos, cout, cin), device=dy.device, dtype=torch.float32)
+        call("uem_wino_wgrad_gemm", ptr(vv), ptr(dm), ptr(du), t, cin, cout, npos, stream())
+        call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, m, stream())
 
-    PROF.run("conv_wgrad", 2.0 * n * h * w * cout * 9 * cin, run, executed=2.0 * n * h * w * cout * 4 * cin)
+    alg, exe = _wino_flops(n * h * w, cout, cin, m)
+    PROF.run("conv_wgrad", alg, run, executed=exe)
 
 
 def nchw3_to_nhwc4(x):
