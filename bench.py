@@ -9,7 +9,9 @@ plus the mining the metric names).
 
 Rank 0 prints ONE JSON line.  `value` = tiles (source + target) per second over all ranks, inputs resident in
 HBM when the timed region starts.  `roofline` is for the dominant kernel family (the f32-MFMA implicit-GEMM
-convolution), from HIP events around every one of its launches inside the timed region.  `cpu_baseline` is the
+convolution), from HIP events around every one of its launches inside the timed region: `achieved` / `frac` count the multiplies
+the matrix pipe EXECUTES (a Winograd conv issues 2.25x / 4x fewer than its algorithmic count), `algorithmic_tflops` is the speed
+figure beside it.  `roofline_hbm` prices the HBM-bound mining phase (label_refine + pseudo_selection).  `cpu_baseline` is the
 oracle (CPU restatement of the reference, `kind: "port"`) timed on the host cores at BASELINE config 1.
 `other_configs` (N = 1): the same step in the other configurations BASELINE.json names (bf16 storage, the PPM head,
 ResNet-101 on 1024x1024 tiles), 3 timed steps each AFTER the headline, each with its own roofline entry; they never touch `value`.
@@ -31,7 +33,8 @@ import torch
 import torch.distributed as dist
 
 F32_MATRIX_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
-BF16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the peak of the opt-in "bf16" operand mode)
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the peak the bf16-storage configurations are priced against)
+HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s is what a streaming copy reaches)
 
 
 def kernel_source_hash():
@@ -106,7 +109,7 @@ def _all_threads_leg(nthreads, q):
     q.put(dict(tiles_per_s=round(4.0 / min(times), 3), s_per_step=round(min(times), 3), timed_steps=len(times), threads=nthreads))
 
 
-def cpu_baseline(seconds_budget=45.0):
+def cpu_baseline(seconds_budget=30.0):
     """The oracle (CPU restatement of the reference, kind "port") on the host cores, as SURVEY 8(d) specifies: BASELINE
     config 1 (B=2, 256x256, fp32), R50-ASPP and R50-PPM, (i) train_src-style and (ii) train_ssl_uem-style steps, 1 warm-up
     + 3 timed steps each on the box's CPU share, one timed step of the ASPP pair pinned to ONE thread, and the ASPP ssl step on
@@ -156,25 +159,29 @@ def cpu_baseline(seconds_budget=45.0):
     for style in ("src", "ssl"):
         if time.time() < t_stop:
             cfg1[f"r50-aspp {style} 1 thread"] = leg("aspp", style, 256, 1, 0, 1)       # no warm-up: one cold step
-    # every host thread the affinity mask shows ("all host threads"), in a child process with a deadline: where the
-    # cgroup grants fewer cores than the mask shows, hundreds of threads on 16 cores would take minutes per step
+    # every host thread the affinity mask shows ("all host threads"): only where the cgroup grants them -- on a one-GPU box
+    # the mask shows 256 CPUs and the cgroup grants 16; 256 torch threads on 16 cores take minutes per step (round 3 spent 40 s of
+    # the run finding that out again), so that leg is declined up front and says why
     if visible > threads:
-        import multiprocessing as mp
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        p = ctx.Process(target=_all_threads_leg, args=(visible, q), daemon=True)
-        p.start()
-        p.join(40.0)
         name = f"r50-aspp ssl all {visible} visible host threads"
-        if p.is_alive():
-            p.terminate()
-            p.join(5.0)
-            cfg1[name] = dict(skipped=f"no result within 40 s: the affinity mask shows {visible} CPUs, the cgroup grants {avail}")
+        if avail >= visible:
+            import multiprocessing as mp
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            p = ctx.Process(target=_all_threads_leg, args=(visible, q), daemon=True)
+            p.start()
+            p.join(40.0)
+            if p.is_alive():
+                p.terminate()
+                p.join(5.0)
+                cfg1[name] = dict(skipped="no result within 40 s")
+            else:
+                try:
+                    cfg1[name] = q.get(timeout=2.0)
+                except Exception:                         # noqa: BLE001
+                    cfg1[name] = dict(error=f"child exited with code {p.exitcode}")
         else:
-            try:
-                cfg1[name] = q.get(timeout=2.0)
-            except Exception:                         # noqa: BLE001
-                cfg1[name] = dict(error=f"child exited with code {p.exitcode}")
+            cfg1[name] = dict(skipped=f"the affinity mask shows {visible} CPUs, the cgroup grants {avail}: not run")
     torch.set_num_threads(threads)
     return dict(value=headline["tiles_per_s"], unit="tiles/s", cores=threads, kind="port",
                 sample=f"oracle (CPU restatement) ssl_step, R50-ASPP, 2 source + 2 target 512x512 tiles per step, fp32, best of "
@@ -196,7 +203,6 @@ class Setup:
         from uemda_amd.step import HYPER, StepState, src_step, ssl_step
         from uemda_amd.utils.tools import lr_poly, lr_warmup, seed_torch
         self.cfg, self.world = cfg, world
-        ops.set_conv_precision(cfg.conv_prec)
         C, B, S = 6, cfg.batch, cfg.size
         seed_torch(2333)
         mcfg = dict(backbone=dict(resnet_type=cfg.model, output_stride=16, pretrained=False), multi_layer=True,
@@ -204,12 +210,16 @@ class Setup:
                     inchannels=2048, num_classes=C, is_ins_norm=True)
         self.model = Deeplabv2(mcfg).cuda().set_storage(cfg.storage)   # random init of the reference's architecture (no checkpoints)
         self.wrapper = wrapper_factory(self.model) if wrapper_factory is not None else None
-        # synthetic tiles: a small seeded pool generated on the host, tiled to the batch on the device
+        # synthetic tiles: every tile of a batch is its own seeded tile (no repeats), generated on the host (2 s per 32
+        # tiles) and resident in HBM before the timed region; `nbatches` distinct batches alternate step by step, so that no two
+        # consecutive steps see the same data
         data_rank = rank if cfg.data_rank is None else cfg.data_rank
-        pool = synth.make_batch(B=min(B, 4), H=S, W=S, C=C, k=2048, seed=2333 + data_rank)
-        self.rep = (B + pool["images_s"].shape[0] - 1) // pool["images_s"].shape[0]
-        self.batch = {k: (v.cuda().repeat((self.rep,) + (1,) * (v.dim() - 1))[:B].contiguous() if k != "prototypes" else v.cuda())
-                      for k, v in pool.items()}
+        nb = max(1, int(getattr(cfg, "unique_batches", 2)))
+        self.batches = []
+        for j in range(nb):
+            pool = synth.make_batch(B=B, H=S, W=S, C=C, k=2048, seed=2333 + data_rank + 1000 * j)
+            self.batches.append({k: v.cuda().contiguous() for k, v in pool.items()})
+        self.batch = self.batches[0]
         self.aligner = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
         # replicas start from the same prototypes: seeded independently of the rank, then broadcast
         self.aligner.prototypes = synth.make_batch(B=1, H=32, W=32, C=C, k=2048, seed=2333)["prototypes"].cuda().contiguous()
@@ -228,28 +238,35 @@ class Setup:
         self._ssl, self._src = ssl_step, src_step
 
     def one_step(self, i, mark=None):
+        batch = self.batches[i % len(self.batches)]
         if self.cfg.workload == "ssl":
-            return self._ssl(self.model, self.aligner, self.opt, self.state, self.batch, self.lr_at(i + 1), dp=self.wrapper,
+            return self._ssl(self.model, self.aligner, self.opt, self.state, batch, self.lr_at(i + 1), dp=self.wrapper,
                              sup_ignore_id=self.sup_ignore, mark=mark)
-        return self._src(self.model, self.opt, self.state, self.batch, self.lr_at(i + 1), dp=self.wrapper)
+        return self._src(self.model, self.opt, self.state, batch, self.lr_at(i + 1), dp=self.wrapper)
 
 
 def roofline_of(prof, peak, traffic_for=None):
-    """bench `roofline` object from the per-launch HIP events of one step: the family with the most time."""
+    """bench `roofline` object from the per-launch HIP events of one step: the family with the most time.  `achieved` and `frac` are
+    what the matrix pipe executes (a fraction of its peak: never above 1); the algorithmic rate -- what the step gets done per second,
+    Winograd's saved multiplies counted -- stands beside it as `algorithmic_tflops`."""
     if not prof:
         return None
     fam, agg = max(prof.items(), key=lambda kv: kv[1]["ms"])
-    ach = agg["flops"] / (agg["ms"] * 1e-3) / 1e12
-    return dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                traffic=traffic_for(fam) if traffic_for else None,
+    exe = agg["executed"] / (agg["ms"] * 1e-3) / 1e12
+    alg = agg["flops"] / (agg["ms"] * 1e-3) / 1e12
+    frac = exe / peak
+    assert frac <= 1.0, f"roofline fraction {frac} of {fam}: executed flops cannot exceed the peak"
+    return dict(bound="mfma", kernel=fam, achieved=round(exe, 2), peak=peak, unit="TFLOP/s", frac=round(frac, 4),
+                algorithmic_tflops=round(alg, 2), traffic=traffic_for(fam) if traffic_for else None,
                 launches_per_step=agg["launches"], avg_launch_ms=round(agg["ms"] / agg["launches"], 4),
+                executed_gflop_per_launch=round(agg["executed"] / agg["launches"] / 1e9, 3),
                 algorithmic_gflop_per_launch=round(agg["flops"] / agg["launches"] / 1e9, 3),
-                families={k: dict(tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms_per_step=round(v["ms"], 2),
-                                  executed_tflops=round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2)) for k, v in prof.items()},
-                measured="HIP events around every conv launch of the last timed step; flops = ALGORITHMIC flops of the convolution "
-                         "(2*M*Cout*k*k*Cin), also for the 3x3 layers that run as Winograd F(2x2,3x3) (input transform + 16-position "
-                         "GEMM + output transform inside one event pair): `executed_tflops` counts the multiplies actually issued "
-                         "(algorithmic / 2.25 on those layers) and is what the matrix pipe's utilisation is")
+                families={k: dict(executed_tflops=round(v["executed"] / (v["ms"] * 1e-3) / 1e12, 2), frac=round(v["executed"] / (v["ms"] * 1e-3) / 1e12 / peak, 4),
+                                  algorithmic_tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), ms_per_step=round(v["ms"], 2)) for k, v in prof.items()},
+                measured="HIP events around every conv launch of the last timed step.  achieved / frac = EXECUTED flops (the multiplies "
+                         "issued to the matrix pipe) over the event time: a 3x3 layer on Winograd F(2x2,3x3) / F(4x4,3x3) (input transform + "
+                         "16- / 36-position GEMM + output transform inside one event pair) executes 2*M*Cout*Cin*16/4 resp. *36/16 where "
+                         "the direct conv executes 2*M*Cout*9*Cin; algorithmic_tflops counts the latter for every conv")
 
 
 def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
@@ -299,7 +316,7 @@ def short_leg(cfg, steps=3, warmup=2):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ops.PROF.enabled = False
-    bf16 = cfg.storage == "bf16" or cfg.conv_prec == "bf16"
+    bf16 = cfg.storage == "bf16"
     out = dict(value=round(s.tiles_per_step / dt, 2), unit=f"tiles({cfg.size}x{cfg.size})/s", ms_per_step=round(1e3 * dt, 2), steps=steps,
                warmup=warmup, dtype="bf16 storage (fp32 accumulate / statistics / master weights)" if cfg.storage == "bf16" else "f32",
                workload=f"{cfg.model}-{cfg.head} {cfg.workload} step, {cfg.batch} source + {cfg.batch} target {cfg.size}x{cfg.size} tiles",
@@ -334,12 +351,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dump-conv-events", default=None, help="write the per-launch conv timings of the last timed step to this JSON file")
-    ap.add_argument("--conv-prec", default="fp32", choices=["fp32", "mixed", "bf16x3", "bf16"],
-                    help="matrix-core operand precision of the convolutions (fp32 = exact f32 MFMA, the parity default)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: activations / weight copies of the encoder stored in bf16, bf16 matrix cores (BASELINE config 5)")
-    ap.add_argument("--no-other-precisions", action="store_true",
-                    help="skip the short extra legs that time the same step in the opt-in operand precisions (N=1 only)")
+    ap.add_argument("--no-other-precisions", action="store_true", help="accepted and ignored (the operand-precision legs are retired)")
+    ap.add_argument("--unique-batches", type=int, default=2, help="distinct seeded batches alternating step by step")
     ap.add_argument("--no-hipgraph", action="store_true", help="skip the short leg that replays the step as one hipGraph (N=1 only)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configurations (bf16 storage, PPM head, R101 1024^2; N=1 only)")
@@ -445,45 +460,20 @@ def main():
             json.dump(ops.PROF.per_call(), f)
     ops.PROF.records = []
 
-    others = None
-    if world == 1 and not args.no_other_precisions and args.storage == "fp32":
-        # the same step in the other matrix-core precisions (2 untimed + 3 timed steps each); `value` above is untouched
-        others = {}
-        for prec in ("fp32", "mixed", "bf16x3", "bf16"):
-            if prec == args.conv_prec:
-                continue
-            try:                                  # an opt-in leg must never cost the headline line
-                ops.set_conv_precision(prec)
-                for i in range(2):
-                    one_step(args.warmup + args.steps + i)
-                barrier()
-                t1 = time.perf_counter()
-                for i in range(3):
-                    one_step(args.warmup + args.steps + 2 + i)
-                barrier()
-                dt = (time.perf_counter() - t1) / 3
-                others[prec] = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=3)
-            except Exception as e:                # noqa: BLE001
-                others[prec] = dict(error=repr(e)[:200])
-            note(f"other precision {prec}: {others[prec]}")
-        ops.set_conv_precision(args.conv_prec)
-
     graph_leg = None
     if world == 1 and wrapper is None and not args.no_hipgraph:           # (the data-parallel step holds RCCL calls: not captured)
         graph_leg = replay_leg(s, args.workload, args.warmup + args.steps, tiles_per_step)
         if rank == 0:
             note(f"hipGraph replay: {graph_leg}")
 
-    peak = BF16_MATRIX_PEAK_TFLOPS if (args.conv_prec == "bf16" or args.storage == "bf16") else F32_MATRIX_PEAK_TFLOPS
-    prec_text = {"fp32": "fp32 (f32 MFMA)", "bf16x3": "fp32 storage, 3xbf16 split MFMA with fp32 accumulate",
-                 "mixed": "fp32 (f32 MFMA) forward, 3xbf16 split MFMA data/weight gradients",
-                 "bf16": "fp32 storage, bf16 MFMA operands with fp32 accumulate"}[args.conv_prec]
+    peak = BF16_MATRIX_PEAK_TFLOPS if args.storage == "bf16" else F32_MATRIX_PEAK_TFLOPS
+    prec_text = "fp32 (f32 MFMA)"
     line = None
     if rank == 0:
         # HBM bytes per launch of a family from the PMC passes (scripts/pmc_traffic.py), valid ONLY for the configuration AND the
         # build of the conv kernels they were collected on: anything else reports null
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec={args.conv_prec}" + ("" if args.storage == "fp32" else " storage=bf16")
+        key = f"{args.model}-{args.head} {args.workload} B={B} size={S} prec=fp32" + ("" if args.storage == "fp32" else " storage=bf16")
         tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
         traffic_ok = tj.get("config") == key and tj.get("kernel_source_sha256_16") == kernel_source_hash()
         def traffic_of(fam):               # HBM bytes per launch (= per convolution) of the family: PMC bytes per step / launches per step
@@ -502,13 +492,13 @@ def main():
             "metric": metric,
             "value": round(value, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 storage (fp32 accumulate / statistics / master weights)" if args.storage == "bf16" else {"fp32": "f32", "mixed": "f32 fwd / 3xbf16 split bwd", "bf16x3": "f32 (3xbf16 split)", "bf16": "bf16"}[args.conv_prec],
+            "vs_baseline": None, "dtype": "bf16 storage (fp32 accumulate / statistics / master weights)" if args.storage == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": f"train_ssl_uem step ({args.workload}): {args.model}-{args.head} 6-class, per-GPU {B} source + "
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text if args.storage == 'fp32' else 'bf16 storage in the encoder (bf16 MFMA, fp32 accumulate)'}, "
-                                   f"random init; tiles counted = source + target; the batch repeats {min(B, 4)} unique seeded "
-                                   f"tiles x{s.rep} (no kernel is value-dependent); the last timed step also records per-launch HIP "
-                                   f"events (660 event records: about 1 ms of command-processor bubbles)",
+                                   f"random init; tiles counted = source + target; every tile of a batch is its own seeded tile, "
+                                   f"{len(s.batches)} distinct batches alternate step by step; the last timed step also records "
+                                   f"per-launch HIP events (about 1 ms of command-processor bubbles)",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
                        "collective": None if wrapper is None else ("uem_allreduce_flat (RCCL through the C ABI)" if wrapper.native
                                                                    is not None else f"torch.distributed {args.backend}"),
@@ -531,12 +521,20 @@ def main():
                   "clip_sgd": 5 * 4 * model.flat_parameters()[2] / 1e6}
             line["phases_ms"] = ph
             line["phases_hbm_GBps"] = {k: round(v / 1e3 / (ph[k] * 1e-3), 1) for k, v in mb.items() if ph.get(k, 0) > 0}
+            if ph.get("label_refine_select", 0) > 0:
+                # the HBM-bound phase the path is named after: Pearson similarity, superpixel segment-max, the fused three-view
+                # refinement and pseudo_selection over the B target tiles; SURVEY 8(d): 25.2 MB of algorithmic traffic per tile
+                gbps = mb["label_refine_select"] / 1e3 / (ph["label_refine_select"] * 1e-3)
+                line["roofline_hbm"] = dict(bound="hbm", kernel="label_refine + pseudo_selection (pearson, segment_max, label_refine, pseudo_select)",
+                                            achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBPS, 4), traffic=None,
+                                            algorithmic_mb_per_tile=25.2, tiles=B, ms=ph["label_refine_select"],
+                                            measured="HIP events on the compute stream around the phase in the last timed step; bytes = "
+                                                     "SURVEY 8(d)'s 25.2 MB per target tile (soft 6.29 + superpixels 2.10 + features 8.39 read, "
+                                                     "refined soft 6.29 + hard labels 2.10 written) x tiles")
         ms = torch.cuda.memory_stats()
         line["device_memory"] = {"peak_allocated_GB": round(ms.get("allocated_bytes.all.peak", 0) / 1e9, 1),
                                  "peak_reserved_GB": round(ms.get("reserved_bytes.all.peak", 0) / 1e9, 1),
                                  "alloc_retries": int(ms.get("num_alloc_retries", 0))}
-        if others:
-            line["other_precisions"] = others
         if graph_leg:
             line["hipgraph"] = graph_leg
     if args.dump_params:
@@ -547,7 +545,7 @@ def main():
                         prototypes=aligner.prototypes.cpu(), first_grad_sample=first_grad.get("sample"),
                         first_grad_norm=first_grad.get("norm"), unpaired_forwards=getattr(wrapper, "unpaired_forwards", None)),
                    f"{args.dump_params}.rank{rank}.pt")
-    if rank == 0 and world == 1 and not args.no_other_configs and (args.model, args.head, args.storage, S, args.conv_prec) == ("resnet50", "aspp", "fp32", 512, "fp32"):
+    if rank == 0 and world == 1 and not args.no_other_configs and (args.model, args.head, args.storage, S) == ("resnet50", "aspp", "fp32", 512):
         # the other configurations BASELINE.json names, after the headline and without touching it: the headline's model is
         # released first (R101 on 1024^2 tiles needs ~105 GB of the 288)
         del s, model, aligner, one_step, out
@@ -558,7 +556,7 @@ def main():
         legs = {"bf16 storage r50-aspp 512": dict(storage="bf16"), "fp32 r50-ppm 512": dict(head="ppm"),
                 "bf16 storage r101-aspp 1024 (BASELINE config 5, one GPU's share)": dict(storage="bf16", model="resnet101", size=1024)}
         for name, over in legs.items():
-            cfg = types.SimpleNamespace(**{**vars(args), "conv_prec": "fp32", "data_rank": None, **over})
+            cfg = types.SimpleNamespace(**{**vars(args), "data_rank": None, **over})
             try:
                 oc[name] = short_leg(cfg)
             except Exception as e:                # noqa: BLE001  (an extra leg must never cost the headline line)

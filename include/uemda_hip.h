@@ -48,9 +48,9 @@ typedef struct {
 #define UEM_CONV_IN_AFFINE 1   /* operand prologue: x' = x*in_scale[c] + in_shift[c]  (fused BN apply) */
 #define UEM_CONV_IN_RELU 2     /* operand prologue: x' = max(x', 0)                                  */
 #define UEM_CONV_ACCUMULATE 4  /* epilogue: y += result (ASPP branch sum, Encoder.py:83)               */
-#define UEM_CONV_PREC_BF16X3 16 /* opt-in: operands split x = hi + lo (bf16), hi*hi + hi*lo + lo*hi on the bf16 MFMA,
-                                  fp32 accumulate: ~2^-16 relative error per product (exact fp32 MFMA is the default) */
-#define UEM_CONV_PREC_BF16 32   /* opt-in: plain bf16 operands (hi*hi only), fp32 accumulate                        */
+/* (16 was UEM_CONV_PREC_BF16X3, the split-operand mode of rounds 1-3: retired in round 4, the flag is rejected) */
+#define UEM_CONV_PREC_BF16 32   /* bf16 operands on the bf16 MFMA, fp32 tensors and fp32 accumulate: the operand mode of the fp32
+                                  islands (7x7 stem, ASPP heads' GEMM) of a bf16-STORAGE model; never the fp32 parity path   */
 #define UEM_CONV_TRANSPOSED 8  /* gather of the data-gradient of a strided conv: shape describes the
                                   FORWARD conv, x is dY (N,Ho,Wo,Cout), y is dX (N,H,W,Cin), w is
                                   W'[Cin][KH][KW][Cout] (uem_weight_transpose of the forward weights) */
@@ -394,7 +394,8 @@ int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream);
  *   uem_wino_filter_grad dw (Cout,3,3,Cin) += G^T dU G                                                                   */
 int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, int m, void* stream);
 int uem_wino_input(const float* x, const float* in_scale, const float* in_shift, int relu, float* V, int N, int H, int W, int C,
-                   int dil, int m, void* stream);
+                   int dil, int m, int pass /* 0 forward, 1 data gradient (x = dY), 2 weight gradient recomputing V: same arithmetic,
+                   the kernel instantiation is named after the pass so that profiles attribute it */, void* stream);
 int uem_wino_gemm(const float* V, const float* U, float* M, int T, int K, int N, int npos /* 16 or 36 */,
                   int data_gradient /* 0 forward, 1: the same product through the data-gradient kernel instantiation */, void* stream);
 int uem_wino_output(const float* M, float* y, int N, int H, int W, int C, int dil, int m, float* tile_stats, const float* bn_z,

@@ -14,16 +14,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name):
-    """kernel name -> conv family, as ops.PROF attributes the launches (a Winograd conv is its transforms + its GEMM)"""
-    if "conv_wgrad_kernel" in name or "wgrad_dma_kernel" in name or "wino_dy_kernel" in name or "wino_filter_grad_kernel" in name:
+    """kernel name -> conv family, as ops.PROF attributes the launches (a Winograd conv is its transforms + its GEMM).  The Winograd
+    input transforms carry the pass in their template arguments (<AFFINE, PASS>: 0 forward, 1 data gradient, 2 weight gradient)."""
+    if "conv_wgrad_kernel" in name or "wgrad_dma_kernel" in name or re.search(r"wino4?_dy_kernel", name) or re.search(r"wino4?_filter_grad_kernel", name):
         return "conv_wgrad"
     m = re.search(r"conv_fwd_kernel<\d+, \d+, \d+, (\d)", name) or re.search(r"conv_dma_kernel<\d+, \d+, (\d)", name)   # <BN, KB, MODE, ...>
     if m:
         return "conv_dgrad" if m.group(1) == "1" else "conv_fwd"
-    m = re.search(r"wino_input_kernel<(\w+)>", name) or re.search(r"wino_filter_kernel<(\w+)>", name)
+    m = re.search(r"wino4?_input_kernel<\w+, (\d)>", name)
     if m:
-        return "conv_fwd" if m.group(1) in ("true", "1") and "wino_input" in name or m.group(1) in ("false", "0") and "wino_filter" in name else "conv_dgrad"
-    m = re.search(r"wino_output_kernel<(\d)>", name)
+        return ("conv_fwd", "conv_dgrad", "conv_wgrad")[int(m.group(1))]
+    m = re.search(r"wino4?_filter_kernel<(\w+)>", name)
+    if m:
+        return "conv_dgrad" if m.group(1) in ("true", "1") else "conv_fwd"
+    m = re.search(r"wino4?_output_kernel<(\d)>", name)      # <0>: plain (eval-mode forward; the PPM head's data gradient, counted as forward here)
     if m:
         return "conv_dgrad" if m.group(1) == "2" else "conv_fwd"
     return None

@@ -63,10 +63,11 @@ def test_conv_forward_dgrad_wgrad(case):
     torch.testing.assert_close(nchw(y2), 2 * y_ref.detach() - bias.view(1, -1, 1, 1), rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 6e-3)])
+@pytest.mark.parametrize("prec,tol", [("bf16", 6e-3)])
 @pytest.mark.parametrize("case", [CONV_CASES[1], CONV_CASES[2], CONV_CASES[3], CONV_CASES[5], CONV_CASES[6], CONV_CASES[8]])
-def test_conv_reduced_operand_modes(case, prec, tol):
-    """Opt-in matrix-core precisions: relative-L2 error of forward / data gradient / weight gradient against fp64."""
+def test_conv_bf16_operand_mode_of_the_bf16_storage_islands(case, prec, tol):
+    """bf16 operands over fp32 tensors (how a bf16-storage model runs its fp32 stem and heads): relative-L2 error of forward / data
+    gradient / weight gradient against fp64.  The split-operand modes of rounds 1-3 are retired (the C ABI rejects their flag)."""
     from uemda_amd import ops
     N, H, W, Cin, Cout, k, s, p, d = case
     g = torch.Generator().manual_seed(sum(case) + 1)
@@ -384,20 +385,7 @@ def _model(use_ppm=False, sd=None, **backbone):
     return m.cuda()
 
 
-@pytest.fixture
-def conv_precision(request):
-    from uemda_amd import ops
-    ops.set_conv_precision(request.param)
-    yield request.param
-    ops.set_conv_precision("fp32")
-
-
-# "bf16x3" (opt-in split-bf16 matrix-core mode): ~4e-6 per conv instead of ~3e-7, which this randomly initialised
-# network amplifies to 1.7e-3 on the logits -- over north_star's 1e-3, which is why exact fp32 is the default.  The mode
-# is held to a 5e-3 logit bar and the same pseudo-label agreement (scripts/precision_fullmodel_report.py).
-# "mixed" (fp32 forward, bf16x3 gradients) is held to every assertion of the fp32 default.
-@pytest.mark.parametrize("conv_precision", ["fp32", "mixed", "bf16x3"], indirect=True)
-def test_full_model_aspp_ssl_step_matches_reference_golden(conv_precision):
+def test_full_model_aspp_ssl_step_matches_reference_golden():
     from oracle import synth
     from oracle.weights import checksum, subsample
     from uemda_amd.gast.alignment import Aligner
@@ -422,13 +410,7 @@ def test_full_model_aspp_ssl_step_matches_reference_golden(conv_precision):
     for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
         ref = g[k]
         err = (out[k].cpu() - ref).abs().max() / ref.abs().max()
-        assert err < (5e-3 if conv_precision == "bf16x3" else 1e-3), (k, float(err))
-    if conv_precision == "bf16x3":
-        assert (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item() >= 0.9995
-        torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
-        torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)
-        torch.testing.assert_close(out["grad_norm"].cpu().reshape(()), g["grad_norm"], rtol=5e-3, atol=1e-4)
-        return
+        assert err < 1e-3, (k, float(err))
     torch.testing.assert_close(out["feat_t"].cpu().reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(out["label_t_soft"][:, :, ::4, ::4].cpu(), g["soft_sample"], rtol=1e-3, atol=1e-5)
     agree = (out["label_t_hard"].cpu() == g["hard"].long()).float().mean().item()
@@ -468,7 +450,8 @@ def test_full_model_aspp_ssl_step_b8_512_matches_reference_golden():
     model = _model(False)
     batch = {k: v.cuda() for k, v in synth.make_batch(B=8, H=512, W=512, C=C, k=2048, seed=2333).items()}
     plan = ops.wino_plan((8, 32, 32, 512), 512, 3, 3, 1, 2, 2)                    # the tile sizes this fixture exercises on layer4
-    assert (plan.mf, plan.mb) == (4 if ops.WINOGRAD_F4_FWD else 2, 4 if ops.WINOGRAD_F4_BWD else 2)
+    if ops.WINOGRAD:
+        assert (plan.mf, plan.mb) == (4 if ops.WINOGRAD_F4_FWD else 2, 4 if ops.WINOGRAD_F4_BWD else 2)
     al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
     al.prototypes = batch["prototypes"].clone()
     opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)

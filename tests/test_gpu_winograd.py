@@ -122,16 +122,31 @@ def test_winograd_fused_batchnorm_passes_match_the_direct_kernels(m, case):
     assert rel(dwa, dwb) < (5e-6 if m == 2 else 1e-5)
 
 
-def test_winograd_plans_and_declined_shapes():
+def test_winograd_plans_and_declined_shapes(monkeypatch):
     from uemda_amd import ops
-    f4f, f4b = ops.WINOGRAD_F4_FWD, ops.WINOGRAD_F4_BWD
-    assert ops.wino_plan((2, 16, 16, 64), 64, 3, 3, 1, 1, 1) is None               # narrow layer, too few 4x4 tiles: direct kernels
-    p = ops.wino_plan((2, 16, 16, 128), 128, 3, 3, 1, 1, 1)                       # layer2 at 256^2 tiles: F(2x2) forward + weight gradient
-    assert (p.mf, p.mb, p.dgrad, p.keep_v) == (2, 2, False, True)
-    p = ops.wino_plan((32, 128, 128, 64), 64, 3, 3, 1, 1, 1)                      # layer1 at the benchmark's size: F(4x4) or nothing
-    assert (p.mf, p.mb, p.dgrad) == (4 if f4f else 0, 4 if f4b else 0, f4b) if (f4f or f4b) else p is None
-    p = ops.wino_plan((8, 32, 32, 512), 512, 3, 3, 1, 2, 2)                       # layer4 (dilated) of the 512^2 fixture
-    assert (p.mf, p.mb, p.dgrad, p.keep_v) == (4 if f4f else 2, 4 if f4b else 2, True, f4f == f4b)
+    for k, v in dict(WINOGRAD=True, WINOGRAD_F4_FWD=True, WINOGRAD_F4_BWD=True, WINOGRAD_MIN_CH=128, WINOGRAD_MIN_CH_DGRAD=256,
+                     WINOGRAD_MIN_CH_F4=64, WINOGRAD_MIN_CH_F4_FWD=256).items():
+        monkeypatch.setattr(ops, k, v)                                            # the defaults, whatever the environment says
+
+    def plan(shape, cout, d=1):
+        p = ops.wino_plan(shape, cout, 3, 3, 1, d, d)
+        return None if p is None else (p.mf, p.mb, p.dgrad, p.wgrad, p.keep_v)
+    assert plan((2, 16, 16, 64), 64) is None                                      # narrow layer, too few 4x4 tiles: direct kernels
+    assert plan((2, 16, 16, 128), 128) == (2, 2, False, True, True)               # F(2x2) forward + weight gradient on the kept V
+    # the benchmark's shapes (B = 32, 512^2 tiles): layer1 backward only (data gradient), layer2 F(2x2) forward + F(4x4) backward
+    # recomputing V, layer3 / layer4 / the PPM head F(4x4) both ways sharing V
+    assert plan((32, 128, 128, 64), 64) == (0, 4, True, False, False)
+    assert plan((32, 64, 64, 128), 128) == (2, 4, True, True, False)
+    assert plan((32, 32, 32, 256), 256) == (4, 4, True, True, True)
+    assert plan((32, 32, 32, 512), 512, 2) == (4, 4, True, True, True)
+    assert plan((32, 32, 32, 4096), 512) == (4, 4, True, True, True)
+    assert plan((8, 32, 32, 512), 512, 2) == (4, 4, True, True, True)             # layer4 of the 512^2 reference fixture
+    monkeypatch.setattr(ops, "WINOGRAD_F4_FWD", False)
+    assert plan((32, 32, 32, 256), 256) == (2, 4, True, True, False)
+    monkeypatch.setattr(ops, "WINOGRAD_F4_BWD", False)
+    assert plan((32, 32, 32, 256), 256) == (2, 2, True, True, True) and plan((32, 128, 128, 64), 64) is None
+    monkeypatch.setattr(ops, "WINOGRAD_SAVE_V_BYTES", 1 << 20)                    # V over the byte cap: recomputed in backward
+    assert plan((32, 32, 32, 256), 256) == (2, 2, True, True, False)
     assert ops.wino_plan((2, 16, 16, 256), 256, 3, 3, 2, 1, 1) is None            # stride 2
     assert ops.wino_plan((2, 16, 16, 256), 256, 1, 1, 1, 0, 1) is None            # 1x1
     assert ops.wino_plan((2, 18, 18, 256), 256, 3, 3, 1, 2, 2) is None            # 18 is not a multiple of 2 * dilation

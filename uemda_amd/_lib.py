@@ -115,7 +115,7 @@ SIGNATURES = {
     "uem_cast_f32_bf16": [P, P, L, P],
     "uem_cast_bf16_f32": [P, P, L, P],
     "uem_wino_filter": [P, P, I, I, I, I, P],
-    "uem_wino_input": [P, P, P, I, P, I, I, I, I, I, I, P],
+    "uem_wino_input": [P, P, P, I, P, I, I, I, I, I, I, I, P],
     "uem_wino_gemm": [P, P, P, I, I, I, I, I, P],
     "uem_wino_output": [P, P, I, I, I, I, I, I, P, P, P, P, P],
     "uem_wino_dy": [P, P, I, I, I, I, I, I, P],
@@ -137,7 +137,7 @@ UEM_MAX_CLASSES = 16
 UEM_PROTO_SPLIT = 256
 UEM_NORM_BLOCKS = 1024
 CONV_IN_AFFINE, CONV_IN_RELU, CONV_ACCUMULATE, CONV_TRANSPOSED = 1, 2, 4, 8
-CONV_PREC_BF16X3, CONV_PREC_BF16 = 16, 32
+CONV_PREC_BF16 = 32
 
 
 class UemError(RuntimeError):

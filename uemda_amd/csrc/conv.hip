@@ -386,18 +386,11 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
             if constexpr (PREC == 0) {
                 *reinterpret_cast<float4*>(&stage[row * LDS_LD + lc4]) = v;
             } else {
-                // hi image in the first half of the stage, lo image in the second half ([rows][LDS_LDH] bf16 each)
+                // one bf16 image per stage ([rows][LDS_LDH])
                 __bf16* hi = reinterpret_cast<__bf16*>(stage);
                 bf16x4 h;
                 h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
                 *reinterpret_cast<bf16x4*>(&hi[row * LDS_LDH + lc4]) = h;
-                if constexpr (PREC == 1) {
-                    __bf16* lo = hi + (stage == As ? BM : BN) * LDS_LDH;
-                    bf16x4 l;
-                    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-                    l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-                    *reinterpret_cast<bf16x4*>(&lo[row * LDS_LDH + lc4]) = l;
-                }
             }
         };
 #pragma unroll
@@ -462,33 +455,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
         } else {
             // bf16 operand fragment of v_mfma_f32_32x32x16_bf16: lane (r = l&31, h = l>>5) holds row r, k = 8h..8h+7
             const __bf16* Ah = reinterpret_cast<const __bf16*>(As);
-            const __bf16* Al = Ah + BM * LDS_LDH;
             const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs);
-            const __bf16* Bl = Bh + BN * LDS_LDH;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+                bf16x8 ah[MT], bh[NT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int o = (wm + i * 32 + fr) * LDS_LDH + ks * 16 + fh * 8;
                     ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[o]);
-                    if constexpr (PREC == 1) al[i] = *reinterpret_cast<const bf16x8*>(&Al[o]);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int o = (wn + j * 32 + fr) * LDS_LDH + ks * 16 + fh * 8;
                     bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[o]);
-                    if constexpr (PREC == 1) bl[j] = *reinterpret_cast<const bf16x8*>(&Bl[o]);
-                }
-                if constexpr (PREC == 1) {              // small cross terms first, then the leading term
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -1301,20 +1280,17 @@ static int conv_launch(const ConvP& p, bool affine, hipStream_t st, int prec = 0
     const bool prefer64 = smallk_bn64 > 0 && p.ntaps * p.Cin <= smallk_bn64 && p.Cout % 64 == 0;
     if (p.Cout % 128 == 0 && !prefer64) {
         const int grid = tiles_m * (p.Cout / 128);
-        if (prec == 1) conv_go<128, 2, 2, MODE, 1, 1>(p, affine, grid, st);
-        else if (prec == 2) conv_go<128, 2, 2, MODE, 1, 2>(p, affine, grid, st);
+        if (prec == 2) conv_go<128, 2, 2, MODE, 1, 2>(p, affine, grid, st);
         else if (nbuf == 2) conv_go<128, 2, 2, MODE, 2, 0>(p, affine, grid, st);
         else conv_go<128, 2, 2, MODE, 1, 0>(p, affine, grid, st);
     } else if (p.Cout % 64 == 0) {
         const int grid = tiles_m * (p.Cout / 64);
-        if (prec == 1) conv_go<64, 2, 2, MODE, 1, 1>(p, affine, grid, st);
-        else if (prec == 2) conv_go<64, 2, 2, MODE, 1, 2>(p, affine, grid, st);
+        if (prec == 2) conv_go<64, 2, 2, MODE, 1, 2>(p, affine, grid, st);
         else if (nbuf == 2) conv_go<64, 2, 2, MODE, 2, 0>(p, affine, grid, st);
         else conv_go<64, 2, 2, MODE, 1, 0>(p, affine, grid, st);
     } else {
         const int grid = tiles_m * (int)uem_cdiv(p.Cout, 32);
-        if (prec == 1) conv_go<32, 4, 1, MODE, 1, 1>(p, affine, grid, st);
-        else if (prec == 2) conv_go<32, 4, 1, MODE, 1, 2>(p, affine, grid, st);
+        if (prec == 2) conv_go<32, 4, 1, MODE, 1, 2>(p, affine, grid, st);
         else conv_go<32, 4, 1, MODE, 1, 0>(p, affine, grid, st);
     }
     return uem_check_launch("conv2d");
@@ -1335,7 +1311,7 @@ extern "C" int uem_conv2d_dgrad_bnbwd(const float* dy, const float* w_t, float* 
     if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin)
         return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_bnbwd: needs stride 1, M %% 128 == 0, Cin %% 64 == 0");
     BnBwdFuse f{bn_z, bn_vec, tile_partials, nullptr, nullptr, nullptr};
-    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_dgrad_bnbwd: only precision flags are accepted");
+    UEM_REQUIRE((flags & ~UEM_CONV_PREC_BF16) == 0, "conv2d_dgrad_bnbwd: only precision flags are accepted");
     return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED | flags, nullptr, &f, stream);
 }
 extern "C" int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* dx, const uem_conv_shape* s, const float* acc_src,
@@ -1347,7 +1323,7 @@ extern "C" int uem_conv2d_dgrad_tail(const float* dy, const float* w_t, float* d
                 "conv2d_dgrad_tail: bn_z, bn_vec and tile_partials go together");
     if (s->stride != 1 || ((int64_t)s->N * s->H * s->W) % 128 != 0 || s->Cin % 64 != 0 || s->x_ld != s->Cin || s->Cin % 32 != 0)
         return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_dgrad_tail: needs stride 1, M %% 128 == 0, Cin %% 64 == 0, dense rows");
-    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16 | UEM_CONV_ACCUMULATE)) == 0, "conv2d_dgrad_tail: bad flags");
+    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16 | UEM_CONV_ACCUMULATE)) == 0, "conv2d_dgrad_tail: bad flags");
     BnBwdFuse f{bn_z, bn_vec, tile_partials, acc_src, acc_bits, bn_bits};
     return conv2d_fwd_impl(dy, w_t, nullptr, nullptr, nullptr, dx, s, UEM_CONV_TRANSPOSED | flags | (acc_src ? UEM_CONV_ACCUMULATE : 0),
                            nullptr, &f, stream);
@@ -1366,9 +1342,10 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     UEM_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
     int rc = conv_check(s);
     if (rc) return rc;
+    UEM_REQUIRE(!(flags & 16), "conv2d: flag 16 (the split-bf16 operand mode of rounds 1-3) is retired");
     const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
     const bool transposed = (flags & UEM_CONV_TRANSPOSED) != 0;
-    const int prec = (flags & UEM_CONV_PREC_BF16X3) ? 1 : ((flags & UEM_CONV_PREC_BF16) ? 2 : 0);
+    const int prec = (flags & UEM_CONV_PREC_BF16) ? 2 : 0;
     UEM_REQUIRE(!affine || (in_scale && in_shift), "conv2d_fwd: affine prologue needs scale/shift");
     UEM_REQUIRE(!(affine && transposed), "conv2d_fwd: prologue not supported on the transposed gather");
     ConvP p;
@@ -1452,7 +1429,7 @@ extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, i
 extern "C" int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags,
                                          void* stream) {
     UEM_REQUIRE(tile_stats, "conv2d_stem_fwd_stats: null pointer");
-    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_stem_fwd_stats: only precision flags are accepted");
+    UEM_REQUIRE((flags & ~UEM_CONV_PREC_BF16) == 0, "conv2d_stem_fwd_stats: only precision flags are accepted");
     const int64_t M = (int64_t)N * ((H + 6 - 7) / 2 + 1) * ((W + 6 - 7) / 2 + 1);
     if (M % 128 != 0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_stem_fwd_stats: needs N*Ho*Wo %% 128 == 0");
     return stem_fwd_impl(x4, w8, y, N, H, W, tile_stats, flags, stream);
@@ -1467,7 +1444,7 @@ static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int 
     p.accumulate = 0; p.relu = 0; p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0; p.dbg = 0; p.wg_rows = 0; p.wg_stride = 0;
     p.M = N * p.Ho * p.Wo;
-    return conv_launch<2>(p, false, (hipStream_t)stream, (flags & UEM_CONV_PREC_BF16) ? 2 : ((flags & UEM_CONV_PREC_BF16X3) ? 1 : 0));
+    return conv_launch<2>(p, false, (hipStream_t)stream, (flags & UEM_CONV_PREC_BF16) ? 2 : 0);
 }
 
 // =========================================================================================================
@@ -1511,7 +1488,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
     constexpr int MT = TM / WM / 32, NT = TN / WN / 32;
     constexpr int DTPR = TM / 4, DRPP = 256 / DTPR, DPASS = (BK + DRPP - 1) / DRPP;   // dY loader
     constexpr int XTPR = TN / 4, XRPP = 256 / XTPR, XPASS = (BK + XRPP - 1) / XRPP;   // X loader
-    constexpr int NIMG = PREC == 1 ? 2 : 1;                                            // hi (+ lo) images
+    constexpr int NIMG = 1;                                                            // one bf16 image per operand
     constexpr int LDD = TM * 2 + (TM >= 64 ? 64 : 0), LDX = TN * 2 + (TN >= 64 ? 64 : 0);   // bf16 image row bytes
     constexpr int D_BYTES = PREC == 0 ? BK * TM * 4 : NIMG * BK * LDD;
     constexpr int X_BYTES = PREC == 0 ? BK * TN * 4 : NIMG * BK * LDX;
@@ -1598,12 +1575,6 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
         bf16x4 h;
         h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(img + r * ld + 2 * c4) = h;
-        if constexpr (PREC == 1) {
-            bf16x4 l;
-            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
-            l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-            *reinterpret_cast<bf16x4*>(img + BK * ld + r * ld + 2 * c4) = l;
-        }
     };
     auto store_tiles = [&]() {
 #pragma unroll
@@ -1688,27 +1659,11 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
 #pragma unroll
                 for (int ks = 0; ks < KPW / 16; ++ks) {
                     const int k0 = wk * KPW + ks * 16 + 8 * fh;
-                    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+                    bf16x8 ah[MT], bh[NT];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        ah[i] = lds_tr_frag(Dsm, LDD, k0, wm + i * 32, lane);
-                        if constexpr (PREC == 1) al[i] = lds_tr_frag(Dsm + BK * LDD, LDD, k0, wm + i * 32, lane);
-                    }
+                    for (int i = 0; i < MT; ++i) ah[i] = lds_tr_frag(Dsm, LDD, k0, wm + i * 32, lane);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        bh[j] = lds_tr_frag(Xsm, LDX, k0, wn + j * 32, lane);
-                        if constexpr (PREC == 1) bl[j] = lds_tr_frag(Xsm + BK * LDX, LDX, k0, wn + j * 32, lane);
-                    }
-                    if constexpr (PREC == 1) {
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NT; ++j) bh[j] = lds_tr_frag(Xsm, LDX, k0, wn + j * 32, lane);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1819,18 +1774,16 @@ extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in
     p.Cout = s->Cout; p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.x_ld = s->x_ld; p.dy_ld = s->y_ld; p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0; p.rows_per_split = 0;
     hipStream_t st = (hipStream_t)stream;
-    const int prec = (flags & UEM_CONV_PREC_BF16X3) ? 1 : ((flags & UEM_CONV_PREC_BF16) ? 2 : 0);
+    UEM_REQUIRE(!(flags & 16), "conv2d_wgrad: flag 16 (the split-bf16 operand mode of rounds 1-3) is retired");
+    const int prec = (flags & UEM_CONV_PREC_BF16) ? 2 : 0;
     if (s->Cout % 128 == 0 && s->Cin % 128 == 0) {
-        if (prec == 1) wgrad_go<128, 128, 2, 2, 1, 0, 1>(p, affine, st);
-        else if (prec == 2) wgrad_go<128, 128, 2, 2, 1, 0, 2>(p, affine, st);
+        if (prec == 2) wgrad_go<128, 128, 2, 2, 1, 0, 2>(p, affine, st);
         else wgrad_go<128, 128, 2, 2, 1, 0>(p, affine, st);
     } else if (s->Cout % 64 == 0 && s->Cin % 64 == 0) {
-        if (prec == 1) wgrad_go<64, 64, 2, 2, 1, 0, 1>(p, affine, st);
-        else if (prec == 2) wgrad_go<64, 64, 2, 2, 1, 0, 2>(p, affine, st);
+        if (prec == 2) wgrad_go<64, 64, 2, 2, 1, 0, 2>(p, affine, st);
         else wgrad_go<64, 64, 2, 2, 1, 0>(p, affine, st);
     } else if (s->Cin % 128 == 0) {
-        if (prec == 1) wgrad_go<32, 128, 1, 4, 1, 0, 1>(p, affine, st);
-        else if (prec == 2) wgrad_go<32, 128, 1, 4, 1, 0, 2>(p, affine, st);
+        if (prec == 2) wgrad_go<32, 128, 1, 4, 1, 0, 2>(p, affine, st);
         else wgrad_go<32, 128, 1, 4, 1, 0>(p, affine, st);
     } else wgrad_go<32, 32, 1, 1, 4, 0>(p, affine, st);      // tiny filters: always exact fp32
     return uem_check_launch("conv2d_wgrad");
@@ -1841,7 +1794,7 @@ extern "C" int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw
     return stem_wgrad_impl(x4, dy, dw8, N, H, W, 0, stream);
 }
 extern "C" int uem_conv2d_stem_wgrad_prec(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream) {
-    UEM_REQUIRE((flags & ~(UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) == 0, "conv2d_stem_wgrad_prec: only precision flags are accepted");
+    UEM_REQUIRE((flags & ~UEM_CONV_PREC_BF16) == 0, "conv2d_stem_wgrad_prec: only precision flags are accepted");
     return stem_wgrad_impl(x4, dy, dw8, N, H, W, flags, stream);
 }
 static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream) {
@@ -1852,7 +1805,6 @@ static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, 
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.dy_ld = 64; p.relu = 0; p.rows_per_split = 0;
     p.M = N * p.Ho * p.Wo;
     if (flags & UEM_CONV_PREC_BF16) wgrad_go<64, 32, 2, 1, 2, 2, 2>(p, false, (hipStream_t)stream);
-    else if (flags & UEM_CONV_PREC_BF16X3) wgrad_go<64, 32, 2, 1, 2, 2, 1>(p, false, (hipStream_t)stream);
     else wgrad_go<64, 32, 2, 1, 2, 2>(p, false, (hipStream_t)stream);
     return uem_check_launch("conv2d_stem_wgrad");
 }

@@ -537,7 +537,7 @@ int uem_wgrad_dma_try(const float* x, const float* dy, const float* in_scale, co
     static const int off = getenv("UEM_WGRAD_DMA") ? !atoi(getenv("UEM_WGRAD_DMA")) : 0;
     if (off) return 0;
     const bool affine = (flags & UEM_CONV_IN_AFFINE) != 0;
-    if (flags & (UEM_CONV_PREC_BF16X3 | UEM_CONV_PREC_BF16)) return 0;
+    if (flags & UEM_CONV_PREC_BF16) return 0;
     if (affine && !(flags & UEM_CONV_IN_RELU)) return 0;
     if (s->Cout % 64 != 0 || s->Cin % 64 != 0 || s->x_ld % 4 != 0 || s->y_ld % 4 != 0) return 0;
     if (((uintptr_t)x | (uintptr_t)dy) & 15) return 0;

@@ -53,7 +53,9 @@ __device__ __forceinline__ float4 f4neg(const float4 a) { return make_float4(-a.
 __device__ __forceinline__ float4 f4half(const float4 a) { return make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * a.z, 0.5f * a.w); }
 
 // block = 16 channel quads (64 channels) x 16 tiles; grid = (T / 16, C / 64)
-template <bool AFFINE>
+// PASS (0 forward, 1 data gradient, 2 weight gradient recomputing V) changes nothing but the kernel's NAME: profiles attribute the
+// launch to the family it belongs to (the PPM head's forward transform has no affine prologue either)
+template <bool AFFINE, int PASS>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
     const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int tile = blockIdx.x * 16 + tl;
@@ -349,7 +351,7 @@ __device__ __forceinline__ void f4mac(float4& acc, bool& first, const float k, c
 
 // V = B^T d B; block = 16 channel quads (64 channels) x 16 tiles; grid = (T / 16, C / 64).  A window column is transformed as soon as
 // it is loaded, so 36 (not 72) float4 stay live.
-template <bool AFFINE>
+template <bool AFFINE, int PASS>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const WinoP p) {
     const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int tile = blockIdx.x * 16 + tl;
@@ -618,23 +620,31 @@ static int wino_geometry(WinoP& p, int N, int H, int W, int C, int d, int m, con
     return UEM_OK;
 }
 
+template <int PASS>
+static void wino_input_go(const WinoP& p, int m, bool affine, dim3 grid, hipStream_t st) {
+    if (m == 2) {
+        if (affine) wino_input_kernel<true, PASS><<<grid, 256, 0, st>>>(p);
+        else wino_input_kernel<false, PASS><<<grid, 256, 0, st>>>(p);
+    } else {
+        if (affine) wino4_input_kernel<true, PASS><<<grid, 256, 0, st>>>(p);
+        else wino4_input_kernel<false, PASS><<<grid, 256, 0, st>>>(p);
+    }
+}
+
 extern "C" int uem_wino_input(const float* x, const float* in_scale, const float* in_shift, int relu, float* V, int N, int H, int W,
-                              int C, int dil, int m, void* stream) {
+                              int C, int dil, int m, int pass, void* stream) {
     UEM_REQUIRE(x && V, "wino_input: null pointer");
     UEM_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wino_input: scale and shift go together");
+    UEM_REQUIRE(pass >= 0 && pass <= 2, "wino_input: pass is 0 (forward), 1 (data gradient) or 2 (weight gradient)");
     WinoP p;
     const int rc = wino_geometry(p, N, H, W, C, dil, m, "wino_input");
     if (rc) return rc;
     p.x = x; p.v = V; p.scale = in_scale; p.shift = in_shift; p.relu = relu;
     const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
     hipStream_t st = (hipStream_t)stream;
-    if (m == 2) {
-        if (in_scale) wino_input_kernel<true><<<grid, 256, 0, st>>>(p);
-        else wino_input_kernel<false><<<grid, 256, 0, st>>>(p);
-    } else {
-        if (in_scale) wino4_input_kernel<true><<<grid, 256, 0, st>>>(p);
-        else wino4_input_kernel<false><<<grid, 256, 0, st>>>(p);
-    }
+    if (pass == 0) wino_input_go<0>(p, m, in_scale != nullptr, grid, st);
+    else if (pass == 1) wino_input_go<1>(p, m, in_scale != nullptr, grid, st);
+    else wino_input_go<2>(p, m, in_scale != nullptr, grid, st);
     return uem_check_launch("wino_input");
 }
 

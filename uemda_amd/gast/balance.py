@@ -92,7 +92,8 @@ class ClassBalance(nn.Module):
         return self._freq_from_counts(self._class_counts(label))
 
     def ema_update(self, label):
-        self.freq = (1.0 - self.decay) * self._local_freq(label) + self.decay * self.freq
+        # in place (balance.py:55-61 rebinds; same values): a step replayed from a hipGraph reads self.freq at its capture-time address
+        self.freq.mul_(self.decay).add_(self._local_freq(label), alpha=1.0 - self.decay)
 
     def _get_class_wight(self):
         prob = torch.softmax((1.0 - self.freq) / self.temperature, dim=0)

@@ -216,8 +216,10 @@ class BottleneckFn(Function):
             mb = plan.mb
             if plan.keep_v:
                 ops.conv3x3_wino_wgrad(sv[-1], dz2, G(blk.conv2.weight), d)
-            else:
+            elif plan.wgrad:
                 ops.conv3x3_wino_wgrad(None, dz2, G(blk.conv2.weight), d, x=z1, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, m=mb)
+            else:
+                ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
             if not plan.dgrad:
                 dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose_cached(blk.conv2.weight), z1, st1, gb(blk.bn1.weight),
                                                    gb(blk.bn1.bias), stride=s, pad=d, dil=d)

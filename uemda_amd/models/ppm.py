@@ -169,8 +169,10 @@ class PPMHeadFn(Function):
         if plan is not None and plan.mb:
             if plan.keep_v:
                 ops.conv3x3_wino_wgrad(cat, dzc, grad_ohwi(conv0.weight), 1)        # `cat` is the saved transformed input here
-            else:
+            elif plan.wgrad:
                 ops.conv3x3_wino_wgrad(None, dzc, grad_ohwi(conv0.weight), 1, x=cat, m=plan.mb)
+            else:
+                ops.conv2d_wgrad(cat, dzc, grad_ohwi(conv0.weight), pad=1)
             if plan.dgrad:
                 dcat, _ = ops.conv3x3_wino_dgrad(dzc, conv0.weight, 1, m=plan.mb)
             else:

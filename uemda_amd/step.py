@@ -128,9 +128,11 @@ class GraphedStep:
         out = gs(lr)            # writes lr into the device scalar the captured optimizer launch reads, replays; `out` = the step's
                                 # dict of STATIC tensors (overwritten by the next replay)
 
-    Requirements: inputs are the same device tensors every step (copy new data INTO `batch`), single process (the gradient
-    collective is not captured), FusedSGD, at least one optimizer step taken before (the first step initialises the momentum buffer
-    through a by-value flag).  The superpixel-table overflow flag stays on the device while capturing
+    Requirements: inputs are the same device tensors every step (copy new data INTO `batch`), FusedSGD, at least one optimizer step
+    taken before (the first step initialises the momentum buffer through a by-value flag).  Host-side logic of the step function runs
+    ONCE, at capture: only state that is updated IN PLACE on the device survives replay (a rebound tensor -- `x = f(x)` -- would be
+    read at its capture-time address for ever; ClassBalance's frequency EMA is in place for that reason), `param_groups['lr']` is not
+    read again (the learning rate travels through the device scalar), and per-launch event timing (`ops.PROF`) must be off.  The superpixel-table overflow flag stays on the device while capturing
     (`aligner.last_superpixel_range_flag`); `check()` reads it (a host sync: call it now and then, not every step).  The PPM heads'
     Dropout2d draws its masks from torch's graph-safe generator while capturing (models/ppm.py), a fresh mask per replay."""
 
@@ -142,6 +144,9 @@ class GraphedStep:
             raise UemError("GraphedStep needs uemda_amd.optim.FusedSGD (the learning rate travels as a device scalar)")
         if kw.get("dp") is not None:
             raise UemError("GraphedStep captures a single-process step (the gradient all-reduce is not captured)")
+        from . import ops
+        if ops.PROF.enabled:
+            raise UemError("GraphedStep: per-launch event timing (ops.PROF.enabled) cannot be captured; switch it off first")
         self.aligner, self.optimizer = aligner, optimizer
         self.lr = torch.full((1,), float(lr), device=next(model.parameters()).device, dtype=torch.float32)
         optimizer.lr_device = self.lr
@@ -157,12 +162,20 @@ class GraphedStep:
                 run()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        steps_before = optimizer._steps
         with torch.cuda.graph(self.graph):
             self.out = run()
+        optimizer._steps = steps_before                  # the capture pass ran the host side of step() without taking a step
+
+    def _after_replay(self):
+        from . import ops
+        self.optimizer._steps += 1
+        ops.weights_changed()                            # cached filter banks (transposed, Winograd) follow the replayed optimizer
 
     def __call__(self, lr):
         self.lr.fill_(float(lr))
         self.graph.replay()
+        self._after_replay()
         return self.out
 
     def check(self):
