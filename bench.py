@@ -275,6 +275,8 @@ def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
     try:
         from uemda_amd.step import GraphedStep, ssl_step as _ssl, src_step as _src
         kw = dict(sup_ignore_id=s.sup_ignore) if workload == "ssl" else {}
+        if s.wrapper is not None:
+            kw["dp"] = s.wrapper                   # the data-parallel step: RCCL's all-reduces are captured with it
         gs = GraphedStep(_ssl if workload == "ssl" else _src, s.model, s.aligner if workload == "ssl" else None, s.opt, s.state,
                          s.batch, warmup=1, lr=s.lr_at(step0), **kw)
         gs(s.lr_at(step0))
@@ -288,8 +290,8 @@ def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
         gs.check()
         leg = dict(value=round(tiles_per_step / dt, 3), unit="tiles/s", ms_per_step=round(1e3 * dt, 2), steps=nrep,
                    host_ms_per_step=round(1e3 * t_host, 3),
-                   note="the whole step (2 forwards, mining, losses, backward, clip + SGD) as ONE hipGraph launch per step; lr "
-                        "travels as a device scalar")
+                   note="the whole step (2 forwards, mining, losses, backward, " + ("gradient all-reduce, " if s.wrapper is not None else "") +
+                        "clip + SGD) as ONE hipGraph launch per step; lr travels as a device scalar")
         del gs
     except Exception as e:                    # noqa: BLE001
         leg = dict(error=repr(e)[:300])
@@ -355,7 +357,8 @@ def main():
                     help="bf16: activations / weight copies of the encoder stored in bf16, bf16 matrix cores (BASELINE config 5)")
     ap.add_argument("--no-other-precisions", action="store_true", help="accepted and ignored (the operand-precision legs are retired)")
     ap.add_argument("--unique-batches", type=int, default=2, help="distinct seeded batches alternating step by step")
-    ap.add_argument("--no-hipgraph", action="store_true", help="skip the short leg that replays the step as one hipGraph (N=1 only)")
+    ap.add_argument("--no-hipgraph", action="store_true", help="skip the short leg that replays the step as one hipGraph")
+    ap.add_argument("--hipgraph-dp", action="store_true", help="run the hipGraph leg under data parallel too (nccl backend: the all-reduces are captured)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configurations (bf16 storage, PPM head, R101 1024^2; N=1 only)")
     args = ap.parse_args()
@@ -461,7 +464,9 @@ def main():
     ops.PROF.records = []
 
     graph_leg = None
-    if world == 1 and wrapper is None and not args.no_hipgraph:           # (the data-parallel step holds RCCL calls: not captured)
+    # data parallel: RCCL's all-reduces are captured with the step (GraphedStep(dp=...)); under N > 1 the leg is opt-in (--hipgraph-dp):
+    # a capture that fails on one rank only would leave the others waiting in a collective, and no multi-GPU box exists to rehearse it
+    if not args.no_hipgraph and (wrapper is None or (args.hipgraph_dp and wrapper.capturable)):
         graph_leg = replay_leg(s, args.workload, args.warmup + args.steps, tiles_per_step)
         if rank == 0:
             note(f"hipGraph replay: {graph_leg}")
@@ -500,8 +505,7 @@ def main():
                                    f"{len(s.batches)} distinct batches alternate step by step; the last timed step also records "
                                    f"per-launch HIP events (about 1 ms of command-processor bubbles)",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
-                       "collective": None if wrapper is None else ("uem_allreduce_flat (RCCL through the C ABI)" if wrapper.native
-                                                                   is not None else f"torch.distributed {args.backend}"),
+                       "collective": None if wrapper is None else f"torch.distributed {args.backend}",
                        "collective_bytes_per_step": None if wrapper is None else arena_bytes + 4 * (6 * 2048 + 6),
                        "host_cores_per_rank": cores},
             "loss_source": round(float(out["loss_source"]), 5),

@@ -65,13 +65,44 @@ def test_single_rank_rccl_step_matches_plain_step():
     assert forced["loss_source"] == pytest.approx(plain["loss_source"], rel=1e-4)
 
 
-def test_single_rank_native_rccl_allreduce_through_the_c_abi():
-    """uem_comm_unique_id / uem_comm_init / uem_allreduce_flat (SURVEY 8b `allreduce_flat`) driving the same DataParallel
-    object: one rank, so the collective is trivial, but it is RCCL on a stream of ours, loaded from the host process."""
-    plain = _bench({})
-    native = _bench({"UEM_DP_FORCE": "1", "UEM_DP_NATIVE": "1", "MASTER_PORT": str(_free_port())})
-    assert native["n_gpus"] == 1 and native["config"]["collective"] == "uem_allreduce_flat (RCCL through the C ABI)"
-    assert native["loss_source"] == pytest.approx(plain["loss_source"], rel=1e-4)
+def test_single_rank_rccl_allreduce_through_the_c_abi():
+    """uem_comm_unique_id / uem_comm_init / uem_allreduce_flat / uem_comm_destroy (SURVEY 8b `allreduce_flat`), the C ABI's own
+    collective for hosts without torch.distributed: one rank (RCCL refuses two on one device), so the sum is the buffer itself, but it
+    is RCCL on a stream of the caller's choosing, loaded from the host process.  In a child process: the test process keeps no
+    communicator."""
+    code = (
+        "import ctypes, torch\n"
+        "from uemda_amd._lib import call\n"
+        "ident = ctypes.create_string_buffer(128)\n"
+        "call('uem_comm_unique_id', ident)\n"
+        "h = ctypes.c_void_p()\n"
+        "call('uem_comm_init', ctypes.byref(h), ident.raw, 0, 1)\n"
+        "x = torch.randn(1 << 20, device='cuda'); ref = x.clone()\n"
+        "st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())\n"
+        "call('uem_allreduce_flat', h, x.data_ptr(), x.numel(), st.cuda_stream)\n"
+        "st.synchronize()\n"
+        "assert torch.equal(x, ref)\n"
+        "call('uem_comm_destroy', h)\n"
+        "print('ALLREDUCE_OK')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ALLREDUCE_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_single_rank_rccl_graphed_data_parallel_step():
+    """GraphedStep(dp=wrapper) over the nccl (= RCCL) backend: the early tail-bucket all-reduce and the head all-reduce are captured
+    with the step.  One rank (one device), real RCCL launches inside the graph; each replay against an eager data-parallel step
+    from the same complete state (scripts/dp_graph_check.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), UEM_DP_FORCE="1",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dp_graph_check.py")], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    # and the gloo group (host round trip) is refused up front, not captured wrongly
+    env["UEM_DP_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dp_graph_check.py")], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "DP_GRAPH_REFUSED" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
 
 
 def test_two_rank_data_parallel_object(tmp_path):

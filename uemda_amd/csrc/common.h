@@ -55,6 +55,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Hardware transcendental forms for the HBM-bound per-pixel kernels (mining, losses), which were VALU-bound on the IEEE forms: a
+// correctly rounded `a / b` is ~10 VALU instructions, expf / logf ~12-15, powf ~40; label_refine spent ~900 instructions per pixel on
+// 42 divisions and 18 expf against 56 bytes of traffic.  v_rcp_f32 / v_exp_f32 / v_log_f32 are accurate to 1 ulp of their own result;
+// the argument scaling of exp adds |x| * 6e-8 relative (x <= 0 everywhere here: softmax shifts), far inside the 1e-5 / 2e-5 bars the
+// parity tests hold these kernels to.
+__device__ __forceinline__ float fast_rcp(const float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp(const float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_log(const float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+// x^p for x in [0, 1], p > 0:  0^p = 0 (log2(0) = -inf, exp2(-inf) = 0), 1^p = 1 exactly
+__device__ __forceinline__ float fast_pow01(const float x, const float p) { return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)); }
+
 // order-preserving float <-> uint key (key(a) < key(b)  <=>  a < b); key 0 is below every float.
 __device__ __forceinline__ uint32_t f2key(float f) {
     uint32_t u = __float_as_uint(f);
@@ -70,6 +81,23 @@ struct Lerp {
     int i0, i1;
     float l0, l1;
 };
+// align_corners=True form with the scale (in-1)/(out-1) computed once by the caller: the same arithmetic as lerp_setup(.., true)
+__device__ __forceinline__ float lerp_scale_ac(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+__device__ __forceinline__ Lerp lerp_ac(int dst, int in_size, float scale) {
+    const float src = scale * (float)dst;
+    int i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    Lerp r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    float l1 = src - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    r.l1 = l1;
+    r.l0 = 1.f - l1;
+    return r;
+}
 __device__ __forceinline__ Lerp lerp_setup(int dst, int in_size, int out_size, bool align_corners) {
     float src;
     if (align_corners) {

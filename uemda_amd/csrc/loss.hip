@@ -29,11 +29,11 @@ __device__ __forceinline__ void softmax_ce(float (&v)[CMAX], int C, int label, f
     for (int c = 0; c < CMAX; ++c) if (c < C) m = fmaxf(m, v[c]);
     float s = 0.f, vl = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) { if (c == label) vl = v[c]; v[c] = expf(v[c] - m); s += v[c]; }
-    const float inv = 1.0f / s;
+    for (int c = 0; c < CMAX; ++c) if (c < C) { if (c == label) vl = v[c]; v[c] = fast_exp(v[c] - m); s += v[c]; }
+    const float inv = fast_rcp(s);
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) if (c < C) v[c] *= inv;
-    ce = (label >= 0) ? -(vl - m - logf(s)) : 0.f;
+    ce = (label >= 0) ? -(vl - m - fast_log(s)) : 0.f;
 }
 
 __device__ __forceinline__ float uvem_weight_dev(float u, float m, float t, float inv_gamma) {
@@ -43,14 +43,14 @@ __device__ __forceinline__ float uvem_weight_dev(float u, float m, float t, floa
         float x = (u <= m && u >= 0.f) ? u : 1.0f;
         float q = (-1.0f / (m * m)) * ((x - m) * (x - m)) + 1.0f;
         q = fminf(fmaxf(q, 0.f), 1.f);
-        left = powf(q, inv_gamma);
+        left = fast_pow01(q, inv_gamma);
     }
     float right = 0.f;
     if (m < t) {
         float x = (u > m && u <= t) ? u : 0.f;
         float q = (-1.0f / ((t - m) * (t - m))) * ((x - m) * (x - m)) + 1.0f;
         q = fminf(fmaxf(q, 0.f), 1.f);
-        right = powf(q, inv_gamma);
+        right = fast_pow01(q, inv_gamma);
     }
     float wgt = (u <= m) ? left : right;
     return (u >= t) ? 0.f : wgt;
@@ -100,10 +100,11 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
     while (ya <= yb && lerp_setup(ya, h, H, true).i0 != cy) ++ya;
     while (yb >= ya && lerp_setup(yb, h, H, true).i0 != cy) --yb;
     float* wacc = acc + (size_t)wave * 4 * w * CMAX;
+    const float sy = lerp_scale_ac(h, H), sx = lerp_scale_ac(w, W);     // hoisted: one division per block instead of one per pixel
     float loss1 = 0.f, loss2 = 0.f, valid = 0.f;
     struct Px { int64_t lab; float q[CMAX]; float pw; };
     for (int X = tid; X < W; X += LOSS_THREADS) {
-        const Lerp lx = lerp_setup(X, w, W, true);
+        const Lerp lx = lerp_ac(X, w, sx);
         const float* L00 = low + (size_t)lx.i0 * CMAX;                 // head 0, row 0
         const float* L01 = low + (size_t)lx.i1 * CMAX;
         // x-interpolated logits of the band's two rows (constant down the column): top/bot [head][class]
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
         if (ya <= yb) fetch(ya, cur);
         for (int Y = ya; Y <= yb; ++Y) {
             if (Y < yb) fetch(Y + 1, nxt);                            // next row's loads fly during this row's math
-            const Lerp ly = lerp_setup(Y, h, H, true);
+            const Lerp ly = lerp_ac(Y, h, sy);
             const int64_t lab64 = cur.lab;
             const bool lab_ok = (lab64 != ignore) && lab64 >= 0 && lab64 < C;
             const int lab = lab_ok ? (int)lab64 : -1;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
                 float u = 0.f;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
-                    if (c < C) { const float q = cur.q[c]; u += -q * logf(q); }
+                    if (c < C) { const float q = cur.q[c]; u += -q * fast_log(q); }
                 const bool gate = !(u > ut);                          // ce[u > t] = 0
                 pw = gate ? uvem_weight_dev(u, um, ut, inv_gamma) : 0.f;
                 if ((u <= ut) && lab64 != ignore) valid += 1.f;

@@ -164,7 +164,12 @@ extern "C" int uem_index_max(const int64_t* idx, int64_t count, int64_t* out, vo
 // an LDS open-addressing table (key = id) absorbs the per-pixel atomics, then one global
 // atomicMax per (segment, class) per tile.  Overflowing ids fall back to direct global atomics.
 // ================================================================================================
-#define SEG_SLOTS 128
+#define SEG_SLOTS 256
+#define SEG_ROWS 16
+// Block = 256 columns x SEG_ROWS rows.  A thread walks ONE column down the tile and keeps the running maximum of the segment it is
+// in (superpixels are spatially compact: a column of 16 pixels crosses one or two of them), so the LDS table sees one update per
+// (column, segment run) instead of one per pixel: the round-3 kernel issued 6 LDS atomics per pixel, 16 lanes of every wave on the
+// same address (148 us for 268 MB at B = 32: LDS-atomic bound at 1.8 TB/s).  Rows of a plane are read coalesced (lanes = columns).
 template <int CMAX>
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ soft,
                                                           const int64_t* __restrict__ sup,
@@ -180,38 +185,58 @@ __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restric
     }
     __syncthreads();
     const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (tid & 63);
+    const int x = blockIdx.x * 256 + tid;
+    const int y0 = blockIdx.y * SEG_ROWS;
     const size_t plane = (size_t)H * W;
     const float* sb = soft + (size_t)b * C * plane;
     const int64_t* ib = sup + (size_t)b * plane;
     uint32_t* segb = seg + (size_t)b * S * C;
     int bad = 0;                                        // largest id outside [0, S) seen by this thread (negative ids count as INT_MAX)
+    int cur_id = -1;                                    // segment of the current run (-1: none / out of range)
+    uint32_t cur[CMAX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int y = blockIdx.y * 16 + (tid >> 6) + 4 * j;
-        if (x < W && y < H) {
-            const size_t p = (size_t)y * W + x;
-            const int64_t id64 = ib[p];
-            const int id = (int)id64;
-            if (id64 < 0 || id64 >= (int64_t)S) bad = max(bad, id64 < 0 || id64 > 0x7fffffffLL ? 0x7fffffff : id);
-            else {
-                uint32_t hsh = ((uint32_t)id * 2654435761u) >> 25;   // 7 bits
-                int slot = -1;
-                for (int probe = 0; probe < SEG_SLOTS; ++probe) {
-                    int prev = atomicCAS(&keys[hsh], -1, id);
-                    if (prev == -1 || prev == id) { slot = (int)hsh; break; }
-                    hsh = (hsh + 1) & (SEG_SLOTS - 1);
-                }
+    for (int c = 0; c < CMAX; ++c) cur[c] = 0u;
+    auto flush = [&]() {
+        if (cur_id < 0) return;
+        uint32_t hsh = ((uint32_t)cur_id * 2654435761u) >> 24;       // 8 bits
+        int slot = -1;
+        for (int probe = 0; probe < SEG_SLOTS; ++probe) {
+            const int prev = atomicCAS(&keys[hsh], -1, cur_id);
+            if (prev == -1 || prev == cur_id) { slot = (int)hsh; break; }
+            hsh = (hsh + 1) & (SEG_SLOTS - 1);
+        }
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) {
-                    if (c < C) {
-                        uint32_t kv = f2key(sb[(size_t)c * plane + p]);
-                        if (slot >= 0) atomicMax(&vals[slot][c], kv);
-                        else atomicMax(&segb[(size_t)id * C + c], kv);
-                    }
-                }
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < C && cur[c]) {
+                if (slot >= 0) atomicMax(&vals[slot][c], cur[c]);
+                else atomicMax(&segb[(size_t)cur_id * C + c], cur[c]);
             }
         }
+    };
+    if (x < W) {
+        const int rows = min(SEG_ROWS, H - y0);
+        for (int r = 0; r < rows; ++r) {
+            const size_t p = (size_t)(y0 + r) * W + x;
+            const int64_t id64 = ib[p];
+            uint32_t kv[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) kv[c] = c < C ? f2key(sb[(size_t)c * plane + p]) : 0u;
+            int id;
+            if (id64 < 0 || id64 >= (int64_t)S) {
+                bad = max(bad, id64 < 0 || id64 > 0x7fffffffLL ? 0x7fffffff : (int)id64);
+                id = -1;
+            } else id = (int)id64;
+            if (id != cur_id) {
+                flush();
+                cur_id = id;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) cur[c] = kv[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) cur[c] = max(cur[c], kv[c]);
+            }
+        }
+        flush();
     }
     __syncthreads();
     for (int i = tid; i < SEG_SLOTS * CMAX; i += 256) {
@@ -234,7 +259,7 @@ extern "C" int uem_segment_max_planar(const float* soft, const int64_t* sup, uin
                                       int H, int W, int S, int* out_of_range, void* stream) {
     UEM_REQUIRE(soft && sup && seg_keys, "segment_max: null pointer");
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && H > 0 && W > 0 && S > 0, "segment_max: bad shape");
-    dim3 grid((unsigned)uem_cdiv(W, 64), (unsigned)uem_cdiv(H, 16), (unsigned)B);
+    dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)uem_cdiv(H, SEG_ROWS), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (C <= 8) segment_max_kernel<8><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
     else segment_max_kernel<16><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
@@ -246,19 +271,20 @@ extern "C" int uem_segment_max_planar(const float* soft, const int64_t* sup, uin
 // ================================================================================================
 template <int CMAX>
 __device__ __forceinline__ void softmax_maxnorm(float (&v)[CMAX], int C, float inv_temp) {
-    // v <- softmax(v * inv_temp) / (max + 1e-7)     (alignment.py:221-222, 230-235, 252-253)
+    // v <- softmax(v * inv_temp) / (max + 1e-7)     (alignment.py:221-222, 230-235, 252-253); one reciprocal per division row
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= inv_temp; m = fmaxf(m, v[c]); }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - m); s += v[c]; }
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = fast_exp(v[c] - m); s += v[c]; }
+    const float rs = fast_rcp(s);
     float pm = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = v[c] / s; pm = fmaxf(pm, v[c]); }
-    const float d = pm + 1e-7f;
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = v[c] * rs; pm = fmaxf(pm, v[c]); }
+    const float rd = fast_rcp(pm + 1e-7f);
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] / d;
+    for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] * rd;
 }
 
 // One block = 256 consecutive pixels of ONE image row, so the vertical lerp is block-uniform and the strip
@@ -288,22 +314,26 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     extern __shared__ __attribute__((aligned(16))) float lowres[];       // [3 maps][2 rows][ncell][CMAX]
     const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * 256;
     const size_t plane = (size_t)H * W;
-    const Lerp ly = lerp_setup(Y, h, H, true);
-    const int c0 = lerp_setup(X0, w, W, true).i0;                        // first cell of the strip
+    const float sy = lerp_scale_ac(h, H), sx = lerp_scale_ac(w, W);
+    const Lerp ly = lerp_ac(Y, h, sy);
+    const int c0 = lerp_ac(X0, w, sx).i0;                                // first cell of the strip
     const int Xl = min(X0 + 255, W - 1);
-    const int c1 = lerp_setup(Xl, w, W, true).i1;                        // last cell of the strip
+    const int c1 = lerp_ac(Xl, w, sx).i1;                                // last cell of the strip
     const int nc = c1 - c0 + 1;                                          // <= ncell by construction
     {
         const float* maps[3] = {sim, lg1, lg2};
-        const int per_map = 2 * ncell * CMAX;
-        for (int i = threadIdx.x; i < 3 * per_map; i += 256) {
-            const int m = i / per_map, r = i - m * per_map;
-            const int row = r / (ncell * CMAX), q = r - row * (ncell * CMAX);
-            const int cell = q / CMAX, c = q - cell * CMAX;
-            float v = 0.f;
-            if (maps[m] != nullptr && cell < nc && c < C)
-                v = maps[m][(((size_t)b * h + (row ? ly.i1 : ly.i0)) * w + (c0 + cell)) * C + c];
-            lowres[i] = v;
+        const int ncc = ncell * CMAX;                                    // CMAX is 8 or 16: cell / class by shift and mask
+        for (int i = threadIdx.x; i < ncc; i += 256) {
+            const int cell = i / CMAX, c = i % CMAX;
+            const bool in = cell < nc && c < C;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int row = 0; row < 2; ++row) {
+                    float v = 0.f;
+                    if (maps[m] != nullptr && in) v = maps[m][(((size_t)b * h + (row ? ly.i1 : ly.i0)) * w + (c0 + cell)) * C + c];
+                    lowres[(m * 2 + row) * ncc + i] = v;
+                }
         }
     }
     __syncthreads();
@@ -321,7 +351,7 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) o[c] = 0.f;
     if (active) {
-        const Lerp lx = lerp_setup(X, w, W, true);
+        const Lerp lx = lerp_ac(X, w, sx);
         float wgt[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) wgt[c] = 0.f;
@@ -344,13 +374,14 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
                 for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= inv_temp; u[c] *= inv_temp; m1 = fmaxf(m1, v[c]); m2 = fmaxf(m2, u[c]); }
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = expf(v[c] - m1); u[c] = expf(u[c] - m2); s1 += v[c]; s2 += u[c]; }
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = fast_exp(v[c] - m1); u[c] = fast_exp(u[c] - m2); s1 += v[c]; s2 += u[c]; }
+                const float r1 = fast_rcp(s1), r2 = fast_rcp(s2);
                 float pm = 0.f;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = (v[c] / s1 + u[c] / s2) * 0.5f; pm = fmaxf(pm, v[c]); }
-                const float d = pm + 1e-7f;
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = (v[c] * r1 + u[c] * r2) * 0.5f; pm = fmaxf(pm, v[c]); }
+                const float rd = fast_rcp(pm + 1e-7f);
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] / d;
+                for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] * rd;
             } else {
                 softmax_maxnorm<CMAX>(v, C, inv_temp);
             }
@@ -383,9 +414,9 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = wgt[c] * soft[((size_t)b * C + c) * plane + p]; sum += o[c]; }
-        const float d = sum + 1e-7f;
+        const float rd = fast_rcp(sum + 1e-7f);
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] / d; out[((size_t)b * C + c) * plane + p] = o[c]; }
+        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] * rd; out[((size_t)b * C + c) * plane + p] = o[c]; }
     }
     // per-(b,c) maximum for the selection pass: block maximum -> blockmax[b][block][c]; a second tiny kernel
     // reduces the blocks.  (One atomicMax per wave on the B*C result words serialised 0.8 M atomics on 192

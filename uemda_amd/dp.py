@@ -18,46 +18,10 @@ from . import ops
 # UEM_DP_FORCE=1: take the data-parallel code paths (process group, broadcast, bucketed all-reduce) even with a single
 # rank -- a one-GPU smoke test of the RCCL plumbing (the collectives are then trivial but real).
 FORCE = os.environ.get("UEM_DP_FORCE", "0") != "0"
-# UEM_DP_NATIVE=1: the gradient all-reduce goes through the C ABI (uem_allreduce_flat: RCCL on a stream of ours) instead of
-# torch.distributed.  Same RCCL either way; torch.distributed stays the default because the multi-rank leg of the native
-# path cannot be rehearsed on a one-GPU box (the single-rank leg is: tests/test_gpu_dp.py).
-NATIVE = os.environ.get("UEM_DP_NATIVE", "0") != "0"
-
-
-class NativeComm:
-    """RCCL communicator behind the C ABI: rank 0 draws the id, the torch.distributed store ships its 128 bytes."""
-
-    def __init__(self):
-        import ctypes
-        from ._lib import call
-        rank, world = dist.get_rank(), dist.get_world_size()
-        ident = ctypes.create_string_buffer(128)
-        if rank == 0:
-            call("uem_comm_unique_id", ident)
-        box = [ident.raw]
-        dist.broadcast_object_list(box, src=0)
-        self._handle = ctypes.c_void_p()
-        call("uem_comm_init", ctypes.byref(self._handle), box[0], rank, world)
-        self.stream = torch.cuda.Stream()
-
-    def all_reduce_(self, flat, async_op=False):
-        """Sum-reduce `flat` in place on the communicator's stream, ordered after the current stream's work.  Returns an
-        event the caller makes its stream wait for (async_op) or waits for right away."""
-        from ._lib import call
-        cur = torch.cuda.current_stream()
-        self.stream.wait_stream(cur)
-        call("uem_allreduce_flat", self._handle, flat.data_ptr(), flat.numel(), self.stream.cuda_stream)
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        if not async_op:
-            cur.wait_event(ev)
-        return ev
-
-    def close(self):
-        from ._lib import call
-        if self._handle:
-            call("uem_comm_destroy", self._handle)
-            self._handle = None
+# One transport: torch.distributed (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU / one-device rehearsals).  Round 3 also had
+# a switch (UEM_DP_NATIVE) that sent the gradient collective through the C ABI's uem_allreduce_flat; it could only ever be rehearsed with
+# one rank and was a second path to distrust -- removed.  uem_comm_* / uem_allreduce_flat stay in the C ABI for
+# hosts without torch.distributed; tests/test_gpu_dp.py drives them directly.
 
 
 def init(backend=None, device=None):
@@ -98,6 +62,10 @@ def allreduce_flat_(flat, async_op=False):
 class DataParallel:
     """Broadcast at construction, then per iteration `reduce_gradients()` after backward.
 
+    hipGraph: with the "nccl" backend both all-reduces are capturable (RCCL launches kernels on its own stream; the event
+    hand-shakes with the compute stream become graph edges), so `uemda_amd.step.GraphedStep(..., dp=wrapper)` captures the whole
+    data-parallel step; `capturable` says whether the process group allows it ("gloo" moves the buffer through the host: it does not).
+
     The gradient all-reduce is split into two buckets of the flat arena and the first one is started while
     backward is still running: parameters sit in the arena in forward order, backward finishes them last-to-
     first, so once `layer3[0]` has finished its backward for every forward of the step, the tail of the arena
@@ -119,9 +87,15 @@ class DataParallel:
         self._bwd_calls = 0
         self.unpaired_forwards = 0          # train-mode forwards that never saw a backward (diagnostic)
         self._active = self.world > 1 or (FORCE and dist.is_initialized())
-        self.native = NativeComm() if (NATIVE and self._active and arena.is_cuda) else None
         if overlap:
             self._install_overlap()     # also with one rank: the forward/backward pairing is checked either way
+
+    @property
+    def capturable(self):
+        """can the gradient collective be recorded into a hipGraph?  (no process group: nothing to record; RCCL: yes; gloo: no)"""
+        if not self._active:
+            return True
+        return dist.get_backend() == "nccl"
 
     # ---- overlap machinery -------------------------------------------------------------------------------
     def _install_overlap(self):
@@ -154,10 +128,7 @@ class DataParallel:
                                f"reduce_gradients() but only {self._fwd_calls} train-mode forwards were counted")
         if self._active and self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
             _, garena, n = self.model.flat_parameters()
-            if self.native is not None:
-                self._pending = self.native.all_reduce_(garena[self._split:n], async_op=True)
-            else:
-                self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+            self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
 
     def reduce_gradients(self):
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
@@ -171,13 +142,7 @@ class DataParallel:
                 raise ops.UemError("DataParallel: the early gradient bucket was sent before every backward pass had "
                                    f"run ({self._fwd_calls} forwards, {self._bwd_calls} backwards)")
             self.unpaired_forwards += self._fwd_calls - self._bwd_calls
-        if self._active and self.native is not None:
-            if self._pending is not None:
-                self.native.all_reduce_(garena[:self._split])
-                torch.cuda.current_stream().wait_event(self._pending)
-            else:
-                self.native.all_reduce_(garena)
-        elif self._active:
+        if self._active:
             if self._pending is not None:
                 dist.all_reduce(garena[:self._split], op=dist.ReduceOp.SUM)
                 self._pending.wait()

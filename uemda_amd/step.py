@@ -128,6 +128,8 @@ class GraphedStep:
         out = gs(lr)            # writes lr into the device scalar the captured optimizer launch reads, replays; `out` = the step's
                                 # dict of STATIC tensors (overwritten by the next replay)
 
+    Data parallel: pass `dp=wrapper` (uemda_amd.dp.DataParallel over the nccl / RCCL backend); the early tail-bucket all-reduce and the
+    head all-reduce are captured with the step, on RCCL's stream, as graph edges -- every rank replays the same graph.
     Requirements: inputs are the same device tensors every step (copy new data INTO `batch`), FusedSGD, at least one optimizer step
     taken before (the first step initialises the momentum buffer through a by-value flag).  Host-side logic of the step function runs
     ONCE, at capture: only state that is updated IN PLACE on the device survives replay (a rebound tensor -- `x = f(x)` -- would be
@@ -142,8 +144,10 @@ class GraphedStep:
         from .ops import UemError
         if not isinstance(optimizer, FusedSGD):
             raise UemError("GraphedStep needs uemda_amd.optim.FusedSGD (the learning rate travels as a device scalar)")
-        if kw.get("dp") is not None:
-            raise UemError("GraphedStep captures a single-process step (the gradient all-reduce is not captured)")
+        dp = kw.get("dp")
+        if dp is not None and not dp.capturable:
+            raise UemError("GraphedStep: this process group's all-reduce cannot be captured (gloo moves the buffer through the host); "
+                           "use the nccl (RCCL) backend or run the data-parallel step eagerly")
         from . import ops
         if ops.PROF.enabled:
             raise UemError("GraphedStep: per-launch event timing (ops.PROF.enabled) cannot be captured; switch it off first")
