@@ -389,7 +389,7 @@ int uem_cast_bf16_f32(const uint16_t* x, float* y, int64_t n, void* stream);
  *   uem_wino_output      y (N,H,W,C) = A^T M A; tile_stats [2][C][N*H*W/128]: per-128-pixel sums of y and y*y (forward; for
  *                        uem_bn_stats_from_tiles), OR bn_z / bn_vec (4,C) / tile_bnbwd [2][C][N*H*W/128]: per-group sums of
  *                        dp = y*[bn_z*scale + shift > 0] and dp*xhat (data gradient; for uem_bn_bwd_from_tiles); all may be NULL
- *   uem_wino_dy          dM[npos][T][C] = A dY A^T (weight gradient)
+ *   uem_wino_dy          dM[npos][T][C] = A dY A^T (weight gradient); optionally clears dU in the same launch
  *   uem_wino_wgrad_gemm  dU[npos][N][K] += sum_tiles dM[pos][tile][n] * V[pos][tile][k] (split-K fp32 atomics: zero dU first)
  *   uem_wino_filter_grad dw (Cout,3,3,Cin) += G^T dU G                                                                   */
 int uem_wino_filter(const float* w_ohwi, float* U, int Cout, int Cin, int transposed, int m, void* stream);
@@ -400,9 +400,31 @@ int uem_wino_gemm(const float* V, const float* U, float* M, int T, int K, int N,
                   int data_gradient /* 0 forward, 1: the same product through the data-gradient kernel instantiation */, void* stream);
 int uem_wino_output(const float* M, float* y, int N, int H, int W, int C, int dil, int m, float* tile_stats, const float* bn_z,
                     const float* bn_vec, float* tile_bnbwd, void* stream);
-int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, int m, void* stream);
+int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, int m, float* zero /* optional: a buffer the launch also
+                clears -- the dU accumulator of uem_wino_wgrad_gemm -- */, int64_t zero_floats, void* stream);
 int uem_wino_wgrad_gemm(const float* V, const float* dM, float* dU, int T, int K, int N, int npos, void* stream);
 int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, int m, void* stream);
+
+/* ---- every per-step weight re-layout in one launch ----------------------------------------------------------------------
+ * The kernels read their filter banks in layouts derived from the OIHW / OHWI parameters (reference: nn.Conv2d weights,
+ * uemda/_resnets.py:21-29): the transposed bank of a direct data gradient (uem_weight_transpose), the Winograd banks U / U'
+ * (uem_wino_filter, m = 2 / 4), the stem's padded taps (uem_stem_pack_weight).  After an optimizer step all of them are stale at once;
+ * uem_weight_prep refreshes a whole table of such jobs in ONE launch.  `jobs` and `block_starts` (njobs + 1 prefix sums of
+ * uem_weight_prep_blocks over the jobs) live in DEVICE memory; the caller owns them and every src / dst buffer.                  */
+#define UEM_PREP_TRANSPOSE 0   /* src w[cout][taps][cin] -> dst wt[cin][taps][cout]                                        */
+#define UEM_PREP_WINO2 1       /* src w[cout][3][3][cin] -> dst U[16][cout][cin]      (uem_wino_filter, m = 2)             */
+#define UEM_PREP_WINO2_T 2     /*                        -> dst U'[16][cin][cout], flipped taps                            */
+#define UEM_PREP_WINO4 3       /*                        -> dst U[36][cout][cin]      (m = 4)                              */
+#define UEM_PREP_WINO4_T 4     /*                        -> dst U'[36][cin][cout]                                          */
+#define UEM_PREP_STEM_PACK 5   /* src w[64][7][7][3] -> dst w8[64][7][8][4] (cout 64, cin 3, taps 49)                       */
+typedef struct uem_prep_job {
+    const void* src;
+    void* dst;
+    int kind, cout, cin, taps;
+} uem_prep_job;
+int uem_weight_prep_blocks(int kind, int cout, int cin, int taps);   /* blocks the job takes; -1: shape not supported by this kind */
+int uem_weight_prep(const uem_prep_job* jobs /* device */, const int* block_starts /* device, njobs + 1 */, int njobs,
+                    int total_blocks, void* stream);
 
 /* ---- data parallel (new relative to the reference, which is single-GPU: SURVEY 2a, 8e) --------------------------
  * all-reduce(sum, in place) of a flat fp32 buffer -- the gradient arena, 98 MB for R50-ASPP -- over RCCL on `stream`:

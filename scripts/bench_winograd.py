@@ -66,7 +66,7 @@ def main():
             mt = ops.wino_gemm(v, u)
             t_out = timeit(lambda: ops.call("uem_wino_output", ops.ptr(mt), ops.ptr(y), B, h, h, cout, d, m, None, None, None, None, ops.stream()))
             dm = torch.empty((npos, v.shape[1], cout), device="cuda")
-            t_dy = timeit(lambda: ops.call("uem_wino_dy", ops.ptr(dy), ops.ptr(dm), B, h, h, cout, d, m, ops.stream()))
+            t_dy = timeit(lambda: ops.call("uem_wino_dy", ops.ptr(dy), ops.ptr(dm), B, h, h, cout, d, m, None, 0, ops.stream()))
             du = torch.zeros((npos, cout, cin), device="cuda")
             t_wg = timeit(lambda: ops.call("uem_wino_wgrad_gemm", ops.ptr(v), ops.ptr(dm), ops.ptr(du), v.shape[1], cin, cout, npos, ops.stream()))
             t_fg = timeit(lambda: ops.call("uem_wino_filter_grad", ops.ptr(du), ops.ptr(dw), cout, cin, m, ops.stream()))

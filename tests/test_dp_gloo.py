@@ -74,7 +74,10 @@ def test_two_rank_gloo_data_parallel_contract():
 
 
 class _Trig(torch.autograd.Function):
-    """stands in for blocks.BottleneckFn: identity forward, calls the block's data-parallel trigger in backward"""
+    """stands in for the END of blocks.BottleneckFn.backward: identity forward, calls the block's data-parallel trigger in backward.
+    It sits on the block's INPUT, so that autograd runs it after the block's own weight gradient has been accumulated -- as the real
+    callback runs after the block's weight-gradient launches.  (Round 3 had it on the block's output: the early bucket could leave
+    before layer3's gradient of the last graph had landed, a race the test lost under CPU contention.)"""
 
     @staticmethod
     def forward(ctx, x, blk):
@@ -119,7 +122,7 @@ def _toy_model():
 
         def forward(self, x):
             r = self.encoder.resnet
-            return self.head(_Trig.apply(r.layer3[0](torch.relu(r.stem(x))), r.layer3[0]))
+            return self.head(r.layer3[0](_Trig.apply(torch.relu(r.stem(x)), r.layer3[0])))
 
     return Toy()
 

@@ -156,3 +156,69 @@ def test_winograd_plans_and_declined_shapes(monkeypatch):
         ops.wino_input(torch.zeros(1, 6, 6, 64, device="cuda"), 1)           # the C ABI refuses too (T % 32)
     with pytest.raises(ops.UemError):
         ops.wino_input(torch.zeros(2, 18, 16, 64, device="cuda"), 1, m=4)    # 18 is not a multiple of 4
+
+
+def test_weight_prep_refreshes_every_derived_bank_in_one_launch():
+    """uem_weight_prep (ops.PREP): the transposed banks of the direct data gradients, the Winograd banks of both tile sizes and the
+    stem's packed taps, refreshed together -- bit-equal to the one-bank-per-launch entry points, following in-place weight updates,
+    FusedSGD's epoch and the death of a parameter."""
+    import ctypes
+    import gc
+    from uemda_amd import ops
+    g = torch.Generator().manual_seed(5)
+
+    def param(cout, cin, k):
+        return torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=g) * 0.1).cuda().contiguous(memory_format=torch.channels_last))
+    p1, p3, p3b, ps = param(256, 64, 1), param(128, 128, 3), param(512, 256, 3), param(64, 3, 7)
+
+    def singles():
+        out = {}
+        for name, p in (("p1", p1), ("p3", p3), ("p3b", p3b)):
+            out[name, "t"] = ops.weight_transpose(ops.weight_ohwi(p))
+        for name, p in (("p3", p3), ("p3b", p3b)):
+            cout, cin = p.shape[:2]
+            for m in (2, 4):
+                for tr in (False, True):
+                    u = torch.empty(((m + 2) ** 2, cin, cout) if tr else ((m + 2) ** 2, cout, cin), device="cuda")
+                    ops.call("uem_wino_filter", ops.ptr(ops.weight_ohwi(p)), ops.ptr(u), cout, cin, 1 if tr else 0, m, ops.stream())
+                    out[name, m, tr] = u
+        w8 = torch.empty(64, 7, 8, 4, device="cuda")
+        ops.call("uem_stem_pack_weight", ops.ptr(ops.weight_ohwi(ps)), ops.ptr(w8), ops.stream())
+        out["stem"] = w8
+        return out
+
+    def batched():
+        out = {("p1", "t"): ops.weight_transpose_cached(p1), ("p3", "t"): ops.weight_transpose_cached(p3), ("p3b", "t"): ops.weight_transpose_cached(p3b)}
+        for name, p in (("p3", p3), ("p3b", p3b)):
+            for m in (2, 4):
+                for tr in (False, True):
+                    out[name, m, tr] = ops.wino_filter_cached(p, tr, m)
+        out["stem"] = ops.stem_weight_packed(ps)
+        return out
+
+    def same(a, b):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    same(batched(), singles())                                        # first requests: one-job tables
+    first = batched()
+    assert all(first[k].data_ptr() == v.data_ptr() for k, v in batched().items())       # cached: the same buffers, no refresh
+    with torch.no_grad():
+        p3.mul_(1.5)                                                  # in place through torch: the parameter's version moves
+        p1.add_(0.25)
+    same(batched(), singles())                                        # ONE launch refreshed all of them
+    ops.weights_changed()                                             # what FusedSGD / a replayed graph announce
+    with torch.no_grad():
+        p3b.data.mul_(0.5)                                            # (a kernel wrote the arena behind torch's back)
+    same(batched(), singles())
+    # a parameter that dies leaves the table before its memory can be read again
+    prep = ops.PREP.by_device[torch.cuda.current_device()]
+    n_before = len(prep.jobs)
+    del p3b, first
+    gc.collect()
+    ops.weights_changed()
+    got = ops.weight_transpose_cached(p1)
+    assert torch.equal(got, ops.weight_transpose(ops.weight_ohwi(p1)))
+    assert len(prep.jobs) == n_before - 5                             # p3b's transposed bank and its four Winograd banks are gone
+    lib = ops._lib.load()
+    assert lib.uem_weight_prep_blocks(1, 100, 64, 9) == -1 and lib.uem_weight_prep_blocks(0, 256, 64, 1) == 16

@@ -17,6 +17,11 @@ LIB_PATH = os.environ.get("UEM_LIB_PATH") or os.path.join(_HERE, "libuemda_hip.s
 _lib = None
 
 
+class PrepJob(Structure):
+    """mirror of `uem_prep_job`"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("kind", c_int), ("cout", c_int), ("cin", c_int), ("taps", c_int)]
+
+
 class ConvShape(Structure):
     """mirror of `uem_conv_shape`"""
     _fields_ = [(n, c_int) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
@@ -118,9 +123,11 @@ SIGNATURES = {
     "uem_wino_input": [P, P, P, I, P, I, I, I, I, I, I, I, P],
     "uem_wino_gemm": [P, P, P, I, I, I, I, I, P],
     "uem_wino_output": [P, P, I, I, I, I, I, I, P, P, P, P, P],
-    "uem_wino_dy": [P, P, I, I, I, I, I, I, P],
+    "uem_wino_dy": [P, P, I, I, I, I, I, I, P, L, P],
     "uem_wino_wgrad_gemm": [P, P, P, I, I, I, I, P],
     "uem_wino_filter_grad": [P, P, I, I, I, P],
+    "uem_weight_prep_blocks": [I, I, I, I],
+    "uem_weight_prep": [P, P, I, I, P],
     "uem_comm_unique_id": [P],
     "uem_comm_init": [POINTER(c_void_p), P, I, I],
     "uem_allreduce_flat": [P, P, L, P],
@@ -138,6 +145,7 @@ UEM_PROTO_SPLIT = 256
 UEM_NORM_BLOCKS = 1024
 CONV_IN_AFFINE, CONV_IN_RELU, CONV_ACCUMULATE, CONV_TRANSPOSED = 1, 2, 4, 8
 CONV_PREC_BF16 = 32
+PREP_TRANSPOSE, PREP_WINO2, PREP_WINO2_T, PREP_WINO4, PREP_WINO4_T, PREP_STEM_PACK = range(6)
 
 
 class UemError(RuntimeError):

@@ -32,7 +32,21 @@ struct WinoP {
     const float* bn_z;         // data gradient: first pass of the consumer's BatchNorm+ReLU backward
     const float* bn_vec;       // (4, C): scale, shift, mean, invstd
     float* tile_bnbwd;         // [2][C][M/128]: sum dp, sum dp*xhat
+    // dY transform extra: a buffer the launch also zeroes (the weight gradient's dU accumulator, so that no separate fill is launched)
+    float* zero;
+    long long zero_q;          // its size in float4
 };
+
+// every block clears its slice of p.zero (16-byte stores)
+__device__ __forceinline__ void wino_zero_slice(const WinoP& p) {
+    if (p.zero == nullptr) return;
+    const long long nblk = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+    const long long per = (p.zero_q + nblk - 1) / nblk;
+    for (long long i = threadIdx.x; i < per; i += 256) {
+        const long long idx = bid * per + i;
+        if (idx < p.zero_q) reinterpret_cast<float4*>(p.zero)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 
 // tile -> (image, sub-image row / column, tile row / column); th / tw are tiles per sub-image for the launch's tile edge (2 or 4)
 __device__ __forceinline__ void wino_tile(const WinoP& p, const int tile, int& n, int& ry, int& rx, int& ty, int& tx) {
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoP p) {
 
 // dM = A dY A^T with A = [1 0; 1 1; 1 -1; 0 -1]; same thread mapping as the input transform
 __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoP p) {
+    wino_zero_slice(p);
     const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int tile = blockIdx.x * 16 + tl;
     const int c = blockIdx.y * 64 + q * 4;
@@ -215,11 +230,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoP p) {
 // U = G g G^T.  TRANSPOSED = false: U[pos][co][ci] from w[co][ky][kx][ci];  true: U'[pos][ci][co] from the flipped taps w[co][2-ky][2-kx][ci]
 // (the data gradient's filter bank).  One thread per (co, ci quad); the transposed form goes through LDS so that both the reads
 // (ci contiguous) and the writes (co contiguous) are coalesced: block = 16 co x 16 ci quads.
+#define WINO_FILTER_SMEM (8 * 16 * 65)          // floats: the transposed forms stage [positions][16 co][64 ci + 1 pad] through LDS
 template <bool TRANSPOSED>
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin) {
-    __shared__ float tile[TRANSPOSED ? 8 : 1][16][65];                   // TRANSPOSED: [pos (half of them)][co][ci (64 + 1 pad)]
+__device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin,
+                                                 const int bx, const int by, float* __restrict__ smem) {
+    // TRANSPOSED: smem is [pos (half of them)][co][ci (64 + 1 pad)]
     const int q = threadIdx.x & 15, col = threadIdx.x >> 4;
-    const int co = blockIdx.y * 16 + col, ci = blockIdx.x * 64 + q * 4;
+    const int co = by * 16 + col, ci = bx * 64 + q * 4;
     float4 g[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
                 if (!TRANSPOSED) {
                     *reinterpret_cast<float4*>(U + (size_t)(i * 4 + j) * pos_stride + (size_t)co * Cin + ci) = u[j];
                 } else {
-                    float* t = &tile[ii * 4 + j][col][q * 4];
+                    float* t = smem + ((ii * 4 + j) * 16 + col) * 65 + q * 4;
                     t[0] = u[j].x; t[1] = u[j].y; t[2] = u[j].z; t[3] = u[j].w;
                 }
             }
@@ -266,11 +283,16 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int cil = wci0 + 16 * k;
-                    U[(size_t)(half * 8 + pl) * pos_stride + (size_t)(blockIdx.x * 64 + cil) * Cout + blockIdx.y * 16 + wco] = tile[pl][wco][cil];
+                    U[(size_t)(half * 8 + pl) * pos_stride + (size_t)(bx * 64 + cil) * Cout + by * 16 + wco] = smem[(pl * 16 + wco) * 65 + cil];
                 }
             __syncthreads();
         }
     }
+}
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin) {
+    __shared__ float smem[TRANSPOSED ? WINO_FILTER_SMEM : 1];
+    wino_filter_body<TRANSPOSED>(w, U, Cout, Cin, blockIdx.x, blockIdx.y, smem);
 }
 
 // dW[co][ky][kx][ci] += (G^T dU G)[ky][kx], dU[pos][co][ci]; one thread per (co, ci quad)
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const WinoP p) {
 
 // dM = A dY A^T (A = (A^T)^T, 6x4): the weight gradient's transform of a 4x4 block of dY
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const WinoP p) {
+    wino_zero_slice(p);
     const int q = threadIdx.x & 15, tl = threadIdx.x >> 4;
     const int tile = blockIdx.x * 16 + tl;
     const int c = blockIdx.y * 64 + q * 4;
@@ -514,12 +537,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const WinoP p) {
     }
 }
 
-// U = G g G^T, 36 positions; TRANSPOSED as in wino_filter_kernel (flipped taps, U'[pos][ci][co] through LDS, one U row at a time)
+// U = G g G^T, 36 positions; TRANSPOSED as in wino_filter_body (flipped taps, U'[pos][ci][co] through LDS, one U row at a time)
 template <bool TRANSPOSED>
-__global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin) {
-    __shared__ float tile[TRANSPOSED ? 6 : 1][16][65];
+__device__ __forceinline__ void wino4_filter_body(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin,
+                                                  const int bx, const int by, float* __restrict__ smem) {
     const int q = threadIdx.x & 15, col = threadIdx.x >> 4;
-    const int co = blockIdx.y * 16 + col, ci = blockIdx.x * 64 + q * 4;
+    const int co = by * 16 + col, ci = bx * 64 + q * 4;
     float4 r[6][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restri
             if (!TRANSPOSED) {
                 *reinterpret_cast<float4*>(U + (size_t)(i * 6 + j) * pos_stride + (size_t)co * Cin + ci) = u;
             } else {
-                float* t = &tile[j][col][q * 4];
+                float* t = smem + (j * 16 + col) * 65 + q * 4;
                 t[0] = u.x; t[1] = u.y; t[2] = u.z; t[3] = u.w;
             }
         }
@@ -562,11 +585,16 @@ __global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restri
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int cil = wci0 + 16 * k;
-                    U[(size_t)(i * 6 + pl) * pos_stride + (size_t)(blockIdx.x * 64 + cil) * Cout + blockIdx.y * 16 + wco] = tile[pl][wco][cil];
+                    U[(size_t)(i * 6 + pl) * pos_stride + (size_t)(bx * 64 + cil) * Cout + by * 16 + wco] = smem[(pl * 16 + wco) * 65 + cil];
                 }
             __syncthreads();
         }
     }
+}
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, const int Cout, const int Cin) {
+    __shared__ float smem[TRANSPOSED ? WINO_FILTER_SMEM : 1];
+    wino4_filter_body<TRANSPOSED>(w, U, Cout, Cin, blockIdx.x, blockIdx.y, smem);
 }
 
 // dW[co][ky][kx][ci] += (G^T dU G)[ky][kx], dU[36][co][ci]; one thread per (co, ci quad)
@@ -617,6 +645,7 @@ static int wino_geometry(WinoP& p, int N, int H, int W, int C, int d, int m, con
         return uem_fail(UEM_ERR_UNSUPPORTED, "%s: needs the tile count a multiple of 32 and positions*T*C < 2^30 elements (split the batch)", what);
     p.T = (int)T;
     p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.scale = p.shift = nullptr; p.relu = 0;
+    p.zero = nullptr; p.zero_q = 0;
     return UEM_OK;
 }
 
@@ -648,12 +677,15 @@ extern "C" int uem_wino_input(const float* x, const float* in_scale, const float
     return uem_check_launch("wino_input");
 }
 
-extern "C" int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, int m, void* stream) {
+extern "C" int uem_wino_dy(const float* dy, float* dM, int N, int H, int W, int C, int dil, int m, float* zero, int64_t zero_floats,
+                           void* stream) {
     UEM_REQUIRE(dy && dM, "wino_dy: null pointer");
+    UEM_REQUIRE((zero == nullptr && zero_floats == 0) || (zero != nullptr && zero_floats > 0 && zero_floats % 4 == 0 && ((uintptr_t)zero & 15) == 0),
+                "wino_dy: the buffer to clear needs a 16-byte aligned address and a multiple of 4 floats");
     WinoP p;
     const int rc = wino_geometry(p, N, H, W, C, dil, m, "wino_dy");
     if (rc) return rc;
-    p.x = dy; p.v = dM;
+    p.x = dy; p.v = dM; p.zero = zero; p.zero_q = zero_floats / 4;
     const dim3 grid((unsigned)(p.T / 16), (unsigned)(C / 64));
     if (m == 2) wino_dy_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
     else wino4_dy_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
@@ -705,4 +737,70 @@ extern "C" int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, i
     if (m == 2) wino_filter_grad_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(dU, dw_ohwi, Cout, Cin);
     else wino4_filter_grad_kernel<<<(unsigned)uem_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(dU, dw_ohwi, Cout, Cin);
     return uem_check_launch("wino_filter_grad");
+}
+
+// =====================================================================================================================
+// Every per-step weight re-layout of a model in ONE launch (uem_weight_prep): the (Cin,KH,KW,Cout) banks of the direct data gradients,
+// the Winograd filter banks U / U' of either tile size, the stem's padded 7x8x4 taps.  A step used to spend ~70 launches of 5-8 us
+// on them (46 weight transposes + the filter transforms: profiles/r03_i_launches_per_step.txt); the job table lives in device memory
+// and is rebuilt only when the set of weights changes.  Block b belongs to the job whose [starts[j], starts[j+1]) holds it.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void weight_prep_kernel(const uem_prep_job* __restrict__ jobs, const int* __restrict__ starts, const int njobs) {
+    __shared__ float smem[WINO_FILTER_SMEM];
+    int lo = 0, hi = njobs;
+    const int b = (int)blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uem_prep_job j = jobs[lo];
+    const int lb = b - starts[lo];
+    const float* const w = reinterpret_cast<const float*>(j.src);
+    float* const out = reinterpret_cast<float*>(j.dst);
+    if (j.kind == UEM_PREP_TRANSPOSE) {
+        // w[o][t][i] -> wt[i][t][o], 1024 consecutive outputs per block
+        const int64_t total = (int64_t)j.cout * j.taps * j.cin;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t idx = (int64_t)lb * 1024 + k * 256 + threadIdx.x;
+            if (idx < total) {
+                const int o = (int)(idx % j.cout);
+                const int64_t r = idx / j.cout;
+                const int t = (int)(r % j.taps);
+                const int i = (int)(r / j.taps);
+                out[idx] = w[((size_t)o * j.taps + t) * j.cin + i];
+            }
+        }
+    } else if (j.kind == UEM_PREP_STEM_PACK) {
+        // w[64][7][7][3] (OHWI) -> w8[64][7][8][4], zero padded
+        const int idx = lb * 256 + threadIdx.x;
+        if (idx < 64 * 7 * 8 * 4) {
+            const int c = idx & 3, kx = (idx >> 2) & 7, ky = (idx >> 5) % 7, o = idx / (7 * 32);
+            out[idx] = (c < 3 && kx < 7) ? w[((o * 7 + ky) * 7 + kx) * 3 + c] : 0.f;
+        }
+    } else {
+        const int gx = j.cin / 64;
+        const int bx = lb % gx, by = lb / gx;
+        if (j.kind == UEM_PREP_WINO2) wino_filter_body<false>(w, out, j.cout, j.cin, bx, by, smem);
+        else if (j.kind == UEM_PREP_WINO2_T) wino_filter_body<true>(w, out, j.cout, j.cin, bx, by, smem);
+        else if (j.kind == UEM_PREP_WINO4) wino4_filter_body<false>(w, out, j.cout, j.cin, bx, by, smem);
+        else wino4_filter_body<true>(w, out, j.cout, j.cin, bx, by, smem);
+    }
+}
+
+extern "C" int uem_weight_prep_blocks(int kind, int cout, int cin, int taps) {
+    if (cout <= 0 || cin <= 0 || taps <= 0) return -1;
+    switch (kind) {
+    case UEM_PREP_TRANSPOSE: return (int)uem_cdiv((int64_t)cout * cin * taps, 1024);
+    case UEM_PREP_STEM_PACK: return (cout == 64 && cin == 3 && taps == 49) ? (64 * 7 * 8 * 4 + 255) / 256 : -1;
+    case UEM_PREP_WINO2: case UEM_PREP_WINO2_T: case UEM_PREP_WINO4: case UEM_PREP_WINO4_T:
+        return (taps == 9 && cout % 16 == 0 && cin % 64 == 0) ? (cin / 64) * (cout / 16) : -1;
+    default: return -1;
+    }
+}
+
+extern "C" int uem_weight_prep(const uem_prep_job* jobs_dev, const int* block_starts_dev, int njobs, int total_blocks, void* stream) {
+    UEM_REQUIRE(jobs_dev && block_starts_dev && njobs > 0 && total_blocks > 0, "weight_prep: bad arguments");
+    weight_prep_kernel<<<(unsigned)total_blocks, 256, 0, (hipStream_t)stream>>>(jobs_dev, block_starts_dev, njobs);
+    return uem_check_launch("weight_prep");
 }

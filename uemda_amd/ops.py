@@ -351,9 +351,10 @@ def weight_transpose(w_ohwi):
     return wt
 
 
-# (Cin,KH,KW,Cout) copies for the data gradients, kept until the weights change: a step's two backward passes (source and
-# target graph) share them.  Weights change through FusedSGD (bumps WEIGHT_EPOCH: its kernel writes the arena behind
-# torch's back) or through torch in-place ops such as load_state_dict's copy_ (bump the tensor's _version).
+# Layouts the kernels read their filter banks in, derived from the OHWI parameters and kept until the weights change: the
+# (Cin,KH,KW,Cout) banks of the direct data gradients, the Winograd banks U / U' of either tile size, the stem's padded taps.  A step's
+# two backward passes (source and target graph) share them.  Weights change through FusedSGD (bumps WEIGHT_EPOCH: its kernel writes the
+# arena behind torch's back) or through torch in-place ops such as load_state_dict's copy_ (bump the tensor's _version).
 WEIGHT_EPOCH = 0
 
 
@@ -362,13 +363,110 @@ def weights_changed():
     WEIGHT_EPOCH += 1
 
 
+class _WeightPrep:
+    """Every derived filter bank anybody asked for since its parameter came to life, refreshed TOGETHER: the first request that finds
+    its bank stale (after an optimizer step all of them are) launches uem_weight_prep once over the whole job table instead of one
+    small kernel per bank (round 3: 46 weight transposes + the Winograd filter transforms per step).  A new job is served by the same
+    entry point on a one-job table and joins the big one; jobs of parameters that no longer exist are dropped when the table is rebuilt.
+    Under hipGraph capture the refresh launch is captured like any other (the table itself is never rebuilt there: its set of jobs is
+    fixed by the warm-up steps)."""
+    BATCH = os.environ.get("UEM_WEIGHT_PREP_BATCH", "1") != "0"
+
+    def __init__(self):
+        self.jobs = {}              # (param data_ptr, kind) -> job dict
+        self.table = None           # (jobs tensor, starts tensor, njobs, total blocks) on the device; None = rebuild before use
+
+    @staticmethod
+    def _stamp(param):
+        return (WEIGHT_EPOCH, param._version)
+
+    def _build(self, jobs):
+        n = len(jobs)
+        arr = (_lib.PrepJob * n)()
+        starts = [0]
+        for i, j in enumerate(jobs):
+            arr[i].src, arr[i].dst, arr[i].kind = j["src"], j["dst"].data_ptr(), j["kind"]
+            arr[i].cout, arr[i].cin, arr[i].taps = j["cout"], j["cin"], j["taps"]
+            starts.append(starts[-1] + j["blocks"])
+        dev = jobs[0]["dst"].device
+        jt = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        st = torch.tensor(starts, dtype=torch.int32).to(dev)
+        return jt, st, n, starts[-1]
+
+    def _run(self, table):
+        jt, st, n, total = table
+        call("uem_weight_prep", ptr(jt), ptr(st), n, total, stream())
+
+    def get(self, param, kind, shape):
+        """the derived bank of `param` (a conv weight, logical OIHW in channels_last storage) for `kind`, of shape `shape`"""
+        import weakref
+        key = (param.data_ptr(), kind)
+        job = self.jobs.get(key)
+        if job is not None and (job["ref"]() is not param or tuple(job["dst"].shape) != tuple(shape)):
+            job = None                                           # the address was recycled by another parameter
+        if job is None:
+            w = weight_ohwi(param)
+            cout, kh, kw, cin = w.shape
+            blocks = _lib.load().uem_weight_prep_blocks(kind, cout, cin, kh * kw)
+            if blocks <= 0:
+                raise UemError(f"weight_prep: kind {kind} does not take a ({cout},{kh},{kw},{cin}) filter bank")
+            job = dict(ref=weakref.ref(param), src=w.data_ptr(), dst=torch.empty(shape, device=w.device, dtype=torch.float32), kind=kind,
+                       cout=cout, cin=cin, taps=kh * kw, blocks=blocks, stamp=None)
+            self.jobs[key] = job
+            self.table = None
+            if torch.cuda.is_current_stream_capturing():
+                raise UemError("weight_prep: a new filter bank was requested while capturing a hipGraph; run a warm-up step first")
+            self._run(self._build([job]))
+            job["stamp"] = self._stamp(param)
+            return job["dst"]
+        if job["stamp"] == self._stamp(param):
+            return job["dst"]
+        if not self.BATCH:
+            self._run(self._build([job]))
+            job["stamp"] = self._stamp(param)
+            return job["dst"]
+        # stale: refresh every live job in one launch
+        def gone(j):
+            p = j["ref"]()
+            return p is None or p.data_ptr() != j["src"]         # freed, or moved to another arena: the old address may be unmapped
+        if self.table is not None and any(gone(j) for j in self.live):
+            self.table = None
+        if self.table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise UemError("weight_prep: the job table changed while capturing a hipGraph; run a warm-up step first")
+            for k in [k for k, j in self.jobs.items() if gone(j)]:
+                del self.jobs[k]
+            self.live = list(self.jobs.values())
+            self.table = self._build(self.live)
+        self._run(self.table)
+        for j in self.live:
+            j["stamp"] = self._stamp(j["ref"]())
+        return job["dst"]
+
+
+class _WeightPrepPerDevice:
+    def __init__(self):
+        self.by_device = {}
+
+    def get(self, param, kind, shape):
+        need_gpu(param)
+        prep = self.by_device.get(param.device.index)
+        if prep is None:
+            prep = self.by_device[param.device.index] = _WeightPrep()
+        return prep.get(param, kind, shape)
+
+
+PREP = _WeightPrepPerDevice()
+
+
 def weight_transpose_cached(param):
-    key = (WEIGHT_EPOCH, param._version, param.data_ptr())
-    hit = getattr(param, "_uem_wt", None)
-    if hit is None or hit[0] != key:
-        hit = (key, weight_transpose(weight_ohwi(param)))
-        param._uem_wt = hit
-    return hit[1]
+    cout, cin, kh, kw = param.shape
+    return PREP.get(param, _lib.PREP_TRANSPOSE, (cin, kh, kw, cout))
+
+
+def stem_weight_packed(param):
+    """the 7x7 stem filter bank as the stem kernels read it: (64, 7, 8, 4), kx and the channel padded with zeros"""
+    return PREP.get(param, _lib.PREP_STEM_PACK, (64, 7, 8, 4))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -455,18 +553,10 @@ def wino_ok(x_shape, cout, kh, kw, stride, pad, dil):
 
 def wino_filter_cached(param, transposed, m=2):
     """U = G w G^T of a 3x3 conv weight (transposed: the data gradient's flipped bank), kept until the weights change."""
-    key = (WEIGHT_EPOCH, param._version, param.data_ptr())
-    name = f"_uem_wino{m}_ut" if transposed else f"_uem_wino{m}_u"
-    hit = getattr(param, name, None)
-    if hit is None or hit[0] != key:
-        w = weight_ohwi(param)
-        cout, _, _, cin = w.shape
-        npos = (m + 2) ** 2
-        u = torch.empty((npos, cin, cout) if transposed else (npos, cout, cin), device=w.device, dtype=torch.float32)
-        call("uem_wino_filter", ptr(w), ptr(u), cout, cin, 1 if transposed else 0, m, stream())
-        hit = (key, u)
-        setattr(param, name, hit)
-    return hit[1]
+    cout, cin = param.shape[0], param.shape[1]
+    npos = (m + 2) ** 2
+    kind = {(2, False): _lib.PREP_WINO2, (2, True): _lib.PREP_WINO2_T, (4, False): _lib.PREP_WINO4, (4, True): _lib.PREP_WINO4_T}[(m, bool(transposed))]
+    return PREP.get(param, kind, (npos, cin, cout) if transposed else (npos, cout, cin))
 
 
 def wino_input(x, dil, in_scale=None, in_shift=None, in_relu=False, m=2, which=0):
@@ -597,8 +687,8 @@ def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None
         vv = v if v is not None else wino_input(x, dil, in_scale, in_shift, in_relu, m, which=2)
         npos, t, _ = vv.shape
         dm = torch.empty((npos, t, cout), device=dy.device, dtype=torch.float32)
-        call("uem_wino_dy", ptr(dy), ptr(dm), n, h, w, cout, dil, m, stream())
-        du = torch.zeros((npos, cout, cin), device=dy.device, dtype=torch.float32)
+        du = torch.empty((npos, cout, cin), device=dy.device, dtype=torch.float32)       # cleared by the dY transform's launch
+        call("uem_wino_dy", ptr(dy), ptr(dm), n, h, w, cout, dil, m, ptr(du), du.numel(), stream())
         call("uem_wino_wgrad_gemm", ptr(vv), ptr(dm), ptr(du), t, cin, cout, npos, stream())
         call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, m, stream())
 
@@ -617,10 +707,12 @@ def nchw3_to_nhwc4(x):
     return x4
 
 
-def stem_conv(x4, w_ohwi):
+def stem_conv(x4, w_ohwi, w8=None):
+    """w8: the packed taps when the caller holds them (stem_weight_packed(param)); else packed here from w_ohwi"""
     n, h, w, _ = x4.shape
-    w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
-    call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
+    if w8 is None:
+        w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+        call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
     y = torch.empty((n, conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1), 64), device=x4.device,
                     dtype=torch.float32)
     flops = 2.0 * y.numel() * 147
@@ -628,7 +720,7 @@ def stem_conv(x4, w_ohwi):
     return y
 
 
-def stem_conv_bn(x4, w_ohwi, bn):
+def stem_conv_bn(x4, w_ohwi, bn, w8=None):
     """The stem conv followed by its BatchNorm statistics -> (z, BNState): out of the conv epilogue when the tiles are full and
     the BatchNorm is in training mode, else stem_conv + bn_stats (eval mode, odd sizes)."""
     n, h, w, _ = x4.shape
@@ -636,11 +728,12 @@ def stem_conv_bn(x4, w_ohwi, bn):
     M = n * ho * wo
     training = bn.training or bn.running_mean is None
     if not training or M % 128 != 0 or not FUSE_BN_STATS:
-        z = stem_conv(x4, w_ohwi)
+        z = stem_conv(x4, w_ohwi, w8)
         return z, bn_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training, bn.eps,
                            bn.momentum if bn.momentum is not None else 0.1)
-    w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
-    call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
+    if w8 is None:
+        w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+        call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
     z = torch.empty((n, ho, wo, 64), device=x4.device, dtype=torch.float32)
     ts = torch.empty((M // 128, 2, 64), device=x4.device, dtype=torch.float32)
     PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), CONV_PREC, stream()))
