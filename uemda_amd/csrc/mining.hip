@@ -287,22 +287,22 @@ __device__ __forceinline__ void softmax_maxnorm(float (&v)[CMAX], int C, float i
     for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] * rd;
 }
 
-// One block = 256 consecutive pixels of ONE image row, so the vertical lerp is block-uniform and the strip
-// only touches <= 256*(w-1)/(W-1) + 3 low-resolution cells: the two source rows of sim / logits1 / logits2 for
-// that cell range are staged in LDS once ([map][row][cell][CMAX]) and every per-pixel bilinear tap is an LDS
-// read instead of an L2 round trip (72 scattered loads per pixel before: 3.0 ms per B=32 step, 2 % of the HBM
-// roofline; the kernel is now bounded by its 56 B/pixel of soft-label / superpixel traffic).
+// One block = 256 consecutive pixels of ONE image row, so the vertical lerp is block-uniform and the strip only touches
+// <= 256*(w-1)/(W-1) + 3 low-resolution cells: the two source rows of sim / logits1 / logits2 for that cell range are interpolated
+// in y ONCE per block while they are staged into LDS ([map][cell][CMAX]) and every per-pixel tap is a 16-byte LDS read (72 scattered
+// loads per pixel in the first version: 3.0 ms per B=32 step; round 3 staged both rows and interpolated 4 taps per pixel).  Round 4:
+// the pixel's own operands (superpixel id first, then the soft label) are requested BEFORE the staging so that their latency, the
+// staging's and the segment gather's overlap instead of queueing behind one another; divisions and libm calls are gone (common.h).
 template <int CMAX>
-__device__ __forceinline__ void bilerp_lds(const float* __restrict__ r0, const float* __restrict__ r1, int C, int c0,
-                                           const Lerp& ly, const Lerp& lx, float (&v)[CMAX]) {
-    // same operation order as the global-memory form: ly.l0*(lx.l0*v00 + lx.l1*v01) + ly.l1*(lx.l0*v10 + lx.l1*v11)
-    const float* a0 = r0 + (lx.i0 - c0) * CMAX;
-    const float* a1 = r0 + (lx.i1 - c0) * CMAX;
-    const float* b0 = r1 + (lx.i0 - c0) * CMAX;
-    const float* b1 = r1 + (lx.i1 - c0) * CMAX;
+__device__ __forceinline__ void xlerp_lds(const float* __restrict__ row, int C, int c0, const Lerp& lx, float (&v)[CMAX]) {
+    const float4* a0 = reinterpret_cast<const float4*>(row + (lx.i0 - c0) * CMAX);
+    const float4* a1 = reinterpret_cast<const float4*>(row + (lx.i1 - c0) * CMAX);
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) v[c] = ly.l0 * (lx.l0 * a0[c] + lx.l1 * a1[c]) + ly.l1 * (lx.l0 * b0[c] + lx.l1 * b1[c]);
+    for (int q = 0; q < CMAX / 4; ++q) {
+        const float4 x0 = a0[q], x1 = a1[q];
+        v[4 * q + 0] = lx.l0 * x0.x + lx.l1 * x1.x; v[4 * q + 1] = lx.l0 * x0.y + lx.l1 * x1.y;
+        v[4 * q + 2] = lx.l0 * x0.z + lx.l1 * x1.z; v[4 * q + 3] = lx.l0 * x0.w + lx.l1 * x1.w;
+    }
 }
 
 template <int CMAX>
@@ -311,42 +311,67 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     const float* __restrict__ lg1, const float* __restrict__ lg2, const uint32_t* __restrict__ seg,
     const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C, int h,
     int w, int H, int W, int S, float inv_temp, int mode, int ncell) {
-    extern __shared__ __attribute__((aligned(16))) float lowres[];       // [3 maps][2 rows][ncell][CMAX]
+    extern __shared__ __attribute__((aligned(16))) float lowres[];       // [3 maps][ncell][CMAX], interpolated in y
     const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * 256;
     const size_t plane = (size_t)H * W;
+    const int X = X0 + threadIdx.x;
+    const bool active = X < W;
+    const size_t p = (size_t)Y * W + X;
+    const bool use_sup = mode == UEM_REFINE_ALL || mode == UEM_REFINE_S;
+    // ---- this pixel's operands: requested first, consumed last --------------------------------------------------------------
+    int64_t id = 0;
+    float sv[CMAX];
+    if (active) {
+        if (use_sup) id = sup[(size_t)b * plane + p];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) sv[c] = c < C ? soft[((size_t)b * C + c) * plane + p] : 0.f;
+    }
+    // ---- the strip's low-resolution cells, interpolated between the two source rows -----------------------------------------
     const float sy = lerp_scale_ac(h, H), sx = lerp_scale_ac(w, W);
     const Lerp ly = lerp_ac(Y, h, sy);
     const int c0 = lerp_ac(X0, w, sx).i0;                                // first cell of the strip
     const int Xl = min(X0 + 255, W - 1);
     const int c1 = lerp_ac(Xl, w, sx).i1;                                // last cell of the strip
     const int nc = c1 - c0 + 1;                                          // <= ncell by construction
+    const int ncc = ncell * CMAX;                                        // CMAX is 8 or 16: cell / class by shift and mask
     {
         const float* maps[3] = {sim, lg1, lg2};
-        const int ncc = ncell * CMAX;                                    // CMAX is 8 or 16: cell / class by shift and mask
         for (int i = threadIdx.x; i < ncc; i += 256) {
             const int cell = i / CMAX, c = i % CMAX;
             const bool in = cell < nc && c < C;
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int row = 0; row < 2; ++row) {
-                    float v = 0.f;
-                    if (maps[m] != nullptr && in) v = maps[m][(((size_t)b * h + (row ? ly.i1 : ly.i0)) * w + (c0 + cell)) * C + c];
-                    lowres[(m * 2 + row) * ncc + i] = v;
+            for (int m = 0; m < 3; ++m) {
+                float v = 0.f;
+                if (maps[m] != nullptr && in) {
+                    const float r0 = maps[m][(((size_t)b * h + ly.i0) * w + (c0 + cell)) * C + c];
+                    const float r1 = maps[m][(((size_t)b * h + ly.i1) * w + (c0 + cell)) * C + c];
+                    v = ly.l0 * r0 + ly.l1 * r1;
                 }
+                lowres[m * ncc + i] = v;
+            }
+        }
+    }
+    // ---- the superpixel's class maxima: the gather can leave as soon as the id is here -------------------------------------
+    bool inrange = false, ignored = true;
+    uint32_t sk[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) sk[c] = 0u;
+    if (active && use_sup) {
+        inrange = id >= 0 && id < (int64_t)S;
+        // an id outside the table (reported by uem_segment_max_planar, the host raises) never borrows another
+        // segment's maxima: the pixel keeps its weight, as an ignored one does
+        ignored = (id == *ignore_id) || !inrange;
+        if (inrange) {
+            const uint32_t* sg = seg + ((size_t)b * S + (size_t)id) * C;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) if (c < C) sk[c] = sg[c];
         }
     }
     __syncthreads();
-    const float* s_sim0 = lowres;
-    const float* s_sim1 = lowres + ncell * CMAX;
-    const float* s_l10 = lowres + 2 * ncell * CMAX;
-    const float* s_l11 = lowres + 3 * ncell * CMAX;
-    const float* s_l20 = lowres + 4 * ncell * CMAX;
-    const float* s_l21 = lowres + 5 * ncell * CMAX;
+    const float* s_sim = lowres;
+    const float* s_l1 = lowres + ncc;
+    const float* s_l2 = lowres + 2 * ncc;
 
-    const int X = X0 + threadIdx.x;
-    const bool active = X < W;
-    const size_t p = (size_t)Y * W + X;
     float o[CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) o[c] = 0.f;
@@ -357,17 +382,17 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
         for (int c = 0; c < CMAX; ++c) wgt[c] = 0.f;
         if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_P) {          // prototype view
             float v[CMAX];
-            bilerp_lds<CMAX>(s_sim0, s_sim1, C, c0, ly, lx, v);
+            xlerp_lds<CMAX>(s_sim, C, c0, lx, v);
             softmax_maxnorm<CMAX>(v, C, 1.0f);
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) wgt[c] += v[c];
         }
         if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) {          // prediction view
             float v[CMAX];
-            bilerp_lds<CMAX>(s_l10, s_l11, C, c0, ly, lx, v);
+            xlerp_lds<CMAX>(s_l1, C, c0, lx, v);
             if (lg2 != nullptr) {
                 float u[CMAX];
-                bilerp_lds<CMAX>(s_l20, s_l21, C, c0, ly, lx, u);
+                xlerp_lds<CMAX>(s_l2, C, c0, lx, u);
                 // 0.5 * (softmax(x1/T) + softmax(x2/T)), then max-normalise
                 float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
@@ -388,20 +413,10 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) wgt[c] += v[c];
         }
-        if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_S) {          // superpixel view
-            const int64_t id = sup[(size_t)b * plane + p];
-            const bool inrange = id >= 0 && id < (int64_t)S;
-            // an id outside the table (reported by uem_segment_max_planar, the host raises) never borrows another
-            // segment's maxima: the pixel keeps its weight, as an ignored one does
-            const bool ignored = (id == *ignore_id) || !inrange;
+        if (use_sup) {                                                 // superpixel view
             float v[CMAX];
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) v[c] = 0.f;
-            if (inrange) {
-                const uint32_t* sg = seg + ((size_t)b * S + (size_t)id) * C;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) { uint32_t kv = sg[c]; v[c] = kv ? key2f(kv) : 0.f; }
-            }
+            for (int c = 0; c < CMAX; ++c) v[c] = (c < C && sk[c]) ? key2f(sk[c]) : 0.f;
             softmax_maxnorm<CMAX>(v, C, inv_temp);
             if (mode == UEM_REFINE_ALL) {
 #pragma unroll
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
         }
         float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = wgt[c] * soft[((size_t)b * C + c) * plane + p]; sum += o[c]; }
+        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = wgt[c] * sv[c]; sum += o[c]; }
         const float rd = fast_rcp(sum + 1e-7f);
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] * rd; out[((size_t)b * C + c) * plane + p] = o[c]; }
@@ -465,7 +480,7 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
     // cells touched by a 256-pixel strip: floor(255*(w-1)/(W-1)) + 3 covers every alignment
     const int ncell = (W > 1 ? (int)((255LL * (w - 1)) / (W - 1)) : 0) + 4;      // +1 slack for float rounding
     const int cmax = C <= 8 ? 8 : 16;
-    const size_t lds = (size_t)6 * ncell * cmax * sizeof(float);
+    const size_t lds = (size_t)3 * ncell * cmax * sizeof(float);
     UEM_REQUIRE(lds <= 150 * 1024, "label_refine: low-resolution strip does not fit LDS");
     dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)H, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;

@@ -426,22 +426,29 @@ class _WeightPrep:
             job["stamp"] = self._stamp(param)
             return job["dst"]
         # stale: refresh every live job in one launch
-        def gone(j):
-            p = j["ref"]()
-            return p is None or p.data_ptr() != j["src"]         # freed, or moved to another arena: the old address may be unmapped
-        if self.table is not None and any(gone(j) for j in self.live):
-            self.table = None
-        if self.table is None:
-            if torch.cuda.is_current_stream_capturing():
-                raise UemError("weight_prep: the job table changed while capturing a hipGraph; run a warm-up step first")
-            for k in [k for k, j in self.jobs.items() if gone(j)]:
-                del self.jobs[k]
-            self.live = list(self.jobs.values())
-            self.table = self._build(self.live)
+        self.settle()
         self._run(self.table)
         for j in self.live:
             j["stamp"] = self._stamp(j["ref"]())
         return job["dst"]
+
+    def settle(self):
+        """(re)build the device job table if the set of live jobs changed since it was built: new banks, parameters that were freed or
+        moved to another arena (their old address may be unmapped).  GraphedStep calls this before capturing, and keeps the table's
+        tensors alive for the captured refresh launch."""
+        def gone(j):
+            p = j["ref"]()
+            return p is None or p.data_ptr() != j["src"]
+        if self.table is not None and any(gone(j) for j in self.live):
+            self.table = None
+        if self.table is None and self.jobs:
+            if torch.cuda.is_current_stream_capturing():
+                raise UemError("weight_prep: the set of filter banks changed while capturing a hipGraph; run a warm-up step first")
+            for k in [k for k, j in self.jobs.items() if gone(j)]:
+                del self.jobs[k]
+            self.live = list(self.jobs.values())
+            self.table = self._build(self.live) if self.live else None
+        return self.table
 
 
 class _WeightPrepPerDevice:
@@ -454,6 +461,10 @@ class _WeightPrepPerDevice:
         if prep is None:
             prep = self.by_device[param.device.index] = _WeightPrep()
         return prep.get(param, kind, shape)
+
+    def settle(self):
+        """every device's job table as it stands (built now if stale): [(jobs tensor, starts tensor, njobs, blocks)]"""
+        return [t for t in (p.settle() for p in self.by_device.values()) if t is not None]
 
 
 PREP = _WeightPrepPerDevice()

@@ -165,6 +165,9 @@ class GraphedStep:
             for _ in range(max(int(warmup), 1 if optimizer._steps == 0 else 0)):
                 run()
         torch.cuda.current_stream().wait_stream(side)
+        # the weight-preparation job table is fixed before the capture (a single warm-up step leaves it half built) and stays alive as
+        # long as the graph whose refresh launch reads it
+        self._prep_tables = ops.PREP.settle()
         self.graph = torch.cuda.CUDAGraph()
         steps_before = optimizer._steps
         with torch.cuda.graph(self.graph):
