@@ -1,7 +1,8 @@
 """Oracle (CPU, fp32) restatement of the segmentation network.  TEST INFRASTRUCTURE ONLY.
 
 Functional re-statement of reference
-  uemda/models/Encoder.py:87-165   Deeplabv2 (multi_layer, non-cascade branch)
+  uemda/models/Encoder.py:87-165   Deeplabv2: the multi_layer branch every script instantiates (:103-110,144-155), the single-head
+                                   default (multi_layer=False, :111-116,156-165) and the cascade branch (:93-102,129-143)
   uemda/models/Encoder.py:68-84    Classifier_Module (ASPP head)
   uemda/models/Encoder.py:8-65     PPMBilinear head
   uemda/resnet.py:43-208           ResNetEncoder (OS16 => layer4 de-strided + dilated)
@@ -50,8 +51,9 @@ def layer_plan(resnet_type="resnet50", output_stride=16):
     return plan
 
 
-def param_shapes(resnet_type="resnet50", num_classes=6, use_ppm=False, fc_dim=2048):
-    """OrderedDict key -> shape, in the reference's state_dict order."""
+def param_shapes(resnet_type="resnet50", num_classes=6, use_ppm=False, fc_dim=2048, multi_layer=True, cascade=False):
+    """OrderedDict key -> shape, in the reference's state_dict order.  multi_layer=False: one head `cls_pred`
+    (Encoder.py:111-116); cascade: layer5 on the layer3 output (fc_dim // 2 channels), layer6 on the layer4 output (:93-102)."""
     sd = OrderedDict()
 
     def bn(prefix, c):
@@ -73,7 +75,8 @@ def param_shapes(resnet_type="resnet50", num_classes=6, use_ppm=False, fc_dim=20
         if has_ds:
             sd[prefix + ".downsample.0.weight"] = (planes * 4, inpl, 1, 1)
             bn(prefix + ".downsample.1", planes * 4)
-    for head in ("layer5", "layer6"):
+    heads = [("layer5", fc_dim // 2 if cascade else fc_dim), ("layer6", fc_dim)] if multi_layer else [("cls_pred", fc_dim)]
+    for head, fc_dim in heads:
         if use_ppm:
             for i in range(4):
                 sd[f"{head}.ppm.{i}.1.weight"] = (512, fc_dim, 1, 1)
@@ -94,10 +97,11 @@ class OracleDeeplabv2:
 
     def __init__(self, state, resnet_type="resnet50", num_classes=6, use_ppm=False,
                  is_ins_norm=True, requires_grad=True, freeze_at=0, batchnorm_trainable=True,
-                 with_cp=(False, False, False, False)):
+                 with_cp=(False, False, False, False), multi_layer=True, cascade=False):
         """freeze_at / batchnorm_trainable / with_cp: the ResNetEncoder options of reference uemda/resnet.py:57-60 (ctor),
         :112-130 (_frozen_res_bn, _freeze_at), :146-165 (torch.utils.checkpoint per layer), :183-190 (train())."""
         self.freeze_at, self.batchnorm_trainable, self.with_cp = int(freeze_at), bool(batchnorm_trainable), tuple(with_cp)
+        self.multi_layer, self.cascade = bool(multi_layer), bool(cascade)
         self.resnet_type = resnet_type
         self.num_classes = num_classes
         self.use_ppm = use_ppm
@@ -172,6 +176,7 @@ class OracleDeeplabv2:
 
     def encoder(self, x):
         p = self.p                                                     # resnet.py:140-166
+        self.stages = []                                               # the four stage outputs (c2..c5)
         x = F.conv2d(x, p["encoder.resnet.conv1.weight"], stride=2, padding=3)
         x = F.relu(self._bn(x, "encoder.resnet.bn1"))
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
@@ -187,6 +192,7 @@ class OracleDeeplabv2:
                 x = cp.checkpoint(run, x, use_reentrant=True)
             else:
                 x = run(x)
+            self.stages.append(x)
         return x
 
     def aspp_head(self, feat, head):
@@ -216,15 +222,26 @@ class OracleDeeplabv2:
 
     def __call__(self, x, dropout=False):
         feat = self.encoder(x)                                         # Encoder.py:145
+        head = (lambda f, h: self.ppm_head(f, h, dropout)) if self.use_ppm else self.aspp_head
+
+        def up(t):
+            return F.interpolate(t, x.shape[-2:], mode="bilinear", align_corners=True)
+        if self.multi_layer and self.cascade:                          # Encoder.py:129-143
+            feat1, feat2 = self.stages[-2:]
+            if self.is_ins_norm:
+                feat1, feat2 = F.instance_norm(feat1, eps=1e-5), F.instance_norm(feat2, eps=1e-5)
+            x1, x2 = head(feat1, "layer5"), head(feat2, "layer6")
+            if self.training:
+                return x1, feat1, x2, feat2
+            return (up(x1).softmax(dim=1) + up(x2).softmax(dim=1)) / 2
         if self.is_ins_norm:
             feat = F.instance_norm(feat, eps=1e-5)                     # Encoder.py:123,147
-        head = self.ppm_head if self.use_ppm else self.aspp_head
-        if self.use_ppm:
-            x1, x2 = head(feat, "layer5", dropout), head(feat, "layer6", dropout)
-        else:
-            x1, x2 = head(feat, "layer5"), head(feat, "layer6")
+        if not self.multi_layer:                                       # Encoder.py:156-165
+            x1 = head(feat, "cls_pred")
+            if self.training:
+                return x1, feat
+            return up(x1).softmax(dim=1)
+        x1, x2 = head(feat, "layer5"), head(feat, "layer6")
         if self.training:
             return x1, x2, feat                                        # Encoder.py:150-151
-        x1 = F.interpolate(x1, x.shape[-2:], mode="bilinear", align_corners=True)
-        x2 = F.interpolate(x2, x.shape[-2:], mode="bilinear", align_corners=True)
-        return (x1.softmax(dim=1) + x2.softmax(dim=1)) / 2             # Encoder.py:153-155
+        return (up(x1).softmax(dim=1) + up(x2).softmax(dim=1)) / 2     # Encoder.py:153-155

@@ -18,14 +18,14 @@ def _rng(key, seed):
 
 
 def det_state_dict(resnet_type="resnet50", num_classes=6, use_ppm=False, seed=2333, fc_dim=2048,
-                   shapes=None):
+                   shapes=None, multi_layer=True, cascade=False):
     """Return an OrderedDict of CPU tensors covering every state_dict entry.
 
     conv weights ~ N(0, 2/fan_out) (the reference's Kaiming fan_out init, _resnets.py:166);
     ASPP conv weights ~ N(0, 0.01) (Encoder.py:77-78); BN gamma ~ U(.5,1.5), beta ~ N(0,.1),
     running_mean ~ N(0,.1), running_var ~ U(.5,1.5) so that eval-mode BN is non-trivial.
     """
-    shapes = shapes if shapes is not None else param_shapes(resnet_type, num_classes, use_ppm, fc_dim)
+    shapes = shapes if shapes is not None else param_shapes(resnet_type, num_classes, use_ppm, fc_dim, multi_layer, cascade)
     sd = OrderedDict()
     for k, shp in shapes.items():
         g = _rng(k, seed)

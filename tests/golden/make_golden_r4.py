@@ -2,7 +2,7 @@
 """Round-4 golden vectors, produced by running the REFERENCE itself (imported from /root/reference under the stubs of
 make_golden.py, CPU only, build container only):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r4.py [step512] [avg] [pseudo] [evaluate]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r4.py [step512] [avg] [pseudo] [evaluate] [variants]
 
   model_aspp_r50_b8_512.npz   one tools/train_ssl_uem.py iteration of R50-ASPP at the reference's own operating point -- 8 source
                               + 8 target tiles (configs/ToPotsdam.py:58, configs/st/uemda/2potsdam.py:31,43) of 512x512, the
@@ -15,6 +15,10 @@ make_golden.py, CPU only, build container only):
                               `<fname>.pt` wire format (slide=False: model -> bilinear align_corners=True resize -> (C,H,W) fp32),
                               and the sliding-window probability map of a two-window image (pre_slide, tta=False); the TTA leg
                               needs `ttach`, which the tree does not hold
+  model_variants.npz          the Deeplabv2 branches no UemDA script builds but the class offers (uemda/models/Encoder.py:93-102,111-116,
+                              129-143,156-165): the single-head default (multi_layer=False; ASPP and PPM) and the cascade branch
+                              (layer5 on the layer3 output): training-mode outputs, eval-mode probabilities, gradients of a seeded
+                              quadratic loss for a few tensors, B = 2 tiles of 128 x 128
   evaluate_pairs.npz          uemda/utils/eval.py:14-56 `evaluate` through a closed-form model and a recording stand-in for
                               ever's PixelMetric (absent from the tree): what the function FEEDS the metric -- argmax over the
                               sliding-window map, pixels with label >= 0 -- as confusion counts; the IoU / F1 formulas live in
@@ -225,18 +229,67 @@ def evaluate_pairs(ref, logger):
     mg.save("evaluate_pairs", confusion=cm, model_w=np.array(ClosedFormModel.W, dtype=np.float32), n_images=np.array(len(imgs)), **arrays)
 
 
+VARIANTS = {"single_aspp": dict(multi_layer=False, cascade=False, use_ppm=False),
+            "single_ppm": dict(multi_layer=False, cascade=False, use_ppm=True),
+            "cascade_aspp": dict(multi_layer=True, cascade=True, use_ppm=False)}
+
+
+def model_variants(ref, logger):
+    from oracle.weights import det_state_dict
+    print("Deeplabv2 variants: single head (ASPP, PPM), cascade")
+    g = torch.Generator().manual_seed(606)
+    x = torch.randn(2, 3, 128, 128, generator=g)
+    arrays = dict(image=x)
+    for tag, v in VARIANTS.items():
+        sd = det_state_dict("resnet50", C, v["use_ppm"], seed=2333, multi_layer=v["multi_layer"], cascade=v["cascade"])
+        cfg = mg.model_cfg(v["use_ppm"], C)
+        cfg.update(multi_layer=v["multi_layer"], cascade=v["cascade"])
+        model = ref.Encoder.Deeplabv2(cfg)
+        model.load_state_dict(sd, strict=True)
+        assert list(model.state_dict().keys()) == list(sd.keys()), tag
+        if v["use_ppm"]:
+            model.cls_pred.conv_last[3].p = 0.0                       # Dropout2d off for parity
+        model.eval()
+        with torch.no_grad():
+            prob = model(x)
+        model.train()
+        outs = model(x)
+        # a seeded quadratic loss over every output: sum_k <out_k, r_k> with fixed random r_k
+        loss = 0.0
+        for k, o in enumerate(outs):
+            r = torch.randn(o.shape, generator=torch.Generator().manual_seed(700 + k))
+            loss = loss + (o * r).sum() / o.numel() ** 0.5
+        loss.backward()
+        named = dict(model.named_parameters())
+        head = "cls_pred" if not v["multi_layer"] else "layer5"
+        gnames = ["encoder.resnet.conv1.weight", "encoder.resnet.layer3.0.conv1.weight", "encoder.resnet.layer4.2.bn3.bias",
+                  f"{head}.conv_last.4.weight" if v["use_ppm"] else f"{head}.conv2d_list.2.weight"]
+        arrays[f"{tag}:prob_sample"] = prob[:, :, ::4, ::4]
+        arrays[f"{tag}:loss"] = loss.detach()
+        for k, o in enumerate(outs):
+            o = o.detach()
+            arrays[f"{tag}:out{k}"] = o if o.shape[1] == C else o.reshape(-1)[:: max(1, o.numel() // 4096)][:4096]
+        for n in gnames:
+            gr = named[n].grad
+            arrays[f"{tag}:grad:{n}"] = gr if gr.numel() <= 8192 else gr.reshape(-1)[:: max(1, gr.numel() // 4096)][:4096]
+        arrays[f"{tag}:grad_norm"] = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())).float()
+    mg.save("model_variants", **arrays)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = mg.import_reference()
     logger = logging.getLogger("golden-r4")
-    what = set(sys.argv[1:]) or {"avg", "pseudo", "evaluate", "step512"}
+    what = set(sys.argv[1:]) or {"avg", "pseudo", "evaluate", "variants", "step512"}
     if "avg" in what:
         aligner_avg(ref, logger)
     if "pseudo" in what:
         gener_pseudo(ref, logger)
     if "evaluate" in what:
         evaluate_pairs(ref, logger)
+    if "variants" in what:
+        model_variants(ref, logger)
     if "step512" in what:
         step512(ref, logger)
     print("done")

@@ -65,6 +65,15 @@ def test_state_dict_surface_matches_reference_layout():
         assert len(sd) == n and list(sd.keys()) == list(ref.keys())
         for k, shp in ref.items():
             assert tuple(sd[k].shape) == tuple(shp), k
+    # the class's other branches (reference Encoder.py:93-102,111-116): the single head `cls_pred` -- multi_layer=False is the DEFAULT
+    # of the reference class -- and the cascade pair, layer5 on the 1024-channel layer3 output
+    for (ml, ca, ppm), n in (((False, False, False), 326), ((False, False, True), 350), ((True, True, False), 334)):
+        v = Deeplabv2(dict(cfg, multi_layer=ml, cascade=ca, use_ppm=ppm))
+        ref = param_shapes("resnet50", 6, ppm, multi_layer=ml, cascade=ca)
+        assert len(v.state_dict()) == n and list(v.state_dict().keys()) == list(ref.keys())
+        for k, shp in ref.items():
+            assert tuple(v.state_dict()[k].shape) == tuple(shp), k
+    assert Deeplabv2(dict(backbone=dict(pretrained=False))).config.multi_layer is False and hasattr(Deeplabv2(dict(backbone=dict(pretrained=False))), "cls_pred")
     l4 = m.encoder.resnet.layer4
     assert l4[0].conv2.stride == (1, 1) and l4[0].conv2.dilation == (1, 1) and l4[0].downsample[0].stride == (1, 1)
     assert l4[1].conv2.dilation == (2, 2) and l4[1].conv2.padding == (2, 2)

@@ -940,3 +940,57 @@ def test_resnet101_aspp_src_step_vs_oracle():
         got, want = dict(model.named_parameters())[name].detach().cpu(), post[name].detach()
         upd, upd_ref = got - w0[name], want - w0[name]
         assert (upd - upd_ref).norm() / upd_ref.norm() < 6e-2, name
+
+
+VARIANTS = {"single_aspp": dict(multi_layer=False, cascade=False, use_ppm=False),
+            "single_ppm": dict(multi_layer=False, cascade=False, use_ppm=True),
+            "cascade_aspp": dict(multi_layer=True, cascade=True, use_ppm=False)}
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_deeplabv2_single_head_and_cascade_match_reference_golden(tag):
+    """Deeplabv2's other branches (reference uemda/models/Encoder.py:93-102,111-116,129-143,156-165; multi_layer=False is the class's
+    DEFAULT): the single head `cls_pred` and the cascade pair (layer5 on the layer3 output) on the HIP path -- state_dict keys,
+    training-mode outputs, eval-mode probabilities and gradients of a seeded quadratic loss against the reference's own."""
+    from oracle.weights import det_state_dict
+    from uemda_amd.models.Encoder import Deeplabv2
+    g = load_golden("model_variants")
+    v = VARIANTS[tag]
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=v["multi_layer"], cascade=v["cascade"],
+               use_ppm=v["use_ppm"], ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+    sd = det_state_dict("resnet50", C, v["use_ppm"], seed=2333, multi_layer=v["multi_layer"], cascade=v["cascade"])
+    model = Deeplabv2(cfg)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model = model.cuda()
+    if v["use_ppm"]:
+        model.cls_pred.conv_last[3].p = 0.0
+    x = g["image"].cuda()
+    model.eval()
+    with torch.no_grad():
+        prob = model(x)
+    torch.testing.assert_close(prob[:, :, ::4, ::4].cpu(), g[f"{tag}:prob_sample"], rtol=1e-3, atol=1e-5)
+    model.train()
+    outs = model(x)
+    assert len(outs) == (4 if v["cascade"] else 2)
+    loss = 0.0
+    for k, o in enumerate(outs):
+        ref = g[f"{tag}:out{k}"]
+        oc = o.detach().cpu().contiguous()
+        got = oc if o.shape[1] == C else oc.reshape(-1)[:: max(1, oc.numel() // 4096)][:4096]
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 1e-3, (tag, k, err)
+        r = torch.randn(o.shape, generator=torch.Generator().manual_seed(700 + k)).cuda()
+        loss = loss + (o * r).sum() / o.numel() ** 0.5
+    model.zero_grad()
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), g[f"{tag}:loss"], rtol=1e-3, atol=1e-3)
+    named = dict(model.named_parameters())
+    for k, ref in g.items():
+        if k.startswith(f"{tag}:grad:"):
+            gr = named[k.split(":", 2)[2]].grad.cpu().contiguous()
+            got = gr if gr.numel() <= 8192 else gr.reshape(-1)[:: max(1, gr.numel() // 4096)][:4096]
+            err = float((got - ref).norm() / (ref.norm() + 1e-12))
+            assert err < 5e-2, (k, err)                 # the fixtures' per-tensor bound for deep gradients at B = 2 (noise floor 2-3 %)
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())).float().cpu()
+    torch.testing.assert_close(gn, g[f"{tag}:grad_norm"], rtol=2e-2, atol=1e-4)

@@ -454,3 +454,48 @@ def test_full_model_ssl_step_b8_512():
     torch.testing.assert_close(out["grad_norm"], g["grad_norm"], rtol=2e-3, atol=1e-5)
     torch.testing.assert_close(model.p["encoder.resnet.bn1.running_mean"], g["post_bn1_running_mean"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(model.p["encoder.resnet.layer4.2.bn3.running_var"], g["post_l4_bn3_running_var"], rtol=1e-4, atol=1e-6)
+
+
+VARIANTS = {"single_aspp": dict(multi_layer=False, cascade=False, use_ppm=False),
+            "single_ppm": dict(multi_layer=False, cascade=False, use_ppm=True),
+            "cascade_aspp": dict(multi_layer=True, cascade=True, use_ppm=False)}
+
+
+def variant_loss(outs):
+    """the seeded quadratic loss of tests/golden/make_golden_r4.py model_variants"""
+    loss = 0.0
+    for k, o in enumerate(outs):
+        r = torch.randn(o.shape, generator=torch.Generator().manual_seed(700 + k)).to(o.device)
+        loss = loss + (o * r).sum() / o.numel() ** 0.5
+    return loss
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_deeplabv2_variants_golden(tag):
+    """The branches of Deeplabv2 no UemDA script builds (reference uemda/models/Encoder.py:93-102,111-116,129-143,156-165): the
+    single-head default and the cascade branch, forward in both modes and gradients, against the reference's own outputs."""
+    g = load_golden("model_variants")
+    v = VARIANTS[tag]
+    sd = det_state_dict("resnet50", C, v["use_ppm"], seed=2333, multi_layer=v["multi_layer"], cascade=v["cascade"])
+    model = OracleDeeplabv2(sd, "resnet50", C, v["use_ppm"], multi_layer=v["multi_layer"], cascade=v["cascade"])
+    model.eval()
+    with torch.no_grad():
+        prob = model(g["image"])
+    torch.testing.assert_close(prob[:, :, ::4, ::4], g[f"{tag}:prob_sample"], rtol=1e-4, atol=1e-6)
+    model.train()
+    outs = model(g["image"])
+    assert len(outs) == (4 if v["cascade"] else 2)
+    for k, o in enumerate(outs):
+        ref = g[f"{tag}:out{k}"]
+        got = o.detach() if o.shape[1] == C else o.detach().reshape(-1)[:: max(1, o.numel() // 4096)][:4096]
+        torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-4)
+    loss = variant_loss(outs)
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), g[f"{tag}:loss"], rtol=1e-4, atol=1e-4)
+    named = dict(model.named_parameters())
+    for k, ref in g.items():
+        if k.startswith(f"{tag}:grad:"):
+            gr = named[k.split(":", 2)[2]].grad
+            got = gr if gr.numel() <= 8192 else gr.reshape(-1)[:: max(1, gr.numel() // 4096)][:4096]
+            err = float((got - ref).norm() / (ref.norm() + 1e-12))
+            assert err < 2e-2, (k, err)

@@ -57,19 +57,28 @@ class Deeplabv2(nn.Module):
         self.set_default_config()
         self.config.update(config)
         cfg = self.config
-        if not cfg.multi_layer or cfg.cascade:
-            raise UemError("only the multi_layer=True, cascade=False branch (the one every UemDA script "
-                           "instantiates, train_ssl_uem.py:91-108) is implemented")
         self.encoder = ResNetEncoder(cfg.backbone)
-        if cfg.use_ppm:
-            ppm_cfg = {k: v for k, v in cfg.ppm.items() if k != "norm_layer"}
-            self.layer5 = PPMBilinear(**ppm_cfg)
-            self.layer6 = PPMBilinear(**ppm_cfg)
-        else:
-            self.layer5 = Classifier_Module(cfg.inchannels, [6, 12, 18, 24], [6, 12, 18, 24], cfg.num_classes)
-            self.layer6 = Classifier_Module(cfg.inchannels, [6, 12, 18, 24], [6, 12, 18, 24], cfg.num_classes)
-        if cfg.is_ins_norm:
-            self.instance_norm = nn.InstanceNorm2d(cfg.inchannels)      # holder (no parameters)
+
+        def head(inchannels, ppm_cfg):
+            if cfg.use_ppm:
+                if ppm_cfg is None:
+                    raise UemError("Deeplabv2(cascade=True, use_ppm=True) reads config['ppm1'] / config['ppm2'] (Encoder.py:94-96)")
+                return PPMBilinear(**{k: v for k, v in ppm_cfg.items() if k != "norm_layer"})
+            return Classifier_Module(inchannels, [6, 12, 18, 24], [6, 12, 18, 24], cfg.num_classes)
+        if cfg.multi_layer and cfg.cascade:                                       # Encoder.py:93-102: layer5 on the layer3 output
+            self.layer5 = head(cfg.inchannels // 2, cfg.get("ppm1", None))
+            self.layer6 = head(cfg.inchannels, cfg.get("ppm2", None))
+        elif cfg.multi_layer:                                                     # Encoder.py:103-110: what every UemDA script builds
+            self.layer5 = head(cfg.inchannels, cfg.ppm)
+            self.layer6 = head(cfg.inchannels, cfg.ppm)
+        else:                                                                     # Encoder.py:111-116: the class's default
+            self.cls_pred = head(cfg.inchannels, cfg.ppm)
+        if cfg.is_ins_norm:                                                       # holders (no parameters), Encoder.py:118-123
+            if cfg.cascade:
+                self.instance_norm1 = nn.InstanceNorm2d(cfg.inchannels)
+                self.instance_norm2 = nn.InstanceNorm2d(cfg.inchannels)
+            else:
+                self.instance_norm = nn.InstanceNorm2d(cfg.inchannels)
         self._arena = None
         self._grad_arena = None
 
@@ -163,6 +172,25 @@ class Deeplabv2(nn.Module):
                 p.grad = p._uem_grad_view()
 
     # ---- forward ----------------------------------------------------------------------------------------
+    def _head(self, feat, head):
+        """one Classifier_Module / PPMBilinear on its own feature map (the single-head default, the cascade branch)"""
+        bf16 = self.encoder.storage == "bf16" and self.training
+        if self.config.use_ppm:
+            from . import ppm
+            ppm.PPMHeadFn.prec = "bf16" if bf16 else None
+            try:
+                return ppm.ppm_head(feat, head)
+            finally:
+                ppm.PPMHeadFn.prec = None
+        # the two-head GEMM with the same module on both sides: the second head's gradient is zero and both halves add into the one
+        # set of parameters (uem_aspp_unpack_grad accumulates with atomics for exactly this case)
+        blocks.ASPPHeadsFn.prec = "bf16" if bf16 else None
+        try:
+            x1, _ = blocks.ASPPHeadsFn.apply(feat, head, head, *list(head.parameters()))
+            return x1
+        finally:
+            blocks.ASPPHeadsFn.prec = None
+
     def _heads(self, feat):
         bf16 = self.encoder.storage == "bf16" and self.training
         if self.config.use_ppm:
@@ -182,20 +210,45 @@ class Deeplabv2(nn.Module):
         finally:
             blocks.ASPPHeadsFn.prec = None
 
+    def _prob(self, x1, x2, size):
+        """(softmax(up(x1)) + softmax(up(x2))) / 2, bilinear align_corners=True (Encoder.py:139-141,153-155); x2 = x1 gives the
+        single head's softmax(up(x1)) (:164-165): (a + a) / 2 is a, exactly"""
+        n, h, w, c = x1.shape
+        H, W = size
+        prob = torch.empty((n, c, H, W), device=x1.device, dtype=torch.float32)
+        ops.call("uem_upsample_softmax_avg", ops.ptr(x1.contiguous()), ops.ptr(x2.contiguous()), ops.ptr(prob),
+                 n, c, h, w, H, W, ops.stream())
+        return prob
+
     def forward(self, x):
         ops.need_gpu(x)
         if self._arena is None:
             raise UemError("Deeplabv2: move the model to the MI355X device first (model.cuda())")
-        feat = self.encoder.forward_nhwc(x)[-1]                               # Encoder.py:145
-        if self.config.is_ins_norm:
-            feat = blocks.InstNormFn.apply(feat, self.instance_norm.eps)      # Encoder.py:146-147
+        cfg = self.config
+        stages = self.encoder.forward_nhwc(x)
+        if cfg.multi_layer and cfg.cascade:                                       # Encoder.py:129-143
+            if self.encoder.storage != "fp32":
+                raise UemError("Deeplabv2(cascade=True) reads the layer3 output as an fp32 map: use fp32 storage")
+            feat1, feat2 = stages[-2:]
+            if cfg.is_ins_norm:
+                feat1 = blocks.InstNormFn.apply(feat1, self.instance_norm1.eps)
+                feat2 = blocks.InstNormFn.apply(feat2, self.instance_norm2.eps)
+            x1, x2 = self._head(feat1, self.layer5), self._head(feat2, self.layer6)
+            if self.training:
+                self._nbt_step()
+                return ops.as_nchw_view(x1), ops.as_nchw_view(feat1), ops.as_nchw_view(x2), ops.as_nchw_view(feat2)
+            return self._prob(x1, x2, x.shape[-2:])
+        feat = stages[-1]                                                         # Encoder.py:145
+        if cfg.is_ins_norm:
+            feat = blocks.InstNormFn.apply(feat, self.instance_norm.eps)          # Encoder.py:146-147
+        if not cfg.multi_layer:                                                   # Encoder.py:156-165
+            x1 = self._head(feat, self.cls_pred)
+            if self.training:
+                self._nbt_step()
+                return ops.as_nchw_view(x1), ops.as_nchw_view(feat)
+            return self._prob(x1, x1, x.shape[-2:])
         x1, x2 = self._heads(feat)
         if self.training:
             self._nbt_step()
             return ops.as_nchw_view(x1), ops.as_nchw_view(x2), ops.as_nchw_view(feat)   # Encoder.py:150-151
-        n, h, w, c = x1.shape
-        H, W = x.shape[-2:]
-        prob = torch.empty((n, c, H, W), device=x.device, dtype=torch.float32)
-        ops.call("uem_upsample_softmax_avg", ops.ptr(x1.contiguous()), ops.ptr(x2.contiguous()), ops.ptr(prob),
-                 n, c, h, w, H, W, ops.stream())                               # Encoder.py:153-155
-        return prob
+        return self._prob(x1, x2, x.shape[-2:])                                   # Encoder.py:153-155
