@@ -213,12 +213,14 @@ def test_weight_prep_refreshes_every_derived_bank_in_one_launch():
     same(batched(), singles())
     # a parameter that dies leaves the table before its memory can be read again
     prep = ops.PREP.by_device[torch.cuda.current_device()]
-    n_before = len(prep.jobs)
+    addr = p3b.data_ptr()
+    assert sum(1 for (a, _k) in prep.jobs if a == addr) == 5          # p3b's transposed bank and its four Winograd banks
     del p3b, first
     gc.collect()
     ops.weights_changed()
     got = ops.weight_transpose_cached(p1)
     assert torch.equal(got, ops.weight_transpose(ops.weight_ohwi(p1)))
-    assert len(prep.jobs) == n_before - 5                             # p3b's transposed bank and its four Winograd banks are gone
+    assert not any(a == addr for (a, _k) in prep.jobs)                # gone with the parameter (and so is every other dead model's)
+    assert all(j["ref"]() is not None for j in prep.jobs.values())
     lib = ops._lib.load()
     assert lib.uem_weight_prep_blocks(1, 100, 64, 9) == -1 and lib.uem_weight_prep_blocks(0, 256, 64, 1) == 16

@@ -64,7 +64,7 @@ __device__ __forceinline__ float uvem_weight_dev(float u, float m, float t, floa
 // applied per pixel), then added with the two x weights into a per-wave LDS image of the band's two logit rows
 // (LDS atomics; per-wave images summed in fixed order).  Band cy's second row and band cy+1's first row are the
 // same logit row: the bands' images go to the workspace and loss_band_combine_kernel adds the pair.
-#define LOSS_THREADS 512                 // one column per thread at W = 512 (256: two columns in sequence, 4 waves per SIMD on the chip)
+#define LOSS_THREADS 256                 // (512 -- one column per thread at W = 512 -- measured the same 0.21 ms: the bands are VALU-bound, not latency-bound)
 #define LOSS_WAVES (LOSS_THREADS / 64)
 template <int CMAX, int MODE>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
