@@ -166,6 +166,39 @@ def test_scatter_matches_oracle(reduce):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
 
 
+def test_scatter_other_ranks_and_dims():
+    """beyond the path's (B, N, C) / dim=1 call: 1-d, 2-d with dim 0 / -1, 4-d with a middle dim, broadcast index, dim_size, refusals"""
+    from oracle import gast
+    from uemda_amd.ops import UemError
+    from uemda_amd.scatter import scatter
+    g = torch.Generator().manual_seed(8)
+
+    def ref(src, idx, dim, reduce, dim_size=None):
+        d = dim if dim >= 0 else dim + src.dim()
+        ii = idx
+        if ii.dim() == 1:                                  # torch_scatter's broadcast rule
+            for _ in range(d):
+                ii = ii.unsqueeze(0)
+        while ii.dim() < src.dim():
+            ii = ii.unsqueeze(-1)
+        return gast.scatter(src, ii.expand_as(src), d, reduce, dim_size)
+    cases = [(torch.randn(500, generator=g), torch.randint(0, 9, (500,), generator=g), 0),
+             (torch.randn(300, 7, generator=g), torch.randint(0, 5, (300, 1), generator=g), 0),
+             (torch.randn(4, 300, generator=g), torch.randint(0, 11, (4, 300), generator=g), -1),
+             (torch.randn(2, 3, 200, 5, generator=g), torch.randint(0, 13, (2, 3, 200, 1), generator=g), 2),
+             (torch.randn(2, 3, 200, 5, generator=g), torch.randint(0, 13, (200,), generator=g), -2)]        # a 1-d index lined up with dim
+    for src, idx, dim in cases:
+        for reduce in ("max", "sum", "mean"):
+            out = scatter(dev(src), dev(idx), dim=dim, reduce=reduce)
+            torch.testing.assert_close(out.cpu(), ref(src, idx, dim, reduce), rtol=1e-5, atol=1e-5)
+    out = scatter(dev(cases[0][0]), dev(cases[0][1]), dim=0, reduce="sum", dim_size=20)
+    assert out.shape == (20,) and float(out[9:].abs().max()) == 0.0
+    with pytest.raises(UemError):
+        scatter(dev(cases[3][0]), dev(torch.randint(0, 3, (2, 3, 200, 5))), dim=2)       # an index per trailing element: not this kernel's layout
+    with pytest.raises(UemError):
+        scatter(dev(cases[0][0]), dev(cases[0][1]), dim=0, out=torch.zeros(9, device="cuda"))
+
+
 def test_ragged_and_empty_edges():
     """non-multiple-of-tile sizes, a batch with every pixel ignored, all-ignored superpixels."""
     from oracle import gast, synth
