@@ -553,7 +553,7 @@ struct ConvDmaCfg {
 // that can fall outside the image (only then does the affine path need the validity words)
 template <int BN, int KB, int MODE, bool AFFINE, bool PADDED, int EPI, bool PERSIST>
 __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB, PERSIST>::BPC)) void conv_dma_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes,
-                                                                                          const int ntiles, const int stagger) {
+                                                                                          const int ntiles) {
     using C = ConvDmaCfg<BN, KB, PERSIST>;
     constexpr int CPR = C::CPR, RPT = C::RPT, AR = C::AR, BR = C::BR;
     constexpr int SWS = KB == 32 ? 1 : 2;                                 // swizzle = (row >> SWS) & (CPR - 1): rows per 256-B bank row
@@ -781,16 +781,6 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB, PERSIST>::BPC)) void conv_
     asm volatile("" ::: "memory")
     float* const st0 = smem;
     float* const epi_area = C::EPI_SEPARATE ? smem + 2 * C::STAGE_FLOATS : smem;
-    // Round 4: de-phase the persistent blocks that share a CU.  They start together and every tile costs them the same, so they stay
-    // in lock step: all in their MFMA phase (sharing each SIMD's matrix pipe), then all in their epilogue (sharing the CU's path to
-    // HBM) -- the residual-tail data gradients ran at exactly t_mfma + t_streams per tile and CU (layer3: 6.9 + 5.2 us x 16 tiles =
-    // 193 us, measured 198), as if one block were resident.  Block b of a 768- / 512-block grid shares its CU with b + 256 and b + 512
-    // (observed placement: round-robin over 8 XCDs, then over an XCD's 32 CUs; speed only, never correctness): the second and third
-    // start `stagger` x 512 clocks later each, a fraction of the tile period the launcher computes, and the phases interleave.
-    if (PERSIST && stagger > 0) {
-        const int slot = (int)(blockIdx.x >> 8);
-        for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     if (KT > 0) step(st0, st0 + C::STAGE_FLOATS, Ssc, true, false);      // first operand tile of the block's first tile
     int par = 0;                                                         // stage the next k-step consumes
     for (int vc = blockIdx.x; vc < ntiles; vc += gridDim.x) {
@@ -1205,23 +1195,8 @@ static void conv_dma_go(const ConvP& p, bool affine, unsigned xb, unsigned wb, h
     // "padded" variant = the general gather with validity words; besides filters with taps outside the image it takes the
     // strided 1x1 layers, so that the unpadded affine variant can assume output pixel m reads input pixel m
     const bool padded = p.KH * p.KW > 1 || p.stride != 1 || p.pad != 0;
-    // stagger of the co-resident persistent blocks (see the kernel): tile period / resident blocks, in 512-clock sleeps.  Period =
-    // MFMA time of a tile (64 clocks per 32x32x2 MFMA, MT*NT*K/2 of them per wave) + its epilogue streams at a CU's share of HBM
-    // (~25 GB/s: 0.384 clocks per float moved).  Only launches whose epilogue carries extra streams (fused BatchNorm passes, the
-    // residual tail) get it: a plain GEMM's phases are short and interleave by themselves.  UEM_CONV_STAGGER: percent of that (0 off).
-    static const int stagger_pct = getenv("UEM_CONV_STAGGER") ? atoi(getenv("UEM_CONV_STAGGER")) : 100;
-    int stagger = 0;
-    if (PERSIST && stagger_pct > 0 && grid == slots && ntiles >= 2 * slots) {
-        const int streams = 1 + (p.acc_src ? 1 : 0) + (p.accumulate ? 1 : 0) + (p.bn_z ? 1 : 0);      // dx out + what the epilogue reads
-        const bool heavy = MODE == 1 && (p.acc_src || p.accumulate || p.bn_z);
-        if (heavy) {
-            const double mfma_clk = 32.0 * (BM / 4 / 32) * (BN_ / 32) * (double)p.ntaps * p.Cin;
-            const double epi_clk = 0.384 * streams * BM * BN_;
-            stagger = (int)((mfma_clk + epi_clk) / C::BPC / 512.0 * stagger_pct / 100.0 + 0.5);
-        }
-    }
     auto go = [&](auto k) {
-        if (uem_allow_lds((const void*)k, lds)) k<<<grid, 256, lds, st>>>(p, xb, wb, ntiles, stagger);
+        if (uem_allow_lds((const void*)k, lds)) k<<<grid, 256, lds, st>>>(p, xb, wb, ntiles);
     };
     const bool full = p.M % BM == 0 && (MODE == 0 || p.sub == 1) && p.bias == nullptr && !(MODE == 0 && p.accumulate);
     const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);

@@ -60,3 +60,26 @@ extern "C" int uemdbg_mfma_rate(float* out, int blocks, int iters, int mode, voi
     return uem_check_launch("mfma_rate");
 }
 
+
+// Diagnostic only: where do the blocks of a persistent launch land?  Every block records its XCC id and HW_ID (compute unit, shader
+// array / engine) and stays resident for `spin` clocks so that the grid fills the chip as a real persistent launch does.
+// out[3*b + 0] = XCC_ID, + 1 = HW_ID, + 2 = start time (s_memtime, low 32 bits)
+__global__ __launch_bounds__(256) void block_census_kernel(unsigned* out, int spin) {
+    extern __shared__ float pad[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        out[3 * blockIdx.x + 0] = xcc;
+        out[3 * blockIdx.x + 1] = hw;
+        out[3 * blockIdx.x + 2] = (unsigned)t0;
+        pad[0] = 0.f;
+    }
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < spin) __builtin_amdgcn_s_sleep(4);
+}
+extern "C" int uemdbg_block_census(unsigned* out, int blocks, int lds_bytes, int spin, void* stream) {
+    if (!uem_allow_lds((const void*)block_census_kernel, (size_t)lds_bytes)) return uem_check_launch("block_census");
+    block_census_kernel<<<blocks, 256, lds_bytes, (hipStream_t)stream>>>(out, spin);
+    return uem_check_launch("block_census");
+}
