@@ -66,11 +66,14 @@ __device__ __forceinline__ float uvem_weight_dev(float u, float m, float t, floa
 // same logit row: the bands' images go to the workspace and loss_band_combine_kernel adds the pair.
 #define LOSS_THREADS 256                 // (512 -- one column per thread at W = 512 -- measured the same 0.21 ms: the bands are VALU-bound, not latency-bound)
 #define LOSS_WAVES (LOSS_THREADS / 64)
-template <int CMAX, int MODE>
+// EXACT: the class count IS CMAX (6 and 7, the reference's two datasets, have their own CMAX): the `c < C` guards of the unrolled
+// per-class loops fold at compile time instead of costing a compare + select each
+template <int CMAX, int MODE, bool EXACT>
 __global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
     const float* __restrict__ lg1, const float* __restrict__ lg2, const int64_t* __restrict__ label,
     const float* __restrict__ soft, const float* __restrict__ pixw, float* __restrict__ band_grad,
-    float* __restrict__ partial, int C, int h, int w, int H, int W, float um, float ut, float inv_gamma, int64_t ignore) {
+    float* __restrict__ partial, int C_, int h, int w, int H, int W, float um, float ut, float inv_gamma, int64_t ignore) {
+    const int C = EXACT ? CMAX : C_;
     extern __shared__ __attribute__((aligned(16))) float loss_sm[];
     float* low = loss_sm;                              // [2 heads][2 rows][w][CMAX]
     float* acc = loss_sm + 4 * w * CMAX;               // [LOSS_WAVES][2 rows][w][2 heads][CMAX]
@@ -260,7 +263,7 @@ __global__ void scale_by_device_scalar_kernel(float* __restrict__ a, float* __re
     }
 }
 
-static inline int loss_cmax(int C) { return C <= 4 ? 4 : (C <= 6 ? 6 : (C <= 8 ? 8 : 16)); }
+static inline int loss_cmax(int C) { return C <= 4 ? 4 : (C <= 6 ? 6 : (C == 7 ? 7 : (C <= 8 ? 8 : 16))); }
 extern "C" int64_t uem_loss_workspace_floats(int B, int C, int h, int w) {
     const int cmax = loss_cmax(C);
     return (int64_t)B * h * 4 * w * cmax + (int64_t)B * h * 4 + 4;
@@ -280,9 +283,15 @@ static void loss_launch(const float* l1, const float* l2, const int64_t* label, 
     float* partial = ws + (size_t)bands * 4 * w * CMAX;
     float* inv_valid = partial + (size_t)bands * 4;
     const size_t lds = (size_t)(4 + 4 * LOSS_WAVES) * w * CMAX * sizeof(float);
-    auto k = loss_band_kernel<CMAX, MODE>;
-    if (!uem_allow_lds((const void*)k, lds)) return;
-    k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
+    if (C == CMAX) {
+        auto k = loss_band_kernel<CMAX, MODE, true>;
+        if (!uem_allow_lds((const void*)k, lds)) return;
+        k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
+    } else {
+        auto k = loss_band_kernel<CMAX, MODE, false>;
+        if (!uem_allow_lds((const void*)k, lds)) return;
+        k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
+    }
     loss_finalize_kernel<<<1, 256, 0, st>>>(partial, bands, MODE, nheads, ce_denominator, loss_out, MODE ? inv_valid : nullptr);
     const int64_t n = (int64_t)B * h * w * C;
     loss_band_combine_kernel<CMAX><<<(int)uem_cdiv(n, 256), 256, 0, st>>>(band_grad, d1, d2, B, C, h, w, coef,
@@ -304,7 +313,7 @@ extern "C" int uem_ce_upsampled(const float* logits1, const float* logits2, cons
     const float coef = loss_scale / denom / (float)nheads;
 #define CE_GO(CM) loss_launch<CM, 0>(logits1, logits2, label, nullptr, pixel_weight, loss_out, dlogits1, dlogits2, workspace, B, C, \
                                      h, w, H, W, 0.f, 0.f, 0.f, ignore_label, coef, denom, st)
-    switch (loss_cmax(C)) { case 4: CE_GO(4); break; case 6: CE_GO(6); break; case 8: CE_GO(8); break; default: CE_GO(16); }
+    switch (loss_cmax(C)) { case 4: CE_GO(4); break; case 6: CE_GO(6); break; case 7: CE_GO(7); break; case 8: CE_GO(8); break; default: CE_GO(16); }
 #undef CE_GO
     return uem_check_launch("ce_upsampled");
 }
@@ -323,7 +332,7 @@ extern "C" int uem_uvem_upsampled(const float* logits1, const float* logits2, co
     const float coef = loss_scale / (float)nheads;       // 1/(valid+eps) is applied by the combine pass, once the count is known
 #define UV_GO(CM) loss_launch<CM, 1>(logits1, logits2, hard, soft, pixel_weight, loss_out, dlogits1, dlogits2, workspace, B, C, h, w, \
                                      H, W, m, t, 1.0f / gamma, ignore_label, coef, 1.f, st)
-    switch (loss_cmax(C)) { case 4: UV_GO(4); break; case 6: UV_GO(6); break; case 8: UV_GO(8); break; default: UV_GO(16); }
+    switch (loss_cmax(C)) { case 4: UV_GO(4); break; case 6: UV_GO(6); break; case 7: UV_GO(7); break; case 8: UV_GO(8); break; default: UV_GO(16); }
 #undef UV_GO
     return uem_check_launch("uvem_upsampled");
 }

@@ -170,11 +170,12 @@ extern "C" int uem_index_max(const int64_t* idx, int64_t count, int64_t* out, vo
 // in (superpixels are spatially compact: a column of 16 pixels crosses one or two of them), so the LDS table sees one update per
 // (column, segment run) instead of one per pixel: the round-3 kernel issued 6 LDS atomics per pixel, 16 lanes of every wave on the
 // same address (148 us for 268 MB at B = 32: LDS-atomic bound at 1.8 TB/s).  Rows of a plane are read coalesced (lanes = columns).
-template <int CMAX>
+template <int CMAX, int CEX>
 __global__ __launch_bounds__(256) void segment_max_kernel(const float* __restrict__ soft,
                                                           const int64_t* __restrict__ sup,
-                                                          uint32_t* __restrict__ seg, int C, int H, int W, int S,
+                                                          uint32_t* __restrict__ seg, int C_, int H, int W, int S,
                                                           int* __restrict__ oor) {
+    const int C = CEX > 0 ? CEX : C_;
     __shared__ int keys[SEG_SLOTS];
     __shared__ uint32_t vals[SEG_SLOTS][CMAX];
     const int tid = threadIdx.x;
@@ -261,8 +262,10 @@ extern "C" int uem_segment_max_planar(const float* soft, const int64_t* sup, uin
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && H > 0 && W > 0 && S > 0, "segment_max: bad shape");
     dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)uem_cdiv(H, SEG_ROWS), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 8) segment_max_kernel<8><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
-    else segment_max_kernel<16><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
+    if (C == 6) segment_max_kernel<8, 6><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
+    else if (C == 7) segment_max_kernel<8, 7><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
+    else if (C <= 8) segment_max_kernel<8, 0><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
+    else segment_max_kernel<16, 0><<<grid, 256, 0, st>>>(soft, sup, seg_keys, C, H, W, S, out_of_range);
     return uem_check_launch("segment_max");
 }
 
@@ -305,12 +308,16 @@ __device__ __forceinline__ void xlerp_lds(const float* __restrict__ row, int C, 
     }
 }
 
-template <int CMAX>
+// CEX: the class count when it is one of the two the reference's datasets have (6: ISPRS, 7: LoveDA) -- every `c < C` guard of the
+// unrolled per-class loops then folds at compile time (with a run-time C they were 266 v_cndmask + their compares per pixel, a
+// quarter of the kernel's instructions); 0 = any C <= CMAX.
+template <int CMAX, int CEX>
 __global__ __launch_bounds__(256) void label_refine_kernel(
     const float* __restrict__ soft, const int64_t* __restrict__ sup, const float* __restrict__ sim,
     const float* __restrict__ lg1, const float* __restrict__ lg2, const uint32_t* __restrict__ seg,
-    const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C, int h,
+    const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C_, int h,
     int w, int H, int W, int S, float inv_temp, int mode, int ncell) {
+    const int C = CEX > 0 ? CEX : C_;
     extern __shared__ __attribute__((aligned(16))) float lowres[];       // [3 maps][ncell][CMAX], interpolated in y
     const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * 256;
     const size_t plane = (size_t)H * W;
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     __shared__ float wmax[4][CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-        const float m = wave_max(o[c]);
+        const float m = c < C ? wave_max(o[c]) : 0.f;
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6][c] = m;
     }
     __syncthreads();
@@ -484,13 +491,17 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
     UEM_REQUIRE(lds <= 150 * 1024, "label_refine: low-resolution strip does not fit LDS");
     dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)H, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 8) {
-        if (uem_allow_lds((const void*)label_refine_kernel<8>, lds)) label_refine_kernel<8><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
-                                                       workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);
-    } else {
-        if (uem_allow_lds((const void*)label_refine_kernel<16>, lds)) label_refine_kernel<16><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out,
-                                                        workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);
-    }
+#define LAUNCH_LR(CM, CE)                                                                                                        \
+    do {                                                                                                                         \
+        if (uem_allow_lds((const void*)label_refine_kernel<CM, CE>, lds))                                                         \
+            label_refine_kernel<CM, CE><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out, \
+                                                                workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);         \
+    } while (0)
+    if (C == 6) LAUNCH_LR(8, 6);
+    else if (C == 7) LAUNCH_LR(8, 7);
+    else if (C <= 8) LAUNCH_LR(8, 0);
+    else LAUNCH_LR(16, 0);
+#undef LAUNCH_LR
     blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(workspace, plane_max, (int)(grid.x * grid.y), C, cmax);
     return uem_check_launch("label_refine");
 }
@@ -522,11 +533,12 @@ extern "C" int uem_plane_max(const float* mask, uint32_t* plane_max, int B, int 
     return uem_check_launch("plane_max");
 }
 
-template <int CMAX>
+template <int CMAX, int CEX>
 __global__ __launch_bounds__(256) void pseudo_select_kernel(const float* __restrict__ mask,
                                                             const uint32_t* __restrict__ plane_max,
                                                             int64_t* __restrict__ hard, int* __restrict__ range_flag,
-                                                            int C, int64_t HW, float top, float low, int64_t ignore) {
+                                                            int C_, int64_t HW, float top, float low, int64_t ignore) {
+    const int C = CEX > 0 ? CEX : C_;
     const int b = blockIdx.y;
     float thr[CMAX];
 #pragma unroll
@@ -554,8 +566,10 @@ extern "C" int uem_pseudo_select(const float* mask, const uint32_t* plane_max, i
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && HW > 0, "pseudo_select: bad shape");
     dim3 grid((unsigned)uem_cdiv(HW, 256), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 8) pseudo_select_kernel<8><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
-    else pseudo_select_kernel<16><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
+    if (C == 6) pseudo_select_kernel<8, 6><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
+    else if (C == 7) pseudo_select_kernel<8, 7><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
+    else if (C <= 8) pseudo_select_kernel<8, 0><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
+    else pseudo_select_kernel<16, 0><<<grid, 256, 0, st>>>(mask, plane_max, hard, range_flag, C, HW, cutoff_top, cutoff_low, ignore_label);
     return uem_check_launch("pseudo_select");
 }
 
