@@ -2,7 +2,7 @@
 """Round-4 golden vectors, produced by running the REFERENCE itself (imported from /root/reference under the stubs of
 make_golden.py, CPU only, build container only):
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r4.py [step512] [avg] [pseudo] [evaluate] [variants]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_r4.py [step512] [r101] [avg] [pseudo] [evaluate] [variants]
 
   model_aspp_r50_b8_512.npz   one tools/train_ssl_uem.py iteration of R50-ASPP at the reference's own operating point -- 8 source
                               + 8 target tiles (configs/ToPotsdam.py:58, configs/st/uemda/2potsdam.py:31,43) of 512x512, the
@@ -10,6 +10,7 @@ make_golden.py, CPU only, build container only):
                               pseudo-labels, losses, prototypes, gradient norm, the first-step update of EVERY parameter tensor
                               (256 strided samples) with its fp32 noise floor (the same step under the other CPU conv backend and
                               with the images moved by one unit in the last place), as model_aspp_r50_b2_256.npz holds them
+  model_aspp_r101_b2_256.npz  the same step for ResNet-101 (BASELINE config 5's model family; configs/st/uemda/2potsdam.py:6), B = 2, 256 x 256
   aligner_avg.npz             Aligner.update_avg x2 + init_avg (uemda/gast/alignment.py:107-126): the --ckpt-proto prototypes
   gener_pseudo.npz            gener_target_pseudo (uemda/gast/pseudo_generation.py:96-155) through a closed-form model: the
                               `<fname>.pt` wire format (slide=False: model -> bilinear align_corners=True resize -> (C,H,W) fp32),
@@ -56,16 +57,15 @@ class ClosedFormModel(nn.Module):
         return torch.softmax(torch.einsum("kc,bchw->bkhw", w, x), dim=1)
 
 
-def step512(ref, logger):
+def step512(ref, logger, B=8, S=512, rtype="resnet50", name="model_aspp_r50_b8_512", soft_stride=16):
     from oracle import synth
     from oracle.step import HYPER
     from oracle.weights import det_state_dict
-    B, S = 8, 512
 
     def run(mkldnn=True, ulp_noise=False):
         torch.backends.mkldnn.enabled = mkldnn
-        sd = det_state_dict("resnet50", C, False, seed=2333)
-        model = ref.Encoder.Deeplabv2(mg.model_cfg(False, C))
+        sd = det_state_dict(rtype, C, False, seed=2333)
+        model = ref.Encoder.Deeplabv2(mg.model_cfg(False, C, rtype))
         model.load_state_dict(sd, strict=True)
         batch = synth.make_batch(B=B, H=S, W=S, C=C, k=2048, seed=2333)
         if ulp_noise:
@@ -105,7 +105,7 @@ def step512(ref, logger):
         del model, opt
         return out
 
-    print("G-step R50-ASPP B=8+8 512x512 (three reference steps: plain, other conv backend, inputs moved by 1 ulp)", flush=True)
+    print(f"G-step {rtype}-ASPP B={B}+{B} {S}x{S} (three reference steps: plain, other conv backend, inputs moved by 1 ulp)", flush=True)
     r = run()
     print("  plain step done", flush=True)
     r3 = run(ulp_noise=True)
@@ -119,10 +119,10 @@ def step512(ref, logger):
     hard_floor = min(float((r["hard"] == q["hard"]).float().mean()) for q in (r2, r3))
     feat_t = r["feat_t"]
     idx = torch.from_numpy(np.random.default_rng(3).integers(0, feat_t.numel(), 4096))
-    mg.save("model_aspp_r50_b8_512", pred_s1=r["ps1"], pred_s2=r["ps2"], pred_t1=r["pt1"], pred_t2=r["pt2"], feat_idx=idx,
+    mg.save(name, pred_s1=r["ps1"], pred_s2=r["ps2"], pred_t1=r["pt1"], pred_t2=r["pt2"], feat_idx=idx,
             feat_t_sample=feat_t.reshape(-1)[idx], feat_s_sample=r["feat_s"].reshape(-1)[idx],
             feat_t_chmean=feat_t.mean(dim=(0, 2, 3)), feat_t_chvar=feat_t.var(dim=(0, 2, 3)),
-            soft_sample=r["soft"][:, :, ::16, ::16], hard=r["hard"].to(torch.int8), loss_source=r["loss_s"], loss_target=r["loss_t"],
+            soft_sample=r["soft"][:, :, ::soft_stride, ::soft_stride], hard=r["hard"].to(torch.int8), loss_source=r["loss_s"], loss_target=r["loss_t"],
             prototypes=r["protos"], grad_norm=r["gnorm"], lr=r["lr"], post_bn1_running_mean=r["bn1_rm"],
             post_bn1_running_var=r["bn1_rv"], post_l4_bn3_running_var=r["l4_rv"],
             upd_names=np.array(names), upd_offsets=np.cumsum([0] + [r["upd"][n].numel() for n in names]),
@@ -281,7 +281,7 @@ def main():
     torch.set_num_threads(8)
     ref = mg.import_reference()
     logger = logging.getLogger("golden-r4")
-    what = set(sys.argv[1:]) or {"avg", "pseudo", "evaluate", "variants", "step512"}
+    what = set(sys.argv[1:]) or {"avg", "pseudo", "evaluate", "variants", "step512", "r101"}
     if "avg" in what:
         aligner_avg(ref, logger)
     if "pseudo" in what:
@@ -292,6 +292,8 @@ def main():
         model_variants(ref, logger)
     if "step512" in what:
         step512(ref, logger)
+    if "r101" in what:                                   # BASELINE config 5's model family: ResNet-101 (23 blocks in layer3), B = 2, 256 x 256
+        step512(ref, logger, B=2, S=256, rtype="resnet101", name="model_aspp_r101_b2_256", soft_stride=4)
     print("done")
 
 

@@ -435,18 +435,20 @@ def test_evaluate_feeds_the_metric_golden():
     assert np.array_equal(cm, g["confusion"].numpy())
 
 
-def test_full_model_ssl_step_b8_512():
+@pytest.mark.parametrize("name,B,S,rtype,stride", [("model_aspp_r50_b8_512", 8, 512, "resnet50", 16),
+                                                   ("model_aspp_r101_b2_256", 2, 256, "resnet101", 4)])
+def test_full_model_ssl_step_at(name, B, S, rtype, stride):
     """One train_ssl_uem step of R50-ASPP at the reference's own batch (8 + 8, configs/ToPotsdam.py:58) and the benchmark's tile
-    (512 x 512): the oracle against the reference's outputs, bounds scaled by how far the reference moves against itself."""
-    g = load_golden("model_aspp_r50_b8_512")
-    model = OracleDeeplabv2(det_state_dict("resnet50", C, False, seed=2333), "resnet50", C, False)
-    batch = synth.make_batch(B=8, H=512, W=512, C=C, k=2048, seed=2333)
+    (512 x 512), and of ResNet101-ASPP (BASELINE config 5's model family): the oracle against the reference's outputs."""
+    g = load_golden(name)
+    model = OracleDeeplabv2(det_state_dict(rtype, C, False, seed=2333), rtype, C, False)
+    batch = synth.make_batch(B=B, H=S, W=S, C=C, k=2048, seed=2333)
     opt = SGDState(model.parameters(), HYPER["momentum"], HYPER["weight_decay"])
     out = ssl_step(model, opt, batch["prototypes"], batch, float(g["lr"]), HYPER, dropout=False)
     for k in ("pred_s1", "pred_s2", "pred_t1", "pred_t2"):
         err = float((out[k] - g[k]).abs().max() / g[k].abs().max())
         assert err < 1e-3, (k, err)
-    torch.testing.assert_close(out["label_t_soft"][:, :, ::16, ::16], g["soft_sample"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out["label_t_soft"][:, :, ::stride, ::stride], g["soft_sample"], rtol=1e-3, atol=1e-5)
     assert (out["label_t_hard"] == g["hard"].long()).float().mean().item() >= 0.9995
     torch.testing.assert_close(out["loss_source"], g["loss_source"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(out["loss_target"], g["loss_target"], rtol=1e-4, atol=1e-6)
