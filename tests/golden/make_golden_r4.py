@@ -119,6 +119,8 @@ def step512(ref, logger, B=8, S=512, rtype="resnet50", name="model_aspp_r50_b8_5
     hard_floor = min(float((r["hard"] == q["hard"]).float().mean()) for q in (r2, r3))
     feat_t = r["feat_t"]
     idx = torch.from_numpy(np.random.default_rng(3).integers(0, feat_t.numel(), 4096))
+    # ... and the pooled features the mining reads (absolute: they are O(1) after the last ReLU)
+    feat_floor = max(float((r["feat_t"].reshape(-1)[idx] - q["feat_t"].reshape(-1)[idx]).abs().max()) for q in (r2, r3))
     mg.save(name, pred_s1=r["ps1"], pred_s2=r["ps2"], pred_t1=r["pt1"], pred_t2=r["pt2"], feat_idx=idx,
             feat_t_sample=feat_t.reshape(-1)[idx], feat_s_sample=r["feat_s"].reshape(-1)[idx],
             feat_t_chmean=feat_t.mean(dim=(0, 2, 3)), feat_t_chvar=feat_t.var(dim=(0, 2, 3)),
@@ -127,8 +129,9 @@ def step512(ref, logger, B=8, S=512, rtype="resnet50", name="model_aspp_r50_b8_5
             post_bn1_running_var=r["bn1_rv"], post_l4_bn3_running_var=r["l4_rv"],
             upd_names=np.array(names), upd_offsets=np.cumsum([0] + [r["upd"][n].numel() for n in names]),
             upd_samples=torch.cat([r["upd"][n] for n in names]), upd_noise_floor=noise,
-            ref_logit_floor=np.array(logit_floor), ref_hard_agreement_floor=np.array(hard_floor))
-    print(f"  reference against itself: logits {logit_floor:.2e}, hard labels {hard_floor:.6f}, median update floor {np.median(noise):.3e}")
+            ref_logit_floor=np.array(logit_floor), ref_hard_agreement_floor=np.array(hard_floor), ref_feat_floor=np.array(feat_floor))
+    print(f"  reference against itself: logits {logit_floor:.2e}, features {feat_floor:.2e}, hard labels {hard_floor:.6f}, median update floor "
+          f"{np.median(noise):.3e}")
 
 
 def aligner_avg(ref, logger):

@@ -470,7 +470,9 @@ def test_full_model_aspp_ssl_step_matches_reference_golden_at(name, B, S, rtype,
     print(f"{rtype} {S}x{S} B={B}+{B}: worst logit error {worst:.2e} (the reference against itself: {float(g['ref_logit_floor']):.2e}), "
           f"hard labels {agree:.6f} (reference against itself: {float(g['ref_hard_agreement_floor']):.6f})")
     assert agree >= 0.9995, agree
-    torch.testing.assert_close(out["feat_t"].cpu().reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=1e-3)
+    # the features: 1e-3, or 3 x how far the reference's own features move (R101 at B = 2: 23 training-mode BatchNorms deeper)
+    ftol = max(1e-3, 3.0 * float(g["ref_feat_floor"])) if "ref_feat_floor" in g else 1e-3
+    torch.testing.assert_close(out["feat_t"].cpu().reshape(-1)[g["feat_idx"]], g["feat_t_sample"], rtol=1e-3, atol=ftol)
     torch.testing.assert_close(out["label_t_soft"][:, :, ::stride, ::stride].cpu(), g["soft_sample"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(out["loss_source"].cpu(), g["loss_source"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(out["loss_target"].cpu(), g["loss_target"], rtol=1e-3, atol=1e-5)

@@ -151,15 +151,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
             }
 #pragma unroll
             for (int rp0 = 0; rp0 < NRP; rp0 += RB) {
+                // Round 4: the packed gate / mask words are kept RAW and shifted where they are used.  `bits[off >> 5] >> (off & 31)`
+                // at the load is a use of the word just requested: the compiler put an s_waitcnt vmcnt(0) behind every row's pair of
+                // loads -- eight serialised memory round trips per half on the residual tails (layer1 0.424 -> 0.381 ms, layer2 0.268
+                // -> 0.244, layer3 0.198 -> 0.193 in the step).  The word loads are unconditional too (a null bit pointer reads word 0
+                // of the filter bank and ignores it): a uniform branch per row split the batch into basic blocks the wait-count pass
+                // drained one by one.
                 float4 o[RB], zz[RB];
                 uint32_t ob[RB], zb[RB];
+                const bool has_ab = p.acc_bits != nullptr, has_zb = p.bn_bits != nullptr;
+                const uint32_t* const abp = has_ab ? p.acc_bits : reinterpret_cast<const uint32_t*>(p.w);
+                const uint32_t* const zbp = has_zb ? p.bn_bits : reinterpret_cast<const uint32_t*>(p.w);
                 if (acc_on) {
                     const float* const asrc = p.acc_src ? p.acc_src : p.y;
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
                         const size_t off = row_off(m0 + hm * 64 + srow + (rp0 + u) * RPP) + n0 + sc4;
                         o[u] = *reinterpret_cast<const float4*>(asrc + off);
-                        if (p.acc_bits) ob[u] = p.acc_bits[off >> 5] >> (off & 31);
+                        ob[u] = abp[has_ab ? off >> 5 : (size_t)0];
                     }
                 }
                 if (bnbwd_on) {                         // dense rows whenever bn_z is given
@@ -167,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                     for (int u = 0; u < RB; ++u) {
                         const size_t off = (size_t)(m0 + hm * 64 + srow + (rp0 + u) * RPP) * p.y_ld + n0 + sc4;
                         zz[u] = *reinterpret_cast<const float4*>(p.bn_z + off);
-                        if (p.bn_bits) zb[u] = p.bn_bits[off >> 5] >> (off & 31);
+                        zb[u] = zbp[has_zb ? off >> 5 : (size_t)0];
                     }
                 }
 #pragma unroll
@@ -176,8 +185,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                     float4 v = *reinterpret_cast<const float4*>(&stg[row * LDW + sc4]);
                     v.x += bv4.x; v.y += bv4.y; v.z += bv4.z; v.w += bv4.w;
                     if (acc_on) {
-                        if (p.acc_bits) {
-                            const uint32_t m = ob[u];
+                        if (has_ab) {
+                            const uint32_t m = ob[u] >> ((unsigned)(row_off(m0 + hm * 64 + row) + n0 + sc4) & 31u);
                             o[u].x = (m & 1u) ? o[u].x : 0.f; o[u].y = (m & 2u) ? o[u].y : 0.f;
                             o[u].z = (m & 4u) ? o[u].z : 0.f; o[u].w = (m & 8u) ? o[u].w : 0.f;
                         }
@@ -193,7 +202,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                         // thread owns 4 columns x (64/RPP) rows of this half
                         const float4 z = zz[u];
                         bool kx, ky, kz, kw;
-                        if (p.bn_bits) { const uint32_t m = zb[u]; kx = m & 1u; ky = m & 2u; kz = m & 4u; kw = m & 8u; }
+                        if (has_zb) {
+                            const uint32_t m = zb[u] >> ((unsigned)((size_t)(m0 + hm * 64 + row) * p.y_ld + n0 + sc4) & 31u);
+                            kx = m & 1u; ky = m & 2u; kz = m & 4u; kw = m & 8u;
+                        }
                         else { kx = z.x * sc.x + sh.x > 0.f; ky = z.y * sc.y + sh.y > 0.f; kz = z.z * sc.z + sh.z > 0.f; kw = z.w * sc.w + sh.w > 0.f; }
                         const float dx_ = kx ? v.x : 0.f, dy_ = ky ? v.y : 0.f, dz_ = kz ? v.z : 0.f, dw_ = kw ? v.w : 0.f;
                         bb.x += dx_; bb.y += dy_; bb.z += dz_; bb.w += dw_;
@@ -1020,19 +1032,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     // its mask bits -- is fetched one 64-row half ahead: half 0 before the main loop, half 1 while half 0 is written out
     uint4 eo[2][NRP], ez[2][NRP];
     unsigned eab[2][NRP], ebb[2][NRP];
+    const bool has_ab = MODE == 1 && p.acc_bits != nullptr, has_zb = MODE == 1 && p.bn_bits != nullptr;
     auto epi_fetch = [&](const int hm) {
 #pragma unroll
         for (int u = 0; u < NRP; ++u) {
             const int m = m0 + hm * 64 + srow + u * RPP;
-            eab[hm][u] = 0xffu; ebb[hm][u] = 0u;
+            eab[hm][u] = 0xffffffffu; ebb[hm][u] = 0u;                   // RAW words: shifted where they are used (see conv_epilogue)
             if (!FULL && m >= p.M) continue;
             if (acc_on) eo[hm][u] = *reinterpret_cast<const uint4*>(ah + row_off(m) + n0 + sc8);
             if (MODE == 1) {
                 const size_t e0 = (size_t)m * p.Cout + n0 + sc8;           // dense rows whenever bits / bn_z are given
-                if (p.acc_bits != nullptr) eab[hm][u] = (p.acc_bits[e0 >> 5] >> (e0 & 31)) & 0xffu;
+                if (has_ab) eab[hm][u] = p.acc_bits[e0 >> 5];
                 if (fuse_bn) {
                     ez[hm][u] = *reinterpret_cast<const uint4*>(zh + e0);
-                    if (p.bn_bits != nullptr) ebb[hm][u] = (p.bn_bits[e0 >> 5] >> (e0 & 31)) & 0xffu;
+                    if (has_zb) ebb[hm][u] = p.bn_bits[e0 >> 5];
                 }
             }
         }
@@ -1077,8 +1090,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         for (int u = 0; u < NRP; ++u) rok[u] = FULL || m0 + hm * 64 + srow + u * RPP < p.M;
         const uint4 (&o)[NRP] = eo[hm];
         const uint4 (&zq)[NRP] = ez[hm];
-        const unsigned (&abyte)[NRP] = eab[hm];
-        const unsigned (&bbyte)[NRP] = ebb[hm];
+        unsigned abyte[NRP], bbyte[NRP];
+#pragma unroll
+        for (int u = 0; u < NRP; ++u) {
+            const unsigned bshift = (unsigned)(((size_t)(m0 + hm * 64 + srow + u * RPP) * p.Cout + n0 + sc8) & 31);
+            abyte[u] = has_ab ? (eab[hm][u] >> bshift) & 0xffu : 0xffu;
+            bbyte[u] = has_zb ? (ebb[hm][u] >> bshift) & 0xffu : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < NRP; ++u) {
             const int row = srow + u * RPP;
