@@ -16,7 +16,19 @@ CASES = [
     (1, 12, 12, 512, 512, 3, 1, 2, 2),
     (3, 2, 2, 2048, 512, 1, 1, 0, 1),        # tiny M
     (4, 32, 32, 256, 128, 3, 1, 1, 1),       # several k-steps per tap, full tiles: statistics path
+    (8, 64, 64, 64, 512, 1, 1, 0, 1),        # 1024 tiles of one k-step: persistent blocks by rule, two tiles each
+    (8, 64, 64, 64, 384, 3, 1, 1, 1),        # 768 tiles on 512 persistent blocks (forced): one or two tiles per block, nine taps
 ]
+
+
+@pytest.fixture(params=["rule", "persistent"])
+def persist(request):
+    """the conv kernel's persistent-block form by its dispatch rule (>= 1024 full tiles), and forced onto every full-tile launch"""
+    from uemda_amd import _lib
+    lib = _lib.load()
+    lib.uemdbg_conv_bf16_persist(1 if request.param == "persistent" else -1)
+    yield request.param
+    lib.uemdbg_conv_bf16_persist(-1)
 
 
 def _bf(t):
@@ -35,7 +47,7 @@ def _close_bf16(got, ref64, what):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_conv_bf16_forward_and_data_gradient(case):
+def test_conv_bf16_forward_and_data_gradient(case, persist):
     from uemda_amd import ops_bf16
     N, H, W, Cin, Cout, k, s, p, d = case
     g = torch.Generator().manual_seed(sum(case))
@@ -109,11 +121,12 @@ TAIL_CASES = [
     (2, 16, 16, 256, 64, 1, 1, "bits", "none"),
     (4, 8, 8, 512, 128, 1, 1, "accumulate", "bits"),   # after a stride-1 downsample's data gradient
     (1, 16, 24, 64, 64, 3, 1, "none", "z"),            # 64-wide column tiles
+    (8, 64, 64, 256, 64, 1, 1, "bits", "bits"),        # layer1's residual tail at 1024 tiles: persistent blocks by rule
 ]
 
 
 @pytest.mark.parametrize("case", TAIL_CASES)
-def test_dgrad_tail_bf16_epilogue(case):
+def test_dgrad_tail_bf16_epilogue(case, persist):
     """uem_conv2d_dgrad_tail_bf16: the data gradient with the residual tail and the BatchNorm-backward reduction in its epilogue
     against fp64 built from the same bf16 values; the partial sums against sums over the dx the kernel stored."""
     from uemda_amd import ops_bf16

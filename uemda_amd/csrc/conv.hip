@@ -836,11 +836,16 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB, PERSIST>::BPC)) void conv_
 // values (what the next layer will read).
 // =========================================================================================================
 #define KBH 64                                                             // bf16 channels per k-step
-template <int BN>
+// PERSIST (round 4): the block walks tiles bid, bid + grid, ... and the first k-step of tile t+1 is requested under the last MFMA phase
+// of tile t -- on the short-k layers (K = 64 ... 256: one to four k-steps) a block used to spend most of its life waiting for its first
+// operand tile.  The epilogue then stages in the stage tile t consumed last (the other one is being filled), so a stage holds at least
+// the 64 x (BN + 4) floats of an epilogue half.
+template <int BN, bool PERSIST = false>
 struct ConvBf16Cfg {
     static constexpr int A_ELEMS = BM * KBH, B_ELEMS = BN * KBH;          // bf16 elements per stage
-    static constexpr int STAGE_BYTES = (A_ELEMS + B_ELEMS) * 2;
+    static constexpr int RAW_STAGE_BYTES = (A_ELEMS + B_ELEMS) * 2;
     static constexpr int EPI_BYTES = 64 * (BN + 4) * 4;
+    static constexpr int STAGE_BYTES = PERSIST && RAW_STAGE_BYTES < EPI_BYTES ? EPI_BYTES : RAW_STAGE_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
 };
 __device__ __forceinline__ unsigned short f2bf(float f) {                  // RNE, NaN stays NaN (hipcc: v_cvt_pk_bf16_f32)
@@ -853,9 +858,9 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // epilogue that tests its options per row keeps the compiler from batching the LDS reads, conversions and stores:
 //   0  full dense tiles, plain store;  1  full dense tiles + BatchNorm tile statistics (forward) / the residual tail and
 //   BatchNorm-backward options (data gradient);  -1  anything (ragged last tile, strided output rows, accumulate in forward)
-template <int BN, int MODE, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes) {
-    using C = ConvBf16Cfg<BN>;
+template <int BN, int MODE, int EPI, bool PERSIST>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes, const int ntiles) {
+    using C = ConvBf16Cfg<BN, PERSIST>;
     constexpr int WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32, BR = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
@@ -864,8 +869,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = p.Cout / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int m0 = 0, n0 = 0;                                                  // compute side: the tile whose accumulators the block holds
     const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + 32*j
     const int lc8 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 8;                 // swizzled source chunk (elements) of this lane
     const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
@@ -874,25 +878,35 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     // pointwise layers (1x1, stride 1, no padding: two thirds of a ResNet's launches): output pixel m reads input pixel m, no
     // per-row divisions and no bounds tests besides m < M -- the index arithmetic below is most of a small-K block's instructions
     const bool pointwise = p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
+    // issue side: the tile whose operand tiles are being requested (one k-step ahead of the MFMAs; under PERSIST it moves on to the
+    // block's next tile while the current one still computes)
+    int vi = blockIdx.x, in0 = 0;
+    bool issue_live = vi < ntiles;
     int gy[4], gx[4], gpix[4];
-    if (pointwise) {
+    auto issue_tile_setup = [&]() {
+        const int tile = xcd_remap(vi, ntiles);
+        const int im0 = (tile / tiles_n) * BM;
+        in0 = (tile % tiles_n) * BN;
+        if (pointwise) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { gy[j] = gx[j] = 0; gpix[j] = (m0 + lrow + 32 * j < p.M) ? m0 + lrow + 32 * j : -1; }
-    } else {
-        const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
-        const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
+            for (int j = 0; j < 4; ++j) { gy[j] = gx[j] = 0; gpix[j] = (im0 + lrow + 32 * j < p.M) ? im0 + lrow + 32 * j : -1; }
+        } else {
+            const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
+            const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + lrow + 32 * j;
-            if (m < p.M) {
-                const int n = m / HoWo, rem = m - n * HoWo;
-                const int oy = rem / Wrow, ox = rem - oy * Wrow;
-                if (MODE == 1) { gy[j] = oy * p.sub + p.py + p.pad; gx[j] = ox * p.sub + p.px + p.pad; }
-                else { gy[j] = oy * p.stride - p.pad; gx[j] = ox * p.stride - p.pad; }
-                gpix[j] = n * p.H * p.W;
-            } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
+            for (int j = 0; j < 4; ++j) {
+                const int m = im0 + lrow + 32 * j;
+                if (m < p.M) {
+                    const int n = m / HoWo, rem = m - n * HoWo;
+                    const int oy = rem / Wrow, ox = rem - oy * Wrow;
+                    if (MODE == 1) { gy[j] = oy * p.sub + p.py + p.pad; gx[j] = ox * p.sub + p.px + p.pad; }
+                    else { gy[j] = oy * p.stride - p.pad; gx[j] = ox * p.stride - p.pad; }
+                    gpix[j] = n * p.H * p.W;
+                } else { gy[j] = gx[j] = 0; gpix[j] = -1; }
+            }
         }
-    }
+    };
+    issue_tile_setup();
     const int cpb = p.Cin / KBH, KT = p.ntaps * cpb, Ktot = p.KH * p.KW * p.Cin;
     int lt = 0, lci0 = 0;
     unsigned tapok = 0, aoff[4], boff[BR];
@@ -905,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 tapok |= (gpix[j] >= 0 ? 1u : 0u) << j;
             }
 #pragma unroll
-            for (int j = 0; j < BR; ++j) boff[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)lc8) * 2u;
+            for (int j = 0; j < BR; ++j) boff[j] = ((unsigned)(in0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)lc8) * 2u;
             return;
         }
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
@@ -930,16 +944,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            boff[j] = ((unsigned)(n0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc8)) * 2u;
+            boff[j] = ((unsigned)(in0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc8)) * 2u;
     };
 
     f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
@@ -968,7 +976,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         auto advance = [&]() {
             if (!live) return;
             lci0 += KBH;
-            if (lci0 >= p.Cin) { lci0 = 0; ++lt; }
+            if (lci0 >= p.Cin) {
+                lci0 = 0;
+                if (++lt == p.ntaps) {                                   // this tile's operands are all requested: on to the block's next tile
+                    lt = 0;
+                    vi += gridDim.x;
+                    issue_live = PERSIST && vi < ntiles;
+                    if (issue_live) issue_tile_setup();
+                }
+            }
         };
         if (!do_phase) {
 #pragma unroll
@@ -1010,7 +1026,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
     };
     constexpr int LDW = BN + 4, TPR = BN / 8, RPP = 256 / TPR, NRP = 64 / RPP;
-    float* const stg = smem;
+    float* stg = smem;                                                   // PERSIST: the stage the tile consumed last
     const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
     // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
     // backward over the rounded dx (same contract as the fp32 kernel's epilogue, bf16 tensors)
@@ -1021,13 +1037,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const unsigned short* const zh = reinterpret_cast<const unsigned short*>(p.bn_z);
     const unsigned short* const ah = p.acc_src != nullptr ? reinterpret_cast<const unsigned short*>(p.acc_src) : yh;
     float pb[8], pg[8], bsc[8], bsh[8], bmu[8], bis[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { pb[e] = pg[e] = 0.f; bsc[e] = bsh[e] = bmu[e] = bis[e] = 0.f; }
-    if (fuse_bn) {
-        const float* v4 = p.bn_vec + n0 + sc8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { bsc[e] = v4[e]; bsh[e] = v4[p.Cout + e]; bmu[e] = v4[2 * p.Cout + e]; bis[e] = v4[3 * p.Cout + e]; }
-    }
     // what the epilogue reads besides the accumulators -- the tensor accumulated into, its gate bits, the BatchNorm input and
     // its mask bits -- is fetched one 64-row half ahead: half 0 before the main loop, half 1 while half 0 is written out
     uint4 eo[2][NRP], ez[2][NRP];
@@ -1050,25 +1059,45 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             }
         }
     };
-    if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
 #define CONV_SYNC()                                                 \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
     __builtin_amdgcn_s_barrier();                                   \
     asm volatile("" ::: "memory")
+    unsigned short* const st0 = lds16;
+    if (KT > 0) step(st0, st0 + C::STAGE_BYTES / 2, issue_live, false);  // first operand tile of the block's first tile
+    int par = 0;                                                         // stage the next k-step consumes
+    for (int vc = blockIdx.x; vc < ntiles; vc += gridDim.x) {
+    {
+        const int tile = xcd_remap(vc, ntiles);
+        m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pb[e] = pg[e] = 0.f; bsc[e] = bsh[e] = bmu[e] = bis[e] = 0.f; }
+    if (fuse_bn) {
+        const float* v4 = p.bn_vec + n0 + sc8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bsc[e] = v4[e]; bsh[e] = v4[p.Cout + e]; bmu[e] = v4[2 * p.Cout + e]; bis[e] = v4[3 * p.Cout + e]; }
+    }
+    if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
     if (KT > 0) {
-        unsigned short* const st0 = lds16;
-        step(st0, st0 + C::STAGE_BYTES / 2, true, false);
-        int par = 0;
         for (int kt = 0; kt < KT; ++kt) {
             CONV_SYNC();
-            step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), kt + 1 < KT, true);
+            step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), issue_live, true);
             par ^= 1;
         }
-        CONV_SYNC();                                                     // the last step's out-of-range pieces have landed too
+        // every wave past its last operand read, every DMA piece landed: the last step's out-of-range pieces (not persistent: the
+        // staging area spans both stages) or the next tile's first operand tile (persistent: in the other stage)
+        CONV_SYNC();
     } else {
         __syncthreads();
     }
-#undef CONV_SYNC
+    if (PERSIST) stg = reinterpret_cast<float*>(st0 + (par ^ 1) * (C::STAGE_BYTES / 2));
 
     // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
 #pragma unroll
@@ -1155,6 +1184,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
             tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
         }
     }
+    if (!PERSIST) break;
+    }                                                                    // tiles of a persistent block
+#undef CONV_SYNC
 }
 
 static int conv_check(const uem_conv_shape* s) {
@@ -1246,7 +1278,9 @@ static int conv_dma_try(const ConvP& p, bool affine, hipStream_t st) {
     // bn3's reduction streaming through the epilogue) take 64-wide tiles: three resident blocks per CU instead of two cover each
     // other's epilogues (layer1 0.51 -> 0.41 ms, layer2 0.33 -> 0.27, layer3 0.22 -> 0.19, layer4 0.65 -> 0.63:
     // scripts/bench_dgrad_tail.py), and with K this small the second read of dy costs little
-    const bool wide_tail = MODE == 1 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout;
+    static const int wt_env = getenv("UEM_WIDE_TAIL") ? atoi(getenv("UEM_WIDE_TAIL")) : 1;     // 0 off, 1 rule, 2 rule up to 256 channels in
+    const bool wide_tail = wt_env != 0 && MODE == 1 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout &&
+                           (wt_env != 2 || p.Cin <= 256);
     bool bn128 = p.Cout % 128 == 0 && g_conv_dma_bn != 64 && !(wide_tail && g_conv_dma_bn == 0);
     if constexpr (MODE != 2) {
         static const int penv = getenv("UEM_CONV_PERSIST") ? atoi(getenv("UEM_CONV_PERSIST")) : -1;
@@ -2077,20 +2111,39 @@ extern "C" int uem_aspp_unpack_grad(const float* dwall, const float* db, void* c
 // =========================================================================================================
 // bf16-storage entry points (BASELINE config 5)
 // =========================================================================================================
-template <int BN_, int MODE, int EPI>
+static int g_bf16_persist = -1;  // tuning override: 1 / 0 = persistent blocks on / off, -1 = rule
+extern "C" void uemdbg_conv_bf16_persist(int v) { g_bf16_persist = v; }
+template <int BN_, int MODE, int EPI, bool PERSIST>
 static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
-    using C = ConvBf16Cfg<BN_>;
-    const int grid = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
-    auto k = conv_bf16_kernel<BN_, MODE, EPI>;
-    if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb);
+    using C = ConvBf16Cfg<BN_, PERSIST>;
+    const int ntiles = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
+    // persistent: one block per resident-block slot (LDS: two 128-wide or three 64-wide blocks per CU; a multiple of 8, so a block's
+    // tiles stay on its XCD's share)
+    const int slots = 256 * (160 * 1024 / C::LDS_BYTES > 3 ? 3 : 160 * 1024 / C::LDS_BYTES);
+    const int grid = PERSIST && ntiles > slots ? slots : ntiles;
+    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST>;
+    if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
 }
 template <int BN_, int MODE>
 static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
     const bool full = p.M % BM == 0 && (MODE == 0 || p.sub == 1) && UEM_DBG(p.dbg) == 0;
     const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
-    if (!full || (MODE == 0 && p.accumulate)) conv_bf16_launch<BN_, MODE, -1>(p, xb, wb, st);
-    else if (extras) conv_bf16_launch<BN_, MODE, 1>(p, xb, wb, st);
-    else conv_bf16_launch<BN_, MODE, 0>(p, xb, wb, st);
+    static const int penv = getenv("UEM_CONV_BF16_PERSIST") ? atoi(getenv("UEM_CONV_BF16_PERSIST")) : -1;
+    const int pset = g_bf16_persist >= 0 ? g_bf16_persist : penv;
+    const int ntiles = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
+    // persistent blocks: full tiles, at least two tiles per block
+    // Rule (profiles/r04_q_conv_bf16_persist.txt): the short k-loops (at most 12 k-steps: the pointwise layers up to K = 768 and the
+    // 64-channel 3x3) with at least two rounds of tiles, except the fused data-gradient epilogues -- their prefetched operands (the
+    // tensor accumulated into, z, the packed bits) are older than the operand DMA of the next tile, retire before it, and the block
+    // loses what persistence hides (residual tails +15 ... 50 %).  pset: 1 = every full-tile launch, 2 = all but those epilogues.
+    constexpr int slots = 256 * (160 * 1024 / ConvBf16Cfg<BN_, true>::LDS_BYTES > 3 ? 3 : 160 * 1024 / ConvBf16Cfg<BN_, true>::LDS_BYTES);
+    const int KT = p.ntaps * (p.Cin / KBH);
+    const bool persist = full && !(MODE == 0 && p.accumulate) && p.ntaps > 0 &&
+                         (pset == 1 || (pset == 2 && !(MODE == 1 && extras)) ||
+                          (pset < 0 && !(MODE == 1 && extras) && KT <= 12 && ntiles >= 2 * slots));
+    if (!full || (MODE == 0 && p.accumulate)) conv_bf16_launch<BN_, MODE, -1, false>(p, xb, wb, st);
+    else if (extras) { if (persist) conv_bf16_launch<BN_, MODE, 1, true>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 1, false>(p, xb, wb, st); }
+    else { if (persist) conv_bf16_launch<BN_, MODE, 0, true>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 0, false>(p, xb, wb, st); }
 }
 struct BnBwdFuseH { const uint16_t* z; const float* vec; float* tiles; const uint16_t* acc_src; const uint32_t* acc_bits; const uint32_t* bn_bits; };
 static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags, float* tile_stats,
@@ -2173,7 +2226,11 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
             p.M = s->N * p.Hs * p.Ws;
             // the residual tails on 64-wide tiles, as in the fp32 kernel (conv_dma_try): dgrad family 10.71 -> 10.38 ms per step; the
             // forward's wide, small-K layers lose on them (8.48 -> 8.87 ms)
-            const bool wide_tail = (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout;
+            // (round 4: with the packed-bit words no longer serialising the epilogue's loads the 64-wide tiles stopped paying --
+            // layer3 / layer4 tails 10-13 % faster on 128-wide tiles, layer1 / layer2 equal: off unless UEM_BF16_WIDE_TAIL=1)
+            static const int wt_env = getenv("UEM_BF16_WIDE_TAIL") ? atoi(getenv("UEM_BF16_WIDE_TAIL")) : 0;
+            const bool wide_tail = wt_env != 0 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout &&
+                                   (wt_env != 2 || p.Cin <= 256);
             if (p.Cout % 128 == 0 && !wide_tail) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
             else conv_bf16_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);
         }
