@@ -646,7 +646,14 @@ extern "C" int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
     p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo; p.Cout = s->Cout;
     p.KH = s->KH; p.KW = s->KW; p.pad = s->pad; p.x_ld = s->x_ld; p.dy_ld = s->y_ld;
     p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db; p.nbatch = 1;
-    const bool ok = s->Cout % 128 == 0 ? wgb_dispatch<128, 64>(p, s, (hipStream_t)stream) : wgb_dispatch<64, 64>(p, s, (hipStream_t)stream);
+    // 128 x 128 tiles on the largest pointwise filter banks (Cin * Cout >= 2^20: layer4's 2048 <-> 512 and its 1024 -> 2048 downsample,
+    // -4 ... -15 % in the step; the smaller banks lose 15-30 % on them: fewer tiles, longer split-K slices).  UEM_WGRAD_BF16_TN128 = 0
+    // off, 1 every pointwise layer, else the threshold on Cin * Cout.
+    static const int tn128 = getenv("UEM_WGRAD_BF16_TN128") ? atoi(getenv("UEM_WGRAD_BF16_TN128")) : (1 << 20);
+    const bool pw = s->KH == 1 && s->KW == 1 && s->pad == 0 && s->stride == 1;
+    const bool ok = (tn128 && pw && s->Cout % 128 == 0 && s->Cin % 128 == 0 && (tn128 == 1 || s->Cin * s->Cout >= tn128))
+                        ? wgb_dispatch<128, 128>(p, s, (hipStream_t)stream)
+                        : (s->Cout % 128 == 0 ? wgb_dispatch<128, 64>(p, s, (hipStream_t)stream) : wgb_dispatch<64, 64>(p, s, (hipStream_t)stream));
     if (!ok) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_wgrad_bf16: 1x1 (stride 1, or 2 with rows of 32 pixels) and 3x3 on rows of 32 pixels only");
     return uem_check_launch("conv2d_wgrad_bf16");
 }
