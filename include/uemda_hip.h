@@ -417,6 +417,7 @@ int uem_wino_filter_grad(const float* dU, float* dw_ohwi, int Cout, int Cin, int
 #define UEM_PREP_WINO4 3       /*                        -> dst U[36][cout][cin]      (m = 4)                              */
 #define UEM_PREP_WINO4_T 4     /*                        -> dst U'[36][cin][cout]                                          */
 #define UEM_PREP_STEM_PACK 5   /* src w[64][7][7][3] -> dst w8[64][7][8][4] (cout 64, cin 3, taps 49)                       */
+#define UEM_PREP_TRANSPOSE_BF16 6 /* as UEM_PREP_TRANSPOSE, dst in bf16 (round to nearest even): uem_weight_transpose_bf16         */
 typedef struct uem_prep_job {
     const void* src;
     void* dst;

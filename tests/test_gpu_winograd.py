@@ -164,7 +164,7 @@ def test_weight_prep_refreshes_every_derived_bank_in_one_launch():
     FusedSGD's epoch and the death of a parameter."""
     import ctypes
     import gc
-    from uemda_amd import ops
+    from uemda_amd import ops, ops_bf16
     g = torch.Generator().manual_seed(5)
 
     def param(cout, cin, k):
@@ -185,6 +185,11 @@ def test_weight_prep_refreshes_every_derived_bank_in_one_launch():
         w8 = torch.empty(64, 7, 8, 4, device="cuda")
         ops.call("uem_stem_pack_weight", ops.ptr(ops.weight_ohwi(ps)), ops.ptr(w8), ops.stream())
         out["stem"] = w8
+        for name, p in (("p1", p1), ("p3", p3)):                       # the bf16-storage model's data-gradient banks
+            cout, cin, kh, kw = p.shape
+            wt = torch.empty((cin, kh, kw, cout), device="cuda", dtype=torch.bfloat16)
+            ops.call("uem_weight_transpose_bf16", ops.ptr(ops.weight_ohwi(p)), ops.ptr(wt), cout, kh, kw, cin, ops.stream())
+            out[name, "t16"] = wt
         return out
 
     def batched():
@@ -194,6 +199,7 @@ def test_weight_prep_refreshes_every_derived_bank_in_one_launch():
                 for tr in (False, True):
                     out[name, m, tr] = ops.wino_filter_cached(p, tr, m)
         out["stem"] = ops.stem_weight_packed(ps)
+        out["p1", "t16"], out["p3", "t16"] = ops_bf16.weight_t(p1), ops_bf16.weight_t(p3)
         return out
 
     def same(a, b):

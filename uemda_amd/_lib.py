@@ -145,7 +145,7 @@ UEM_PROTO_SPLIT = 256
 UEM_NORM_BLOCKS = 1024
 CONV_IN_AFFINE, CONV_IN_RELU, CONV_ACCUMULATE, CONV_TRANSPOSED = 1, 2, 4, 8
 CONV_PREC_BF16 = 32
-PREP_TRANSPOSE, PREP_WINO2, PREP_WINO2_T, PREP_WINO4, PREP_WINO4_T, PREP_STEM_PACK = range(6)
+PREP_TRANSPOSE, PREP_WINO2, PREP_WINO2_T, PREP_WINO4, PREP_WINO4_T, PREP_STEM_PACK, PREP_TRANSPOSE_BF16 = range(7)
 
 
 class UemError(RuntimeError):

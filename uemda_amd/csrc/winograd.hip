@@ -771,6 +771,21 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const uem_prep_job* __
                 out[idx] = w[((size_t)o * j.taps + t) * j.cin + i];
             }
         }
+    } else if (j.kind == UEM_PREP_TRANSPOSE_BF16) {
+        // the same re-layout rounded to bf16 (RNE): the data-gradient banks of a bf16-storage model (52 launches of 6 us per step before)
+        unsigned short* const outh = reinterpret_cast<unsigned short*>(j.dst);
+        const int64_t total = (int64_t)j.cout * j.taps * j.cin;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t idx = (int64_t)lb * 1024 + k * 256 + threadIdx.x;
+            if (idx < total) {
+                const int o = (int)(idx % j.cout);
+                const int64_t r = idx / j.cout;
+                const int t = (int)(r % j.taps);
+                const int i = (int)(r / j.taps);
+                outh[idx] = __builtin_bit_cast(unsigned short, (__bf16)w[((size_t)o * j.taps + t) * j.cin + i]);
+            }
+        }
     } else if (j.kind == UEM_PREP_STEM_PACK) {
         // w[64][7][7][3] (OHWI) -> w8[64][7][8][4], zero padded
         const int idx = lb * 256 + threadIdx.x;
@@ -791,7 +806,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const uem_prep_job* __
 extern "C" int uem_weight_prep_blocks(int kind, int cout, int cin, int taps) {
     if (cout <= 0 || cin <= 0 || taps <= 0) return -1;
     switch (kind) {
-    case UEM_PREP_TRANSPOSE: return (int)uem_cdiv((int64_t)cout * cin * taps, 1024);
+    case UEM_PREP_TRANSPOSE: case UEM_PREP_TRANSPOSE_BF16: return (int)uem_cdiv((int64_t)cout * cin * taps, 1024);
     case UEM_PREP_STEM_PACK: return (cout == 64 && cin == 3 && taps == 49) ? (64 * 7 * 8 * 4 + 255) / 256 : -1;
     case UEM_PREP_WINO2: case UEM_PREP_WINO2_T: case UEM_PREP_WINO4: case UEM_PREP_WINO4_T:
         return (taps == 9 && cout % 16 == 0 && cin % 64 == 0) ? (cin / 64) * (cout / 16) : -1;

@@ -397,7 +397,7 @@ class _WeightPrep:
         jt, st, n, total = table
         call("uem_weight_prep", ptr(jt), ptr(st), n, total, stream())
 
-    def get(self, param, kind, shape):
+    def get(self, param, kind, shape, dtype=torch.float32):
         """the derived bank of `param` (a conv weight, logical OIHW in channels_last storage) for `kind`, of shape `shape`"""
         import weakref
         key = (param.data_ptr(), kind)
@@ -410,7 +410,7 @@ class _WeightPrep:
             blocks = _lib.load().uem_weight_prep_blocks(kind, cout, cin, kh * kw)
             if blocks <= 0:
                 raise UemError(f"weight_prep: kind {kind} does not take a ({cout},{kh},{kw},{cin}) filter bank")
-            job = dict(ref=weakref.ref(param), src=w.data_ptr(), dst=torch.empty(shape, device=w.device, dtype=torch.float32), kind=kind,
+            job = dict(ref=weakref.ref(param), src=w.data_ptr(), dst=torch.empty(shape, device=w.device, dtype=dtype), kind=kind,
                        cout=cout, cin=cin, taps=kh * kw, blocks=blocks, stamp=None)
             self.jobs[key] = job
             self.table = None
@@ -455,12 +455,12 @@ class _WeightPrepPerDevice:
     def __init__(self):
         self.by_device = {}
 
-    def get(self, param, kind, shape):
+    def get(self, param, kind, shape, dtype=torch.float32):
         need_gpu(param)
         prep = self.by_device.get(param.device.index)
         if prep is None:
             prep = self.by_device[param.device.index] = _WeightPrep()
-        return prep.get(param, kind, shape)
+        return prep.get(param, kind, shape, dtype)
 
     def settle(self):
         """every device's job table as it stands (built now if stale): [(jobs tensor, starts tensor, njobs, blocks)]"""

@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import CONV_ACCUMULATE, CONV_TRANSPOSED, ConvShape, UemError, call
 from .ops import conv_out_size, need_gpu, ptr, stream
 
@@ -173,18 +173,10 @@ def weight(param):
 
 
 def weight_t(param):
-    """bf16 (Cin,KH,KW,Cout) copy for the data gradient: transposed and rounded from the fp32 master in one kernel, once
-    per optimizer step (the same bf16 values as weight())."""
-    key = (ops.WEIGHT_EPOCH, param._version, param.data_ptr())
-    hit = getattr(param, "_uem_wbt", None)
-    if hit is None or hit[0] != key:
-        w = ops.weight_ohwi(param)
-        cout, kh, kw, cin = w.shape
-        wt = torch.empty((cin, kh, kw, cout), device=w.device, dtype=torch.bfloat16)
-        call("uem_weight_transpose_bf16", ptr(w), ptr(wt), cout, kh, kw, cin, stream())
-        hit = (key, wt)
-        param._uem_wbt = hit
-    return hit[1]
+    """bf16 (Cin,KH,KW,Cout) copy for the data gradient: transposed and rounded from the fp32 master (the same bf16 values as weight()),
+    refreshed with every other derived filter bank of the model in the ONE uem_weight_prep launch after an optimizer step."""
+    cout, cin, kh, kw = param.shape
+    return ops.PREP.get(param, _lib.PREP_TRANSPOSE_BF16, (cin, kh, kw, cout), dtype=torch.bfloat16)
 
 
 # ---- BatchNorm / residual passes on bf16 tensors ------------------------------------------------------------------
