@@ -365,6 +365,105 @@ __global__ __launch_bounds__(256) void affine_act_bf16x8_kernel(const bf16_t* __
         }
     }
 }
+// R rows per lane for the two passes above on large tensors (bn_rows below): per-channel vectors loaded once per lane, the rows' loads
+// in flight together.  Same arithmetic; the bit words come out the same way (a row's vectors are lane-aligned: the row stride is a
+// multiple of 256).
+template <typename T, int R>
+__global__ __launch_bounds__(256) void affine_act_rows_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ res,
+                                                              const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                              T* __restrict__ y, int64_t nvec, int C, int relu,
+                                                              uint32_t* __restrict__ bits) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)((i0 * 4) % C);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 rs = make_float4(1.f, 1.f, 1.f, 1.f), rt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res && rscale) { rs = *reinterpret_cast<const float4*>(rscale + c); rt = *reinterpret_cast<const float4*>(rshift + c); }
+    float4 v[R], q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i < nvec) {
+            v[r] = ld4<T>(x + i * 4);
+            if (res) q[r] = ld4<T>(res + i * 4);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i >= nvec) continue;                                        // nvec % 8 == 0 with bits: whole words inside or outside
+        float4 a = v[r];
+        a.x = a.x * sc.x + sh.x; a.y = a.y * sc.y + sh.y; a.z = a.z * sc.z + sh.z; a.w = a.w * sc.w + sh.w;
+        if (res) {
+            float4 b = q[r];
+            if (rscale) { b.x = b.x * rs.x + rt.x; b.y = b.y * rs.y + rt.y; b.z = b.z * rs.z + rt.z; b.w = b.w * rs.w + rt.w; }
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        st4<T>(y + i * 4, a);
+        if (bits) {
+            uint32_t m = (a.x > 0.f ? 1u : 0u) | (a.y > 0.f ? 2u : 0u) | (a.z > 0.f ? 4u : 0u) | (a.w > 0.f ? 8u : 0u);
+            m <<= 4 * (threadIdx.x & 7);
+            m |= __shfl_xor(m, 1);
+            m |= __shfl_xor(m, 2);
+            m |= __shfl_xor(m, 4);
+            if ((threadIdx.x & 7) == 0) bits[i >> 3] = m;
+        }
+    }
+}
+template <int R>
+__global__ __launch_bounds__(256) void affine_act_bf16x8_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, const bf16_t* __restrict__ res,
+                                                                     const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                                     bf16_t* __restrict__ y, int64_t nvec, int C, int relu,
+                                                                     uint32_t* __restrict__ bits) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)((i0 * 8) % C);
+    float sc[8], sh[8], rs[8], rt[8];
+    ldv8(scale + c, sc);
+    ldv8(shift + c, sh);
+    if (res && rscale) { ldv8(rscale + c, rs); ldv8(rshift + c, rt); }
+    float v[R][8], q[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i < nvec) {
+            ld8(x + i * 8, v[r]);
+            if (res) ld8(res + i * 8, q[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i >= nvec) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[r][e] = v[r][e] * sc[e] + sh[e];
+        if (res) {
+            if (rscale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[r][e] = q[r][e] * rs[e] + rt[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[r][e] += q[r][e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[r][e] = fmaxf(v[r][e], 0.f);
+        }
+        st8(y + i * 8, v[r]);
+        if (bits) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m |= (v[r][e] > 0.f ? 1u : 0u) << e;
+            m <<= 8 * (threadIdx.x & 3);
+            m |= __shfl_xor(m, 1);
+            m |= __shfl_xor(m, 2);
+            if ((threadIdx.x & 3) == 0) bits[i >> 2] = m;
+        }
+    }
+}
+static inline int bn_rows(int64_t nvec, int C);
 extern "C" int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
                               const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
                               uint32_t* relu_bits, void* stream) {
@@ -372,7 +471,13 @@ extern "C" int uem_affine_act(const float* x, const float* scale, const float* s
     UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act: relu_bits needs C %% 32 == 0 (C=%d)", C);
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act: bad residual affine");
     const int64_t nvec = M * C / 4;
-    affine_act_kernel<float><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    const int rows = (!relu_bits || nvec % 8 == 0) ? bn_rows(nvec, C) : 1;
+    if (rows == 4)
+        affine_act_rows_kernel<float, 4><<<(unsigned)uem_cdiv(nvec, 1024), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    else if (rows == 2)
+        affine_act_rows_kernel<float, 2><<<(unsigned)uem_cdiv(nvec, 512), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
+    else
+        affine_act_kernel<float><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     return uem_check_launch("affine_act");
 }
 extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const float* shift, const uint16_t* res,
@@ -383,8 +488,14 @@ extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const 
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act_bf16: bad residual affine");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {       // with bits: C % 32 == 0, whole lane quads
         const int64_t nvec8 = M * C / 8;
-        affine_act_bf16x8_kernel<<<uem_flat_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y,
-                                                                                               nvec8, C, relu, relu_bits);
+        const int rows = (!relu_bits || nvec8 % 4 == 0) ? bn_rows(nvec8, C) : 1;
+        if (rows == 4)
+            affine_act_bf16x8_rows_kernel<4><<<(unsigned)uem_cdiv(nvec8, 1024), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec8, C, relu, relu_bits);
+        else if (rows == 2)
+            affine_act_bf16x8_rows_kernel<2><<<(unsigned)uem_cdiv(nvec8, 512), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec8, C, relu, relu_bits);
+        else
+            affine_act_bf16x8_kernel<<<uem_flat_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y,
+                                                                                                   nvec8, C, relu, relu_bits);
         return uem_check_launch("affine_act_bf16");
     }
     const int64_t nvec = M * C / 4;
@@ -575,6 +686,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         st4<T>(dx + off, o);
     }
 }
+// R rows per lane (see bn_bwd_apply_bf16x8_rows_kernel below): the lane's per-channel vectors loaded once, the loads of all R rows in
+// flight together; element arithmetic identical to the kernel above
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                const float* __restrict__ res, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ smean,
+                                                                const float* __restrict__ sinv, const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, int64_t nvec, int C, float invM,
+                                                                int relu, T* __restrict__ dx, T* __restrict__ dres) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)((i0 * 4) % C);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = relu == 1 ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 mu = *reinterpret_cast<const float4*>(smean + c);
+    const float4 is = *reinterpret_cast<const float4*>(sinv + c);
+    float4 dg = *reinterpret_cast<const float4*>(dgamma + c);
+    float4 db = *reinterpret_cast<const float4*>(dbeta + c);
+    dg.x *= invM; dg.y *= invM; dg.z *= invM; dg.w *= invM;
+    db.x *= invM; db.y *= invM; db.z *= invM; db.w *= invM;
+    float4 xv[R], d[R], pre[R];
+    uint32_t m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i < nvec) {
+            const size_t off = (size_t)i * 4;
+            xv[r] = ld4<T>(x + off);
+            d[r] = ld4<T>(dy + off);
+            if (relu == 2) m[r] = reinterpret_cast<const uint32_t*>(res)[off >> 5];
+            else if (relu && res) pre[r] = *reinterpret_cast<const float4*>(res + off);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i >= nvec) continue;
+        const size_t off = (size_t)i * 4;
+        float4 g = d[r];
+        const float4 v = xv[r];
+        if (relu == 2) {
+            const uint32_t mm = m[r] >> (off & 31);
+            g.x = (mm & 1u) ? g.x : 0.f; g.y = (mm & 2u) ? g.y : 0.f; g.z = (mm & 4u) ? g.z : 0.f; g.w = (mm & 8u) ? g.w : 0.f;
+        } else if (relu) {
+            float4 q;
+            if (res) q = pre[r];
+            else { q.x = v.x * sc.x + sh.x; q.y = v.y * sc.y + sh.y; q.z = v.z * sc.z + sh.z; q.w = v.w * sc.w + sh.w; }
+            g.x = q.x > 0.f ? g.x : 0.f; g.y = q.y > 0.f ? g.y : 0.f; g.z = q.z > 0.f ? g.z : 0.f; g.w = q.w > 0.f ? g.w : 0.f;
+        }
+        if (dres) st4<T>(dres + off, g);
+        float4 o;
+        o.x = sc.x * (g.x - db.x - ((v.x - mu.x) * is.x) * dg.x);
+        o.y = sc.y * (g.y - db.y - ((v.y - mu.y) * is.y) * dg.y);
+        o.z = sc.z * (g.z - db.z - ((v.z - mu.z) * is.z) * dg.z);
+        o.w = sc.w * (g.w - db.w - ((v.w - mu.w) * is.w) * dg.w);
+        st4<T>(dx + off, o);
+    }
+}
+// rows per lane of the elementwise BatchNorm passes on large tensors: UEM_BN_ROWS (1 = the grid-stride kernels)
+static inline int bn_rows(int64_t nvec, int C) {
+    static const int rows = getenv("UEM_BN_ROWS") ? atoi(getenv("UEM_BN_ROWS")) : 2;
+    if (rows < 2 || nvec < ((int64_t)1 << 20) || C < 64 || C > 2048 || (C & (C - 1)) != 0) return 1;
+    return rows >= 4 ? 4 : 2;
+}
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                   const uint32_t* __restrict__ rbits, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ smean,
@@ -609,6 +783,59 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const bf16_t* 
         st8(dx + off, o);
     }
 }
+// The same pass with R rows per lane: with 8 channels per 16 bytes of tensor the per-channel vectors are up to 12 load instructions beside
+// 2 loads and a store of data; a lane's channels are the same in every row it visits (the row stride, gridDim * 256 vectors, is a multiple
+// of C / 8 for the power-of-two channel counts of the encoder), so they are loaded once.  Element arithmetic identical to the kernel above.
+template <int R>
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                       const uint32_t* __restrict__ rbits, const float* __restrict__ scale,
+                                                                       const float* __restrict__ shift, const float* __restrict__ smean,
+                                                                       const float* __restrict__ sinv, const float* __restrict__ dgamma,
+                                                                       const float* __restrict__ dbeta, int64_t nvec, int C, float invM,
+                                                                       int relu, bf16_t* dx, bf16_t* __restrict__ dres) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)((i0 * 8) % C);
+    float sc[8], t[8], mu[8], is[8], dgm[8], dbm[8];
+    ldv8(scale + c, sc);
+    if (relu == 1) ldv8(shift + c, t);
+    ldv8(smean + c, mu);
+    ldv8(sinv + c, is);
+    ldv8(dgamma + c, dgm);
+    ldv8(dbeta + c, dbm);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgm[e] = dgm[e] * invM; dbm[e] = dbm[e] * invM; }
+    float xv[R][8], d[R][8];
+    uint32_t m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i < nvec) {
+            const size_t off = (size_t)i * 8;
+            ld8(x + off, xv[r]);
+            ld8(dy + off, d[r]);
+            m[r] = relu == 2 ? rbits[off >> 5] : 0u;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i >= nvec) continue;
+        const size_t off = (size_t)i * 8;
+        if (relu == 2) {
+            const uint32_t mm = m[r] >> (off & 31);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[r][e] = ((mm >> e) & 1u) ? d[r][e] : 0.f;
+        } else if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[r][e] = (xv[r][e] * sc[e] + t[e] > 0.f) ? d[r][e] : 0.f;
+        }
+        if (dres) st8(dres + off, d[r]);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sc[e] * (d[r][e] - dbm[e] - ((xv[r][e] - mu[e]) * is[e]) * dgm[e]);
+        st8(dx + off, o);
+    }
+}
 extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                                 const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta,
                                 int M, int C, int relu, float* dx, float* dres, void* stream) {
@@ -616,8 +843,16 @@ extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* yma
     UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad shape");
     UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "bn_bwd_apply: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = (int64_t)M * C / 4;
-    bn_bwd_apply_kernel<float><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
-        x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
+    const int rows = bn_rows(nvec, C);
+    if (rows == 4)
+        bn_bwd_apply_rows_kernel<float, 4><<<(unsigned)uem_cdiv(nvec, 1024), 256, 0, (hipStream_t)stream>>>(
+            x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
+    else if (rows == 2)
+        bn_bwd_apply_rows_kernel<float, 2><<<(unsigned)uem_cdiv(nvec, 512), 256, 0, (hipStream_t)stream>>>(
+            x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
+    else
+        bn_bwd_apply_kernel<float><<<uem_flat_grid(nvec, 256), 256, 0, (hipStream_t)stream>>>(
+            x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
     return uem_check_launch("bn_bwd_apply");
 }
 extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, const uint32_t* relu_bits, const float* scale,
@@ -628,6 +863,16 @@ extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, cons
     UEM_REQUIRE(relu == 0 || (relu == 1 && !relu_bits) || (relu == UEM_RELU_BITS && relu_bits && C % 32 == 0), "bn_bwd_apply_bf16: bad relu mode");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0) {
         const int64_t nvec8 = (int64_t)M * C / 8;
+        const int rows = bn_rows(nvec8, C);
+        if (rows > 1) {
+            if (rows >= 4)
+                bn_bwd_apply_bf16x8_rows_kernel<4><<<(unsigned)uem_cdiv(nvec8, 1024), 256, 0, (hipStream_t)stream>>>(
+                    x, dy, relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec8, C, 1.0f / (float)M, relu, dx, dres);
+            else
+                bn_bwd_apply_bf16x8_rows_kernel<2><<<(unsigned)uem_cdiv(nvec8, 512), 256, 0, (hipStream_t)stream>>>(
+                    x, dy, relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec8, C, 1.0f / (float)M, relu, dx, dres);
+            return uem_check_launch("bn_bwd_apply_bf16");
+        }
         bn_bwd_apply_bf16x8_kernel<<<uem_flat_grid(nvec8, 256), 256, 0, (hipStream_t)stream>>>(
             x, dy, relu_bits, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec8, C, 1.0f / (float)M, relu, dx, dres);
         return uem_check_launch("bn_bwd_apply_bf16");

@@ -170,7 +170,12 @@ class GraphedStep:
         self._prep_tables = ops.PREP.settle()
         self.graph = torch.cuda.CUDAGraph()
         steps_before = optimizer._steps
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, its watchdog thread polls its work events (hipEventQuery) whenever it likes: under the default
+        # "global" capture mode such a call from ANOTHER thread while this one captures is an error, raised in that thread -- the
+        # process aborts, now and then (seen once in four runs of the captured data-parallel step).  "thread_local" checks this
+        # thread's calls only; what is recorded is the same (capture is per stream).
+        mode = "thread_local" if (dp is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.out = run()
         optimizer._steps = steps_before                  # the capture pass ran the host side of step() without taking a step
 
