@@ -200,28 +200,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(256) void bn_stats_tiles_finalize_kernel(const float* __restrict__ ts, int tiles, int rows, int M, int C,
-                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                      float eps, float momentum, float* __restrict__ rmean,
-                                                                      float* __restrict__ rvar, float* __restrict__ smean,
-                                                                      float* __restrict__ sinv, float* __restrict__ scale,
-                                                                      float* __restrict__ shift) {
-    __shared__ float red[4];
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const float* const t1 = ts + (size_t)c * tiles;
-    const float* const t2 = ts + ((size_t)C + c) * tiles;
-    const float nb = (float)rows, inb = 1.0f / nb;
-    float a = 0.f;
-    for (int j = lane; j < tiles; j += 256) a += t1[j];
-    const float mean = block_sum_256(a, red) / (float)M;
-    float q = 0.f;
-    for (int j = lane; j < tiles; j += 256) {
-        const float s1 = t1[j], s2 = t2[j];
-        const float mb = s1 * inb, d = mb - mean;
-        q += fmaxf(s2 - s1 * mb, 0.f) + nb * d * d;
-    }
-    const float m2 = block_sum_256(q, red);
-    if (lane != 0) return;
+__device__ __forceinline__ void bn_stats_finish(const int c, const float mean, const float m2, const int M, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, const float eps, const float momentum,
+                                                float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
+                                                float* __restrict__ sinv, float* __restrict__ scale, float* __restrict__ shift) {
     const float var = m2 / (float)M;
     const float invstd = 1.0f / sqrtf(var + eps);
     if (smean) smean[c] = mean;
@@ -235,6 +217,56 @@ __global__ __launch_bounds__(256) void bn_stats_tiles_finalize_kernel(const floa
         rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
     }
+}
+__global__ __launch_bounds__(256) void bn_stats_tiles_finalize_kernel(const float* __restrict__ ts, int tiles, int rows, int M, int C,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float eps, float momentum, float* __restrict__ rmean,
+                                                                      float* __restrict__ rvar, float* __restrict__ smean,
+                                                                      float* __restrict__ sinv, float* __restrict__ scale,
+                                                                      float* __restrict__ shift) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float* const t1 = ts + (size_t)c * tiles;
+    const float* const t2 = ts + ((size_t)C + c) * tiles;
+    const float nb = (float)rows, inb = 1.0f / nb;
+    float a = 0.f, q = 0.f;
+    if (tiles <= 16 * 256) {
+        // both partial rows in registers after ONE round trip to memory (these launches sit between two convolutions with C blocks on
+        // the whole chip: their time is latency); same sums in the same order as the two-pass form below
+        float r1[16], r2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = lane + 256 * k;
+            r1[k] = j < tiles ? t1[j] : 0.f;
+            r2[k] = j < tiles ? t2[j] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (lane + 256 * k < tiles) a += r1[k];
+        const float mean = block_sum_256(a, red) / (float)M;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (lane + 256 * k < tiles) {
+                const float s1 = r1[k], s2 = r2[k];
+                const float mb = s1 * inb, d = mb - mean;
+                q += fmaxf(s2 - s1 * mb, 0.f) + nb * d * d;
+            }
+        }
+        const float m2 = block_sum_256(q, red);
+        if (lane != 0) return;
+        bn_stats_finish(c, mean, m2, M, gamma, beta, eps, momentum, rmean, rvar, smean, sinv, scale, shift);
+        return;
+    }
+    for (int j = lane; j < tiles; j += 256) a += t1[j];
+    const float mean = block_sum_256(a, red) / (float)M;
+    for (int j = lane; j < tiles; j += 256) {
+        const float s1 = t1[j], s2 = t2[j];
+        const float mb = s1 * inb, d = mb - mean;
+        q += fmaxf(s2 - s1 * mb, 0.f) + nb * d * d;
+    }
+    const float m2 = block_sum_256(q, red);
+    if (lane != 0) return;
+    bn_stats_finish(c, mean, m2, M, gamma, beta, eps, momentum, rmean, rvar, smean, sinv, scale, shift);
 }
 extern "C" int uem_bn_stats_from_tiles(const float* tile_stats, int tiles, int M, int C, const float* gamma, const float* beta,
                                        float eps, float momentum, float* running_mean, float* running_var, float* save_mean,
@@ -471,7 +503,10 @@ extern "C" int uem_affine_act(const float* x, const float* scale, const float* s
     UEM_REQUIRE(!relu_bits || (C % 32) == 0, "affine_act: relu_bits needs C %% 32 == 0 (C=%d)", C);
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act: bad residual affine");
     const int64_t nvec = M * C / 4;
-    const int rows = (!relu_bits || nvec % 8 == 0) ? bn_rows(nvec, C) : 1;
+    // (fp32: one row per lane unless asked for -- the block-output affine ran at 5.9 TB/s as it was and drops to 5.7 with two rows per
+    // lane, where the backward apply gains, 5.7 -> 6.1, and both bf16 passes do: UEM_BN_ROWS_AFFINE_F32)
+    static const int f32_rows = getenv("UEM_BN_ROWS_AFFINE_F32") ? atoi(getenv("UEM_BN_ROWS_AFFINE_F32")) : 1;
+    const int rows = (f32_rows > 1 && (!relu_bits || nvec % 8 == 0)) ? bn_rows(nvec, C) : 1;
     if (rows == 4)
         affine_act_rows_kernel<float, 4><<<(unsigned)uem_cdiv(nvec, 1024), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     else if (rows == 2)
