@@ -1067,124 +1067,124 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     if (KT > 0) step(st0, st0 + C::STAGE_BYTES / 2, issue_live, false);  // first operand tile of the block's first tile
     int par = 0;                                                         // stage the next k-step consumes
     for (int vc = blockIdx.x; vc < ntiles; vc += gridDim.x) {
-    {
-        const int tile = xcd_remap(vc, ntiles);
-        m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
-    }
+        {
+            const int tile = xcd_remap(vc, ntiles);
+            m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
+        }
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { pb[e] = pg[e] = 0.f; bsc[e] = bsh[e] = bmu[e] = bis[e] = 0.f; }
-    if (fuse_bn) {
-        const float* v4 = p.bn_vec + n0 + sc8;
+        for (int e = 0; e < 8; ++e) { pb[e] = pg[e] = 0.f; bsc[e] = bsh[e] = bmu[e] = bis[e] = 0.f; }
+        if (fuse_bn) {
+            const float* v4 = p.bn_vec + n0 + sc8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bsc[e] = v4[e]; bsh[e] = v4[p.Cout + e]; bmu[e] = v4[2 * p.Cout + e]; bis[e] = v4[3 * p.Cout + e]; }
-    }
-    if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
-    if (KT > 0) {
-        for (int kt = 0; kt < KT; ++kt) {
+            for (int e = 0; e < 8; ++e) { bsc[e] = v4[e]; bsh[e] = v4[p.Cout + e]; bmu[e] = v4[2 * p.Cout + e]; bis[e] = v4[3 * p.Cout + e]; }
+        }
+        if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
+        if (KT > 0) {
+            for (int kt = 0; kt < KT; ++kt) {
+                CONV_SYNC();
+                step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), issue_live, true);
+                par ^= 1;
+            }
+            // every wave past its last operand read, every DMA piece landed: the last step's out-of-range pieces (not persistent: the
+            // staging area spans both stages) or the next tile's first operand tile (persistent: in the other stage)
             CONV_SYNC();
-            step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), issue_live, true);
-            par ^= 1;
+        } else {
+            __syncthreads();
         }
-        // every wave past its last operand read, every DMA piece landed: the last step's out-of-range pieces (not persistent: the
-        // staging area spans both stages) or the next tile's first operand tile (persistent: in the other stage)
-        CONV_SYNC();
-    } else {
-        __syncthreads();
-    }
-    if (PERSIST) stg = reinterpret_cast<float*>(st0 + (par ^ 1) * (C::STAGE_BYTES / 2));
+        if (PERSIST) stg = reinterpret_cast<float*>(st0 + (par ^ 1) * (C::STAGE_BYTES / 2));
 
-    // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
+        // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
 #pragma unroll
-    for (int hm = 0; hm < 2; ++hm) {
-        if (wm / 64 == hm && !ablate_stage) {
-            const int rbase = wm % 64;
+        for (int hm = 0; hm < 2; ++hm) {
+            if (wm / 64 == hm && !ablate_stage) {
+                const int rbase = wm % 64;
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
+                    for (int j = 0; j < NT; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (hm == 0 && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(1);
-        bool rok[NRP];
+                        for (int r = 0; r < 16; ++r)
+                            stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (hm == 0 && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(1);
+            bool rok[NRP];
 #pragma unroll
-        for (int u = 0; u < NRP; ++u) rok[u] = FULL || m0 + hm * 64 + srow + u * RPP < p.M;
-        const uint4 (&o)[NRP] = eo[hm];
-        const uint4 (&zq)[NRP] = ez[hm];
-        unsigned abyte[NRP], bbyte[NRP];
+            for (int u = 0; u < NRP; ++u) rok[u] = FULL || m0 + hm * 64 + srow + u * RPP < p.M;
+            const uint4 (&o)[NRP] = eo[hm];
+            const uint4 (&zq)[NRP] = ez[hm];
+            unsigned abyte[NRP], bbyte[NRP];
 #pragma unroll
-        for (int u = 0; u < NRP; ++u) {
-            const unsigned bshift = (unsigned)(((size_t)(m0 + hm * 64 + srow + u * RPP) * p.Cout + n0 + sc8) & 31);
-            abyte[u] = has_ab ? (eab[hm][u] >> bshift) & 0xffu : 0xffu;
-            bbyte[u] = has_zb ? (ebb[hm][u] >> bshift) & 0xffu : 0u;
-        }
+            for (int u = 0; u < NRP; ++u) {
+                const unsigned bshift = (unsigned)(((size_t)(m0 + hm * 64 + srow + u * RPP) * p.Cout + n0 + sc8) & 31);
+                abyte[u] = has_ab ? (eab[hm][u] >> bshift) & 0xffu : 0xffu;
+                bbyte[u] = has_zb ? (ebb[hm][u] >> bshift) & 0xffu : 0u;
+            }
 #pragma unroll
-        for (int u = 0; u < NRP; ++u) {
-            const int row = srow + u * RPP;
-            if (!rok[u]) continue;
-            float v[8];
-            *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8]);
-            *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8 + 4]);
-            if (acc_on) {
-                const unsigned w4[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+            for (int u = 0; u < NRP; ++u) {
+                const int row = srow + u * RPP;
+                if (!rok[u]) continue;
+                float v[8];
+                *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8]);
+                *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8 + 4]);
+                if (acc_on) {
+                    const unsigned w4[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
+                        v[2 * e] += ((abyte[u] >> (2 * e)) & 1u) ? lo : 0.f;
+                        v[2 * e + 1] += ((abyte[u] >> (2 * e + 1)) & 1u) ? hi : 0.f;
+                    }
+                }
+                unsigned pk[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
-                    v[2 * e] += ((abyte[u] >> (2 * e)) & 1u) ? lo : 0.f;
-                    v[2 * e + 1] += ((abyte[u] >> (2 * e + 1)) & 1u) ? hi : 0.f;
+                    const unsigned lo = f2bf(v[2 * e]), hi = f2bf(v[2 * e + 1]);
+                    pk[e] = lo | (hi << 16);
+                    v[2 * e] = bf2f((unsigned short)lo); v[2 * e + 1] = bf2f((unsigned short)hi);
+                }
+                if (!ablate_store) *reinterpret_cast<uint4*>(yh + row_off(m0 + hm * 64 + row) + n0 + sc8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if (stats_on) {                                              // BatchNorm statistics of what was stored (rounded)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pb[e] += v[e]; pg[e] = fmaf(v[e], v[e], pg[e]); }
+                }
+                if (fuse_bn) {
+                    const unsigned z4[4] = {zq[u].x, zq[u].y, zq[u].z, zq[u].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float z = (e & 1) ? __uint_as_float(z4[e >> 1] & 0xffff0000u) : __uint_as_float(z4[e >> 1] << 16);
+                        const bool on = p.bn_bits != nullptr ? ((bbyte[u] >> e) & 1u) != 0u : (z * bsc[e] + bsh[e] > 0.f);
+                        const float dp = on ? v[e] : 0.f;
+                        pb[e] += dp;
+                        pg[e] = fmaf(dp, (z - bmu[e]) * bis[e], pg[e]);
+                    }
                 }
             }
-            unsigned pk[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned lo = f2bf(v[2 * e]), hi = f2bf(v[2 * e + 1]);
-                pk[e] = lo | (hi << 16);
-                v[2 * e] = bf2f((unsigned short)lo); v[2 * e + 1] = bf2f((unsigned short)hi);
-            }
-            if (!ablate_store) *reinterpret_cast<uint4*>(yh + row_off(m0 + hm * 64 + row) + n0 + sc8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            if (stats_on) {                                              // BatchNorm statistics of what was stored (rounded)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { pb[e] += v[e]; pg[e] = fmaf(v[e], v[e], pg[e]); }
-            }
-            if (fuse_bn) {
-                const unsigned z4[4] = {zq[u].x, zq[u].y, zq[u].z, zq[u].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float z = (e & 1) ? __uint_as_float(z4[e >> 1] & 0xffff0000u) : __uint_as_float(z4[e >> 1] << 16);
-                    const bool on = p.bn_bits != nullptr ? ((bbyte[u] >> e) & 1u) != 0u : (z * bsc[e] + bsh[e] > 0.f);
-                    const float dp = on ? v[e] : 0.f;
-                    pb[e] += dp;
-                    pg[e] = fmaf(dp, (z - bmu[e]) * bis[e], pg[e]);
-                }
-            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    float* const tile_out = fuse_bn ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
-    if (tile_out != nullptr) {                                           // column sums over the tile's 128 rows
-        // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
-        float* const red = stg;                                          // [2][RPP][BN]
+        float* const tile_out = fuse_bn ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
+        if (tile_out != nullptr) {                                           // column sums over the tile's 128 rows
+            // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
+            float* const red = stg;                                          // [2][RPP][BN]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, col = tid % BN;
-            float a = 0.f;
+            for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; }
+            __syncthreads();
+            if (tid < 2 * BN) {
+                const int which = tid / BN, col = tid % BN;
+                float a = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + col];
-            const size_t tiles_m = (size_t)(p.M / BM);
-            tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
+                for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + col];
+                const size_t tiles_m = (size_t)(p.M / BM);
+                tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
+            }
         }
-    }
-    if (!PERSIST) break;
+        if (!PERSIST) break;
     }                                                                    // tiles of a persistent block
 #undef CONV_SYNC
 }

@@ -651,9 +651,11 @@ extern "C" int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
     // off, 1 every pointwise layer, else the threshold on Cin * Cout.
     static const int tn128 = getenv("UEM_WGRAD_BF16_TN128") ? atoi(getenv("UEM_WGRAD_BF16_TN128")) : (1 << 20);
     const bool pw = s->KH == 1 && s->KW == 1 && s->pad == 0 && s->stride == 1;
-    const bool ok = (tn128 && pw && s->Cout % 128 == 0 && s->Cin % 128 == 0 && (tn128 == 1 || s->Cin * s->Cout >= tn128))
-                        ? wgb_dispatch<128, 128>(p, s, (hipStream_t)stream)
-                        : (s->Cout % 128 == 0 ? wgb_dispatch<128, 64>(p, s, (hipStream_t)stream) : wgb_dispatch<64, 64>(p, s, (hipStream_t)stream));
+    if (tn128 && pw && s->Cout % 128 == 0 && s->Cin % 128 == 0 && (tn128 == 1 || s->Cin * s->Cout >= tn128)) {
+        wgb_go<128, 128, 1, 1, 0, true, 64>(p, (hipStream_t)stream);     // the only 128 x 128 instantiation: linear 1x1, 64-pixel steps
+        return uem_check_launch("conv2d_wgrad_bf16");
+    }
+    const bool ok = s->Cout % 128 == 0 ? wgb_dispatch<128, 64>(p, s, (hipStream_t)stream) : wgb_dispatch<64, 64>(p, s, (hipStream_t)stream);
     if (!ok) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_wgrad_bf16: 1x1 (stride 1, or 2 with rows of 32 pixels) and 3x3 on rows of 32 pixels only");
     return uem_check_launch("conv2d_wgrad_bf16");
 }
