@@ -56,7 +56,15 @@ class conv_precision:
         return False
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """the current HIP stream's handle (what every entry point launches on).  torch.cuda.current_stream() builds a Stream object per
+    call -- 10 % of the host's time per step over ~940 launches; the raw getter is one C call and follows torch.cuda.stream(...) /
+    graph capture the same way."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
