@@ -100,3 +100,43 @@ def test_config_merge_is_recursive():
     c.update(dict(backbone=dict(resnet_type="resnet50", output_stride=32), x=1))
     c.update(dict(backbone=dict(output_stride=16)))
     assert c.backbone.resnet_type == "resnet50" and c.backbone.output_stride == 16 and c.x == 1
+
+
+def test_committed_bench_line_obeys_the_contract():
+    """The bench line under profiles/ (the last `python bench.py` of the round, copied from the GPU box) has the fields the driver
+    and the judge read, fractions are fractions, and its HBM-traffic stamp belongs to the conv sources in the tree."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))[-1]
+    line = json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert line["metric"] == base["metric"] and line["higher_is_better"] is True and line["scaling"] == "weak"
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["vs_baseline"] is None                               # BASELINE.md publishes no number for this metric on this hardware
+    tiles = line["config"]["global_batch"] * line["n_gpus"] if "global_batch" in line["config"] else None
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - (tiles or 64)) < 0.02 * (tiles or 64)     # value = tiles per step / step time
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert 0.0 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    for fam in roof["families"].values():
+        assert 0.0 < fam["frac"] <= 1.0
+    for cfg in line.get("other_configs", {}).values():
+        for fam in cfg["roofline"]["families"].values():
+            assert 0.0 < fam["frac"] <= 1.0
+    hb = line["roofline_hbm"]
+    assert hb["bound"] == "hbm" and 0.0 < hb["frac"] <= 1.0
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # the PMC traffic stamp in the tree was taken on THESE kernel sources (bench.py reports traffic: null otherwise)
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "kernel_source_sha256_16" in src
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv.hip", "wgrad.hip", "winograd.hip"):
+        h.update(open(os.path.join(root, "uemda_amd", "csrc", f), "rb").read())
+    stamp = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))
+    assert stamp["kernel_source_sha256_16"] == h.hexdigest()[:16], "re-run scripts/measure_round.sh: the conv sources changed since the PMC pass"
+    assert roof["traffic"] is not None
