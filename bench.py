@@ -366,6 +366,9 @@ def main():
     from uemda_amd import dp as udp, ops
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     cores = pin_cpus(int(os.environ.get("LOCAL_RANK", "0")), local_world)     # before any thread pool or GPU call
+    # what the rank can actually run on: its slice of the affinity mask capped by the cgroup's CPU grant (a one-GPU box shows 256 CPUs
+    # in the mask and grants 16 -- the figure cpu_baseline.cores reports too)
+    cores = max(1, min(cores, usable_cpus() // max(1, local_world)))
     if args.device is not None:
         torch.cuda.set_device(args.device)
     rank, world, local = udp.init(args.backend, device=args.device)
@@ -433,6 +436,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROF.enabled = False
+    if args.workload == "ssl":
+        aligner.check_superpixel_ids()            # the last step's report (inside the step the check never waits)
     replicas = None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)

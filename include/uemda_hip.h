@@ -434,8 +434,9 @@ int uem_weight_prep(const uem_prep_job* jobs /* device */, const int* block_star
  * uem_comm_init.  This is the library's only state (the communicator handles the caller holds); there is nothing else
  * to shut down, which is why the header has no uem_shutdown().  RCCL is taken from the host process (PyTorch-ROCm
  * carries its own librccl.so) and loaded from /opt/rocm only when the process has none.
- * uemda_amd.dp keeps torch.distributed (backend "nccl" = the same RCCL) as its default transport and switches to these
- * entry points with UEM_DP_NATIVE=1: with one GPU per box the multi-rank leg of this path cannot be rehearsed here.   */
+ * uemda_amd.dp uses torch.distributed (backend "nccl" = the same RCCL) as its ONLY transport (round 4 removed its
+ * UEM_DP_NATIVE switch); these entry points are for hosts without torch.distributed and are driven directly by
+ * tests/test_gpu_dp.py (one rank: with one GPU per box the multi-rank leg cannot be rehearsed here).                 */
 int uem_comm_unique_id(void* id_out_128_bytes /* host */);
 int uem_comm_init(void** comm_out, const void* id_128_bytes /* host */, int rank, int world);
 int uem_allreduce_flat(void* comm, float* buf /* device, in place */, int64_t count, void* stream);

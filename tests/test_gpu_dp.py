@@ -18,6 +18,14 @@ COMMON = ["--batch", "4", "--size", "256", "--steps", "2", "--warmup", "1", "--n
           "--no-kernel-events"]
 
 
+def _report(rc, stdout, stderr, head=2500, tail=2500):
+    """What an assertion on a child process shows: the return code (negative = killed by that signal), the tail of stdout, and
+    BOTH ends of stderr -- the first lines carry the c10 / HIP message that names the failing call, the last ones the abort's frames
+    (a SIGABRT in the captured data-parallel step left only libc frames in the record because the tail alone was kept)."""
+    err = stderr if len(stderr) <= head + tail else stderr[:head] + f"\n... [{len(stderr) - head - tail} chars cut] ...\n" + stderr[-tail:]
+    return f"child rc={rc}\n--- stdout (tail) ---\n{stdout[-1500:]}\n--- stderr (head + tail) ---\n{err}"
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -29,7 +37,7 @@ def _bench(extra_env, *args):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, *args],
                          env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert out.returncode == 0 and lines, out.stderr[-2000:]
+    assert out.returncode == 0 and lines, _report(out.returncode, out.stdout, out.stderr)
     return json.loads(lines[-1])
 
 
@@ -52,7 +60,7 @@ def _two_ranks(path, *args, env=None):
                 q.kill()
             raise
     for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, se[-3000:]
+        assert p.returncode == 0, _report(p.returncode, so, se)
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
     return line, [torch.load(f"{path}.rank{r}.pt") for r in range(2)]
 
@@ -86,7 +94,7 @@ def test_single_rank_rccl_allreduce_through_the_c_abi():
         "print('ALLREDUCE_OK')\n")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
                          capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "ALLREDUCE_OK" in out.stdout, out.stderr[-2000:]
+    assert out.returncode == 0 and "ALLREDUCE_OK" in out.stdout, _report(out.returncode, out.stdout, out.stderr)
 
 
 def test_single_rank_rccl_graphed_data_parallel_step():
@@ -97,12 +105,12 @@ def test_single_rank_rccl_graphed_data_parallel_step():
                RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dp_graph_check.py")], env=env, capture_output=True, text=True,
                          timeout=600)
-    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    assert out.returncode == 0 and "DP_GRAPH_OK" in out.stdout, _report(out.returncode, out.stdout, out.stderr)
     # and the gloo group (host round trip) is refused up front, not captured wrongly
     env["UEM_DP_BACKEND"] = "gloo"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dp_graph_check.py")], env=env, capture_output=True, text=True,
                          timeout=600)
-    assert out.returncode == 0 and "DP_GRAPH_REFUSED" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    assert out.returncode == 0 and "DP_GRAPH_REFUSED" in out.stdout, _report(out.returncode, out.stdout, out.stderr)
 
 
 def test_two_rank_data_parallel_object(tmp_path):

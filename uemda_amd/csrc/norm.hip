@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void affine_act_bf16x8_rows_kernel(const bf16_
         }
     }
 }
-static inline int bn_rows(int64_t nvec, int C);
+static inline int bn_rows(int64_t nvec, int C, int per_vec);
 extern "C" int uem_affine_act(const float* x, const float* scale, const float* shift, const float* res,
                               const float* res_scale, const float* res_shift, float* y, int64_t M, int C, int relu,
                               uint32_t* relu_bits, void* stream) {
@@ -506,7 +506,7 @@ extern "C" int uem_affine_act(const float* x, const float* scale, const float* s
     // (fp32: one row per lane unless asked for -- the block-output affine ran at 5.9 TB/s as it was and drops to 5.7 with two rows per
     // lane, where the backward apply gains, 5.7 -> 6.1, and both bf16 passes do: UEM_BN_ROWS_AFFINE_F32)
     static const int f32_rows = getenv("UEM_BN_ROWS_AFFINE_F32") ? atoi(getenv("UEM_BN_ROWS_AFFINE_F32")) : 1;
-    const int rows = (f32_rows > 1 && (!relu_bits || nvec % 8 == 0)) ? bn_rows(nvec, C) : 1;
+    const int rows = (f32_rows > 1 && (!relu_bits || nvec % 8 == 0)) ? bn_rows(nvec, C, 4) : 1;
     if (rows == 4)
         affine_act_rows_kernel<float, 4><<<(unsigned)uem_cdiv(nvec, 1024), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec, C, relu, relu_bits);
     else if (rows == 2)
@@ -523,7 +523,7 @@ extern "C" int uem_affine_act_bf16(const uint16_t* x, const float* scale, const 
     UEM_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || res), "affine_act_bf16: bad residual affine");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0) {       // with bits: C % 32 == 0, whole lane quads
         const int64_t nvec8 = M * C / 8;
-        const int rows = (!relu_bits || nvec8 % 4 == 0) ? bn_rows(nvec8, C) : 1;
+        const int rows = (!relu_bits || nvec8 % 4 == 0) ? bn_rows(nvec8, C, 8) : 1;
         if (rows == 4)
             affine_act_bf16x8_rows_kernel<4><<<(unsigned)uem_cdiv(nvec8, 1024), 256, 0, (hipStream_t)stream>>>(x, scale, shift, res, res_scale, res_shift, y, nvec8, C, relu, relu_bits);
         else if (rows == 2)
@@ -779,10 +779,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* __restr
     }
 }
 // rows per lane of the elementwise BatchNorm passes on large tensors: UEM_BN_ROWS (1 = the grid-stride kernels)
-static inline int bn_rows(int64_t nvec, int C) {
+// A lane keeps ONE set of per-channel vectors for all its rows: the row stride (gridDim * 256 vectors of per_vec elements) must be a
+// multiple of C, which an odd block count breaks at C = 2048 with 4-element vectors (odd M = N*H*W) -> one row per lane there.
+static inline int bn_rows(int64_t nvec, int C, int per_vec) {
     static const int rows = getenv("UEM_BN_ROWS") ? atoi(getenv("UEM_BN_ROWS")) : 2;
     if (rows < 2 || nvec < ((int64_t)1 << 20) || C < 64 || C > 2048 || (C & (C - 1)) != 0) return 1;
-    return rows >= 4 ? 4 : 2;
+    const int R = rows >= 4 ? 4 : 2;
+    if ((uem_cdiv(nvec, (int64_t)256 * R) * 256 * per_vec) % C != 0) return 1;
+    return R;
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                   const uint32_t* __restrict__ rbits, const float* __restrict__ scale,
@@ -878,7 +882,7 @@ extern "C" int uem_bn_bwd_apply(const float* x, const float* dy, const void* yma
     UEM_REQUIRE(M > 0 && C > 0 && (C % 4) == 0, "bn_bwd_apply: bad shape");
     UEM_REQUIRE(relu != UEM_RELU_BITS || (ymask && C % 32 == 0), "bn_bwd_apply: UEM_RELU_BITS needs the bit mask and C %% 32 == 0");
     const int64_t nvec = (int64_t)M * C / 4;
-    const int rows = bn_rows(nvec, C);
+    const int rows = bn_rows(nvec, C, 4);
     if (rows == 4)
         bn_bwd_apply_rows_kernel<float, 4><<<(unsigned)uem_cdiv(nvec, 1024), 256, 0, (hipStream_t)stream>>>(
             x, dy, (const float*)ymask, scale, shift, save_mean, save_invstd, dgamma, dbeta, nvec, C, 1.0f / (float)M, relu, dx, dres);
@@ -898,7 +902,7 @@ extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, cons
     UEM_REQUIRE(relu == 0 || (relu == 1 && !relu_bits) || (relu == UEM_RELU_BITS && relu_bits && C % 32 == 0), "bn_bwd_apply_bf16: bad relu mode");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0) {
         const int64_t nvec8 = (int64_t)M * C / 8;
-        const int rows = bn_rows(nvec8, C);
+        const int rows = bn_rows(nvec8, C, 8);
         if (rows > 1) {
             if (rows >= 4)
                 bn_bwd_apply_bf16x8_rows_kernel<4><<<(unsigned)uem_cdiv(nvec8, 1024), 256, 0, (hipStream_t)stream>>>(

@@ -167,13 +167,18 @@ class Aligner:
         ev.record()
         self._oor_pending = (ev, host, S, oor)
 
-    def check_superpixel_ids(self):
-        """Raise if the last label_refine saw a superpixel id outside its table (waits for that call only)."""
+    def check_superpixel_ids(self, wait=True):
+        """Raise if the last label_refine saw a superpixel id outside its table.  wait=True waits for that call (only); wait=False
+        looks at the report only if it has already arrived and otherwise leaves it pending -- the next label_refine (or a later
+        call here) picks it up, one step late and without stalling the host in the middle of a step (the eager step's form:
+        VERDICT r4, the host's enqueue ran in lock step with the device)."""
         pend = getattr(self, "_oor_pending", None)
         if pend is None or _NO_SUP_CHECK:
             return
-        self._oor_pending = None
         ev, host, S, _keep = pend
+        if not wait and not ev.query():
+            return
+        self._oor_pending = None
         ev.synchronize()
         worst = int(host)
         if worst != 0:

@@ -24,14 +24,23 @@ RELU_BITS = os.environ.get("UEM_RELU_BITS", "1") != "0"      # block-output ReLU
 # fp32 islands (7x7 stem, ASPP / PPM heads): models set it per launch through `conv_precision`.  The split-operand modes of rounds
 # 1-3 ("bf16x3", "mixed") are retired: they ran the round-1 register-staged kernels and none could be the headline.
 _PREC_FLAGS = {"fp32": (0, 0), "bf16": (_lib.CONV_PREC_BF16,) * 2}
-CONV_PREC, CONV_PREC_BWD = _PREC_FLAGS[os.environ.get("UEM_CONV_PREC", "fp32")]
+_RETIRED_PREC = ("bf16x3", "mixed")
+
+
+def _prec_flags(name, where):
+    if name in _RETIRED_PREC:
+        raise UemError(f"{where}: conv precision {name!r} was retired in round 4 (DESIGN 3.2); use one of {sorted(_PREC_FLAGS)}")
+    if name not in _PREC_FLAGS:
+        raise UemError(f"{where}: conv precision must be one of {sorted(_PREC_FLAGS)}, got {name!r}")
+    return _PREC_FLAGS[name]
+
+
+CONV_PREC, CONV_PREC_BWD = _prec_flags(os.environ.get("UEM_CONV_PREC", "fp32"), "UEM_CONV_PREC")
 
 
 def set_conv_precision(name):
     global CONV_PREC, CONV_PREC_BWD
-    if name not in _PREC_FLAGS:
-        raise UemError(f"conv precision must be one of {sorted(_PREC_FLAGS)}, got {name!r}")
-    CONV_PREC, CONV_PREC_BWD = _PREC_FLAGS[name]
+    CONV_PREC, CONV_PREC_BWD = _prec_flags(name, "set_conv_precision")
 
 
 class conv_precision:
@@ -39,8 +48,8 @@ class conv_precision:
     block (None: leave it alone); the bf16-storage model runs its fp32 ASPP GEMMs with bf16 operands this way."""
 
     def __init__(self, name):
-        if name is not None and name not in _PREC_FLAGS:
-            raise UemError(f"conv precision must be one of {sorted(_PREC_FLAGS)}, got {name!r}")
+        if name is not None:
+            _prec_flags(name, "conv_precision")
         self.name = name
 
     def __enter__(self):
@@ -473,6 +482,18 @@ class _WeightPrepPerDevice:
     def settle(self):
         """every device's job table as it stands (built now if stale): [(jobs tensor, starts tensor, njobs, blocks)]"""
         return [t for t in (p.settle() for p in self.by_device.values()) if t is not None]
+
+    def hold(self):
+        """Strong references to everything the settled tables point at: [(parameter, derived bank)] of every live job.  A captured
+        `uem_weight_prep` launch reads each job's parameter and writes its bank on EVERY replay -- also the jobs of other models that
+        were alive on the device at capture time -- so whoever owns the graph keeps this list for the graph's life: none
+        of those parameters can then be freed, no job goes `gone`, no bank is released under the graph."""
+        self.settle()
+        out = []
+        for p in self.by_device.values():
+            for j in getattr(p, "live", []) if p.table is not None else []:
+                out.append((j["ref"](), j["dst"]))
+        return out
 
 
 PREP = _WeightPrepPerDevice()

@@ -49,7 +49,9 @@ def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id
     mark("grad_allreduce_wait")
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)             # :230-232 (clip 32 + SGD)
     mark("clip_sgd")
-    aligner.check_superpixel_ids()        # raises if this step's superpixel ids did not fit the segment table
+    # a superpixel id that did not fit the segment table raises here if the device's report is already in, else at the next step's
+    # label_refine (no host wait inside the step; `aligner.check_superpixel_ids()` after the last step waits for the last report)
+    aligner.check_superpixel_ids(wait=False)
     return dict(loss_source=loss_source.detach(), loss_target=loss_target.detach(), label_t_soft=soft,
                 label_t_hard=hard, label_s_ds=label_ds, pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
                 pred_t1=pred_t1.detach(), pred_t2=pred_t2.detach(), feat_s=feat_s.detach(), feat_t=feat_t.detach(),
@@ -113,7 +115,7 @@ def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_
     loss.backward()
     prescale = dp.reduce_gradients() if dp is not None else 1.0
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
-    aligner.check_superpixel_ids()
+    aligner.check_superpixel_ids(wait=False)
     return dict(loss_seg=loss_seg.detach(), loss_domain=loss_domain.detach() if torch.is_tensor(loss_domain) else loss_domain,
                 loss_align=loss_align.detach(), label_t_hard=hard, pred_s1=pred_s1.detach(), pred_t1=pred_t1.detach(),
                 grad_norm=optimizer.last_grad_norm)
@@ -166,8 +168,10 @@ class GraphedStep:
                 run()
         torch.cuda.current_stream().wait_stream(side)
         # the weight-preparation job table is fixed before the capture (a single warm-up step leaves it half built) and stays alive as
-        # long as the graph whose refresh launch reads it
+        # long as the graph whose refresh launch reads it -- and so does every parameter / derived bank the table points at, including
+        # those of OTHER models alive on the device now (the captured launch covers the whole table)
         self._prep_tables = ops.PREP.settle()
+        self._prep_hold = ops.PREP.hold()
         self.graph = torch.cuda.CUDAGraph()
         steps_before = optimizer._steps
         # With a process group alive, its watchdog thread polls its work events (hipEventQuery) whenever it likes: under the default
