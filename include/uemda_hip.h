@@ -236,9 +236,9 @@ int uem_segment_max_planar(const float* soft, const int64_t* sup, uint32_t* seg_
 int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
                      const float* logits2 /* may be NULL */, const uint32_t* seg_keys,
                      const int64_t* ignore_id /* device */, float* soft_out, uint32_t* plane_max,
-                     float* workspace /* uem_label_refine_workspace_floats(B,C,H,W) */, int B, int C, int h, int w,
+                     float* workspace /* uem_label_refine_workspace_floats(B,C,H,W,S) */, int B, int C, int h, int w,
                      int H, int W, int S, float temp, int mode, void* stream);
-int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W);
+int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W, int S);
 /* per-(b,c) max over H*W of an NCHW map                                pseudo_generation.py:76     */
 int uem_plane_max(const float* mask, uint32_t* plane_max, int B, int C, int64_t HW, void* stream);
 /* hard[b][p] = the unique c with mask > max(cutoff_top*max_c, cutoff_low), else ignore

@@ -41,6 +41,30 @@ def test_pearson_golden(aligner):
     torch.testing.assert_close(d.cpu(), g["dist"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("k,n,m", [(2048, 4097, 6), (2048, 2, 7), (1024, 1023, 6), (512, 77, 8), (256, 5, 3), (2048, 1, 1), (192, 33, 6)])
+def test_pearson_register_resident_rows_vs_oracle(k, n, m):
+    """The one-pass kernels (k = 256 * KV: the row lives in registers, prototypes centred in the block's prologue) at every feature
+    width they are instantiated for, with odd row counts (the wave's second row missing) and class counts up to 8; k = 192 takes the
+    two-pass kernel.  Against the oracle's formula (alignment.py:424-451) and against float64."""
+    from oracle import gast
+    from uemda_amd.gast.alignment import Aligner
+    g = torch.Generator().manual_seed(k + n + m)
+    x = torch.randn(n, k, generator=g) * 1.5 + 0.7
+    pr = torch.randn(m, k, generator=g) + 0.2
+    x[0] = pr[0] * 2.0 + 0.1                                           # a row almost perfectly correlated with a prototype: dist ~ 0
+    al = Aligner(None, feat_channels=k, class_num=m, ignore_label=-1, decay=0.996)
+    d = al._pearson_dist(dev(x), dev(pr)).cpu()
+    torch.testing.assert_close(d, gast.pearson_dist(x, pr), rtol=1e-5, atol=2e-6)
+    xd, pd = x.double(), pr.double()
+    xc, pc = xd - xd.mean(1, keepdim=True), pd - pd.mean(1, keepdim=True)
+    r = (xc @ pc.T) / (xc.norm(dim=1, keepdim=True) * pc.norm(dim=1).unsqueeze(0))
+    torch.testing.assert_close(d.double(), 0.5 * (1 - r), rtol=1e-4, atol=2e-6)
+    if m <= 8:
+        al.prototypes = dev(pr).contiguous()
+        sim = al._pearson_sim_map(dev(x).view(1, 1, n, k)).cpu().view(n, m)
+        torch.testing.assert_close(sim[1:], 1.0 / gast.pearson_dist(x, pr)[1:], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("mode", ["all", "s", "p", "l"])
 def test_label_refine_golden(aligner, mode):
     g = load_golden("label_refine")

@@ -86,7 +86,7 @@ SIGNATURES = {
     "uem_scatter": [P, P, P, P, I, I, I, I, I, P],
     "uem_segment_max_planar": [P, P, P, I, I, I, I, I, P, P],
     "uem_label_refine": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
-    "uem_label_refine_workspace_floats": [I, I, I, I],
+    "uem_label_refine_workspace_floats": [I, I, I, I, I],
     "uem_plane_max": [P, P, I, I, L, P],
     "uem_pseudo_select": [P, P, P, P, I, I, L, F, F, L, P],
     "uem_downscale_label": [P, P, I, I, I, I, I, L, F, P],

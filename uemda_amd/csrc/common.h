@@ -49,6 +49,36 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// Wave reductions on the DPP path (no LDS traffic: __shfl_xor is ds_bpermute_b32, one LDS-pipe round trip per step and six dependent
+// steps per reduction).  Prefix scan inside each 16-lane row (row_shr 1, 2, 4, 8, zero fill), then row_bcast:15 / row_bcast:31 carry
+// the row totals up: lane 63 holds the wave's total, read back through v_readlane as a wave-uniform value.  Every lane of the wave must
+// be active at the call (EXEC all ones), as for any cross-lane operation.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take0(float v) {      // lanes without a source read 0
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_take0<0x111, 0xF>(v);                         // row_shr:1
+    v += dpp_take0<0x112, 0xF>(v);                         // row_shr:2
+    v += dpp_take0<0x114, 0xF>(v);                         // row_shr:4
+    v += dpp_take0<0x118, 0xF>(v);                         // row_shr:8   -> lane 15 of each row = the row's sum
+    v += dpp_take<0x142, 0xA>(0.f, v);                     // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xC>(0.f, v);                     // row_bcast:31 into rows 2 and 3 -> lane 63 = the wave's sum
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {   // lanes without a source keep their own value: max(v, v) = v
+    v = fmaxf(v, dpp_take<0x111, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x112, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x114, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x118, 0xF>(v, v));
+    v = fmaxf(v, dpp_take<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_take<0x143, 0xC>(v, v));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

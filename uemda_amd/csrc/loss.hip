@@ -64,31 +64,63 @@ __device__ __forceinline__ float uvem_weight_dev(float u, float m, float t, floa
 // applied per pixel), then added with the two x weights into a per-wave LDS image of the band's two logit rows
 // (LDS atomics; per-wave images summed in fixed order).  Band cy's second row and band cy+1's first row are the
 // same logit row: the bands' images go to the workspace and loss_band_combine_kernel adds the pair.
-#define LOSS_THREADS 256                 // (512 -- one column per thread at W = 512 -- measured the same 0.21 ms: the bands are VALU-bound, not latency-bound)
-#define LOSS_WAVES (LOSS_THREADS / 64)
+// Round 5.  (a) ONE HEAD PER THREAD: a block is 256 threads per head (512 for the two-head calls of the training step), thread
+// group hd = tid / 256 owns head hd of every pixel column; the live state halves (~64 VGPRs, eight waves per SIMD instead of four).
+// The label / soft-label fetch and the UVEM weight are computed by both groups (the second read is an L2 hit).
+// (b) NO LDS ATOMICS.  Round 4 added each column's 24 gradient sums into per-wave LDS images of the two logit rows with ds_add_f32:
+// the ~16 columns of a logit cell sit in adjacent lanes, every such instruction carried four addresses with sixteen lanes each, and
+// the LDS serialised them -- an ablation with the atomics compiled out ran the band in 71 us (CE) / 101 us (UVEM) against 196 / 206
+// with them: more than half of the kernel.  Now a pass's column sums go to LDS column-major, [value][column], and after one barrier
+// each (row, cell, class) output is summed by ONE thread over the ~33 columns that touch its cell, in ascending column order (still
+// deterministic), straight into the band image.
+#define LOSS_COLS 256                    // pixel columns per pass (threads per head)
+#define LOSS_WAVES (LOSS_COLS / 64)      // waves per head
+#define LOSS_CPAD (LOSS_COLS + 1)        // row pitch of the column-major sums (value j, column x -> bank (j + x) mod 32)
+static inline size_t loss_lds_floats(int w, int cmax, int nheads) {
+    // low [2 heads][2 rows][w][cmax] + column sums [nheads][2 cmax][LOSS_CPAD] + per-column l1 [LOSS_COLS] + band image [nheads][2][w][cmax]
+    // + first column of each cell [w + 1]
+    return (size_t)4 * w * cmax + (size_t)nheads * 2 * cmax * LOSS_CPAD + LOSS_COLS + (size_t)nheads * 2 * w * cmax + (size_t)w + 1;
+}
+// first column X in [lo, hi) whose upper-left logit cell min((int)(sx * X), w - 1) is >= x (hi if none): the cells are monotone in X
+__device__ __forceinline__ int loss_first_col(int x, int w, float sx, int lo, int hi) {
+    if (x <= 0) return lo;
+    if (!(sx > 0.f)) return hi;
+    int g = (int)((float)x / sx);
+    g = g < lo ? lo : (g > hi ? hi : g);
+    while (g > lo && lerp_ac(g - 1, w, sx).i0 >= x) --g;
+    while (g < hi && lerp_ac(g, w, sx).i0 < x) ++g;
+    return g;
+}
 // EXACT: the class count IS CMAX (6 and 7, the reference's two datasets, have their own CMAX): the `c < C` guards of the unrolled
 // per-class loops fold at compile time instead of costing a compare + select each
 template <int CMAX, int MODE, bool EXACT>
-__global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
+__global__ __launch_bounds__(2 * LOSS_COLS, (CMAX <= 6 ? 8 : 1)) void loss_band_kernel(
     const float* __restrict__ lg1, const float* __restrict__ lg2, const int64_t* __restrict__ label,
     const float* __restrict__ soft, const float* __restrict__ pixw, float* __restrict__ band_grad,
     float* __restrict__ partial, int C_, int h, int w, int H, int W, float um, float ut, float inv_gamma, int64_t ignore) {
     const int C = EXACT ? CMAX : C_;
     extern __shared__ __attribute__((aligned(16))) float loss_sm[];
+    const int nheads = lg2 ? 2 : 1;                    // blockDim.x == LOSS_COLS * nheads
+    const int nthr = LOSS_COLS * nheads;
+    const int nout = 2 * w * CMAX;                     // outputs per head: [2 rows][w][CMAX]
     float* low = loss_sm;                              // [2 heads][2 rows][w][CMAX]
-    float* acc = loss_sm + 4 * w * CMAX;               // [LOSS_WAVES][2 rows][w][2 heads][CMAX]
+    float* colA = low + 4 * w * CMAX;                  // [nheads][2 * CMAX][LOSS_CPAD]: this pass's column sums (band row 0 classes, then row 1)
+    float* colL1 = colA + (size_t)nheads * 2 * CMAX * LOSS_CPAD;   // [LOSS_COLS]: this pass's x weights l1
+    float* img = colL1 + LOSS_COLS;                    // [nheads][2 rows][w][CMAX]: the band's gradient image
+    int* cstart = reinterpret_cast<int*>(img + (size_t)nheads * nout);     // [w + 1]: first column of each cell in the current pass
     const int cy = blockIdx.x % h, b = blockIdx.x / h;
     const int cy1 = cy + (cy < h - 1 ? 1 : 0);
     const size_t plane = (size_t)H * W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 4 * w * CMAX; i += LOSS_THREADS) {
-        const int c = i % CMAX, x = (i / CMAX) % w, r = (i / (CMAX * w)) & 1, hd = i / (2 * CMAX * w);
-        const float* src = hd ? lg2 : lg1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hd = tid / LOSS_COLS, ctid = tid % LOSS_COLS, wave = ctid >> 6;
+    for (int i = tid; i < 4 * w * CMAX; i += nthr) {
+        const int c = i % CMAX, x = (i / CMAX) % w, r = (i / (CMAX * w)) & 1, hh = i / (2 * CMAX * w);
+        const float* src = hh ? lg2 : lg1;
         float v = 0.f;
         if (src != nullptr && c < C) v = src[(((size_t)b * h + (r ? cy1 : cy)) * w + x) * C + c];
         low[i] = v;
     }
-    for (int i = tid; i < LOSS_WAVES * 4 * w * CMAX; i += LOSS_THREADS) acc[i] = 0.f;
+    for (int i = tid; i < nheads * nout; i += nthr) img[i] = 0.f;
     __syncthreads();
     // candidate rows of the band (a superset; rows whose i0 differs are skipped)
     int ya = 0, yb = H - 1;
@@ -102,108 +134,131 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_band_kernel(
     // exact row range of the band inside the candidate window
     while (ya <= yb && lerp_setup(ya, h, H, true).i0 != cy) ++ya;
     while (yb >= ya && lerp_setup(yb, h, H, true).i0 != cy) --yb;
-    float* wacc = acc + (size_t)wave * 4 * w * CMAX;
+    const float* lowh = low + (size_t)hd * 2 * w * CMAX;
+    float* colAh = colA + (size_t)hd * 2 * CMAX * LOSS_CPAD;
+    float* imgh = img + (size_t)hd * nout;
     const float sy = lerp_scale_ac(h, H), sx = lerp_scale_ac(w, W);     // hoisted: one division per block instead of one per pixel
-    float loss1 = 0.f, loss2 = 0.f, valid = 0.f;
+    float loss = 0.f, valid = 0.f;
     struct Px { int64_t lab; float q[CMAX]; float pw; };
-    for (int X = tid; X < W; X += LOSS_THREADS) {
-        const Lerp lx = lerp_ac(X, w, sx);
-        const float* L00 = low + (size_t)lx.i0 * CMAX;                 // head 0, row 0
-        const float* L01 = low + (size_t)lx.i1 * CMAX;
-        // x-interpolated logits of the band's two rows (constant down the column): top/bot [head][class]
-        float top[2][CMAX], bot[2][CMAX];
-        float a0[2][CMAX], a1[2][CMAX];                                // [band row][class] for head 0 / head 1
+    for (int Xb = 0; Xb < W; Xb += LOSS_COLS) {                         // block-uniform: every thread takes every pass (barriers inside)
+        const int X = Xb + ctid;
+        const bool on = X < W;
+        const Lerp lx = lerp_ac(on ? X : W - 1, w, sx);
+        float a0[CMAX], a1[CMAX];                                       // the column's gradient sums for the band's two rows
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-            a0[0][c] = a0[1][c] = a1[0][c] = a1[1][c] = 0.f;
-            top[0][c] = lx.l0 * L00[c] + lx.l1 * L01[c];
-            bot[0][c] = lx.l0 * L00[w * CMAX + c] + lx.l1 * L01[w * CMAX + c];
-            top[1][c] = lx.l0 * L00[2 * w * CMAX + c] + lx.l1 * L01[2 * w * CMAX + c];
-            bot[1][c] = lx.l0 * L00[3 * w * CMAX + c] + lx.l1 * L01[3 * w * CMAX + c];
-        }
-        auto fetch = [&](int Y, Px& px) {
-            const size_t p = (size_t)b * plane + (size_t)Y * W + X;
-            px.lab = label[p];
-            if (MODE == 1) {
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < C) px.q[c] = soft[((size_t)b * C + c) * plane + (size_t)Y * W + X];
-            }
-            px.pw = pixw ? pixw[p] : 1.0f;
-        };
-        Px cur, nxt;
-        if (ya <= yb) fetch(ya, cur);
-        for (int Y = ya; Y <= yb; ++Y) {
-            if (Y < yb) fetch(Y + 1, nxt);                            // next row's loads fly during this row's math
-            const Lerp ly = lerp_ac(Y, h, sy);
-            const int64_t lab64 = cur.lab;
-            const bool lab_ok = (lab64 != ignore) && lab64 >= 0 && lab64 < C;
-            const int lab = lab_ok ? (int)lab64 : -1;
-            float pw = 1.0f;      // per-pixel coefficient on (softmax - onehot)
-            if (MODE == 1) {
-                float u = 0.f;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < C) { const float q = cur.q[c]; u += -q * fast_log(q); }
-                const bool gate = !(u > ut);                          // ce[u > t] = 0
-                pw = gate ? uvem_weight_dev(u, um, ut, inv_gamma) : 0.f;
-                if ((u <= ut) && lab64 != ignore) valid += 1.f;
-            }
-            pw *= cur.pw;
-            if (!lab_ok) pw = 0.f;                                    // ignore_index: zero loss and gradient
-            float v[CMAX], ce;
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < C) v[c] = ly.l0 * top[0][c] + ly.l1 * bot[0][c];
-            softmax_ce<CMAX>(v, C, lab, ce);
-            loss1 += pw * ce;
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-                if (c < C) { const float g = pw * (v[c] - (c == lab ? 1.f : 0.f)); a0[0][c] += ly.l0 * g; a0[1][c] += ly.l1 * g; }
-            if (lg2) {
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < C) v[c] = ly.l0 * top[1][c] + ly.l1 * bot[1][c];
-                softmax_ce<CMAX>(v, C, lab, ce);
-                loss2 += pw * ce;
-#pragma unroll
-                for (int c = 0; c < CMAX; ++c)
-                    if (c < C) { const float g = pw * (v[c] - (c == lab ? 1.f : 0.f)); a1[0][c] += ly.l0 * g; a1[1][c] += ly.l1 * g; }
-            }
-            cur = nxt;
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < CMAX; ++c) a0[c] = a1[c] = 0.f;
+        if (on) {
+            const float* L0 = lowh + (size_t)lx.i0 * CMAX;
+            const float* L1 = lowh + (size_t)lx.i1 * CMAX;
+            // x-interpolated logits of the band's two rows (constant down the column)
+            float top[CMAX], bot[CMAX];
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
-                if (c >= C) continue;
-                float* q0 = wacc + ((size_t)(r * w + lx.i0) * 2) * CMAX + c;
-                float* q1 = wacc + ((size_t)(r * w + lx.i1) * 2) * CMAX + c;
-                atomicAdd(q0, lx.l0 * a0[r][c]);
-                atomicAdd(q1, lx.l1 * a0[r][c]);
-                if (lg2) {
-                    atomicAdd(q0 + CMAX, lx.l0 * a1[r][c]);
-                    atomicAdd(q1 + CMAX, lx.l1 * a1[r][c]);
-                }
+                top[c] = lx.l0 * L0[c] + lx.l1 * L1[c];
+                bot[c] = lx.l0 * L0[w * CMAX + c] + lx.l1 * L1[w * CMAX + c];
             }
+            auto fetch = [&](int Y, Px& px) {
+                const size_t p = (size_t)b * plane + (size_t)Y * W + X;
+                px.lab = label[p];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (c < C) px.q[c] = soft[((size_t)b * C + c) * plane + (size_t)Y * W + X];
+                }
+                px.pw = pixw ? pixw[p] : 1.0f;
+            };
+            Px cur, nxt;
+            if (ya <= yb) fetch(ya, cur);
+            for (int Y = ya; Y <= yb; ++Y) {
+                if (Y < yb) fetch(Y + 1, nxt);                            // next row's loads fly during this row's math
+                const Lerp ly = lerp_ac(Y, h, sy);
+                const int64_t lab64 = cur.lab;
+                const bool lab_ok = (lab64 != ignore) && lab64 >= 0 && lab64 < C;
+                const int lab = lab_ok ? (int)lab64 : -1;
+                float pw = 1.0f;      // per-pixel coefficient on (softmax - onehot)
+                if (MODE == 1) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c)
+                        if (c < C) { const float q = cur.q[c]; u += -q * fast_log(q); }
+                    const bool gate = !(u > ut);                          // ce[u > t] = 0
+                    pw = gate ? uvem_weight_dev(u, um, ut, inv_gamma) : 0.f;
+                    if ((u <= ut) && lab64 != ignore) valid += 1.f;
+                }
+                pw *= cur.pw;
+                if (!lab_ok) pw = 0.f;                                    // ignore_index: zero loss and gradient
+                float v[CMAX], ce;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) v[c] = ly.l0 * top[c] + ly.l1 * bot[c];
+                softmax_ce<CMAX>(v, C, lab, ce);
+                loss += pw * ce;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) { const float g = pw * (v[c] - (c == lab ? 1.f : 0.f)); a0[c] += ly.l0 * g; a1[c] += ly.l1 * g; }
+                cur = nxt;
+            }
+        }
+        // ---- this pass's columns -> the band image, without atomics ----
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) {
+            colAh[(size_t)c * LOSS_CPAD + ctid] = a0[c];
+            colAh[(size_t)(CMAX + c) * LOSS_CPAD + ctid] = a1[c];
+        }
+        if (hd == 0) colL1[ctid] = lx.l1;
+        // first column of every logit cell inside this pass (cstart[w] = the pass's end): one thread per cell
+        for (int i = tid; i <= w; i += nthr) cstart[i] = loss_first_col(i, w, sx, Xb, min(Xb + LOSS_COLS, W));
+        __syncthreads();
+        for (int o = ctid; o < nout; o += LOSS_COLS) {
+            const int c = o % CMAX, x = (o / CMAX) % w, r = o / (CMAX * w);
+            if (c < C) {
+                const float* A = colAh + (size_t)(r * CMAX + c) * LOSS_CPAD - Xb;
+                const float* L = colL1 - Xb;
+                const int lo = cstart[x], hi = cstart[x + 1], lp = x > 0 ? cstart[x - 1] : lo;
+                const bool last = x == w - 1;                             // last cell: i1 = i0, both x weights land here (l0 + l1)
+                float t = 0.f;
+                // columns of cell x - 1 (their right neighbour is x, weight l1), then the cell's own columns (weight l0): ascending
+                // column order in chunks of 8 with the tail predicated off, so that a chunk's 16 LDS reads are in flight together
+                for (int X0 = lp; X0 < lo; X0 += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int X2 = min(X0 + j, lo - 1);
+                        const float wgt = (X0 + j < lo) ? L[X2] : 0.f;
+                        t = fmaf(wgt, A[X2], t);
+                    }
+                }
+                for (int X0 = lo; X0 < hi; X0 += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int X2 = min(X0 + j, hi - 1);
+                        const float l1 = L[X2];
+                        const float wgt = (X0 + j < hi) ? (last ? (1.f - l1) + l1 : 1.f - l1) : 0.f;
+                        t = fmaf(wgt, A[X2], t);
+                    }
+                }
+                imgh[o] += t;
+            }
+        }
+        __syncthreads();
     }
-    __shared__ float red[LOSS_WAVES][3];
+    __shared__ float red[2][LOSS_WAVES][2];
     {
-        const float a = wave_sum(loss1), d = wave_sum(loss2), e = wave_sum(valid);
-        if (lane == 0) { red[wave][0] = a; red[wave][1] = d; red[wave][2] = e; }
+        const float a = wave_sum(loss), e = wave_sum(valid);
+        if (lane == 0) { red[hd][wave][0] = a; red[hd][wave][1] = e; }
     }
     __syncthreads();
     float* out = band_grad + (size_t)blockIdx.x * 4 * w * CMAX;       // [2 rows][w][2 heads][CMAX]
-    for (int i = tid; i < 4 * w * CMAX; i += LOSS_THREADS) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < LOSS_WAVES; ++k) t += acc[(size_t)k * 4 * w * CMAX + i];      // fixed order
-        out[i] = t;
+    for (int i = tid; i < 4 * w * CMAX; i += nthr) {
+        const int c = i % CMAX, hh = (i / CMAX) & 1, x = (i / (2 * CMAX)) % w, r = i / (2 * CMAX * w);
+        out[i] = hh < nheads ? img[(size_t)hh * nout + ((size_t)r * w + x) * CMAX + c] : 0.f;
     }
-    if (tid < 3) {
+    if (tid < 3) {                                                    // loss of head 0, loss of head 1, valid count (head 0's threads)
+        const int hh = tid == 1 ? 1 : 0, f = tid == 2 ? 1 : 0;
         float t = 0.f;
+        if (hh < nheads) {
 #pragma unroll
-        for (int k = 0; k < LOSS_WAVES; ++k) t += red[k][tid];
+            for (int k = 0; k < LOSS_WAVES; ++k) t += red[hh][k][f];
+        }
         partial[(size_t)blockIdx.x * 4 + tid] = t;
     }
 }
@@ -282,15 +337,15 @@ static void loss_launch(const float* l1, const float* l2, const int64_t* label, 
     float* band_grad = ws;
     float* partial = ws + (size_t)bands * 4 * w * CMAX;
     float* inv_valid = partial + (size_t)bands * 4;
-    const size_t lds = (size_t)(4 + 4 * LOSS_WAVES) * w * CMAX * sizeof(float);
+    const size_t lds = loss_lds_floats(w, CMAX, nheads) * sizeof(float);
     if (C == CMAX) {
         auto k = loss_band_kernel<CMAX, MODE, true>;
         if (!uem_allow_lds((const void*)k, lds)) return;
-        k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
+        k<<<bands, LOSS_COLS * nheads, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
     } else {
         auto k = loss_band_kernel<CMAX, MODE, false>;
         if (!uem_allow_lds((const void*)k, lds)) return;
-        k<<<bands, LOSS_THREADS, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
+        k<<<bands, LOSS_COLS * nheads, lds, st>>>(l1, l2, label, soft, pixw, band_grad, partial, C, h, w, H, W, m, t, inv_gamma, ignore);
     }
     loss_finalize_kernel<<<1, 256, 0, st>>>(partial, bands, MODE, nheads, ce_denominator, loss_out, MODE ? inv_valid : nullptr);
     const int64_t n = (int64_t)B * h * w * C;
@@ -305,7 +360,7 @@ extern "C" int uem_ce_upsampled(const float* logits1, const float* logits2, cons
     UEM_REQUIRE(logits1 && label && loss_out && dlogits1 && workspace, "ce_upsampled: null pointer");
     UEM_REQUIRE(!logits2 || dlogits2, "ce_upsampled: dlogits2 required with logits2");
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w, "ce_upsampled: bad shape");
-    UEM_REQUIRE((size_t)(4 + 4 * LOSS_WAVES) * w * 16 * sizeof(float) <= 160 * 1024, "ce_upsampled: low-resolution width %d too large", w);
+    UEM_REQUIRE(loss_lds_floats(w, loss_cmax(C), logits2 ? 2 : 1) * sizeof(float) <= 150 * 1024, "ce_upsampled: low-resolution width %d too large", w);
     hipStream_t st = (hipStream_t)stream;
     const int nheads = logits2 ? 2 : 1;
     // mean over ALL pixels, ignored ones included in the denominator (balance.py:97-101)
@@ -326,7 +381,7 @@ extern "C" int uem_uvem_upsampled(const float* logits1, const float* logits2, co
     UEM_REQUIRE(!logits2 || dlogits2, "uvem_upsampled: dlogits2 required with logits2");
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w, "uvem_upsampled: bad shape");
     UEM_REQUIRE(gamma > 0.f && t > 0.f, "uvem_upsampled: bad hyper-parameters");
-    UEM_REQUIRE((size_t)(4 + 4 * LOSS_WAVES) * w * 16 * sizeof(float) <= 160 * 1024, "uvem_upsampled: low-resolution width %d too large", w);
+    UEM_REQUIRE(loss_lds_floats(w, loss_cmax(C), logits2 ? 2 : 1) * sizeof(float) <= 150 * 1024, "uvem_upsampled: low-resolution width %d too large", w);
     hipStream_t st = (hipStream_t)stream;
     const int nheads = logits2 ? 2 : 1;
     const float coef = loss_scale / (float)nheads;       // 1/(valid+eps) is applied by the combine pass, once the count is known

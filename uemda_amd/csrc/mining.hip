@@ -94,8 +94,136 @@ __global__ __launch_bounds__(256) void pearson_kernel(const float* __restrict__ 
     }
 }
 
+// Round 5: the row stays in REGISTERS, and the arithmetic is fused.  pearson_kernel above reads every feature row twice (the mean,
+// then the centred sums) and, built like the rest of the library with -ffp-contract=off, spends ~2000 VALU instructions per pair of
+// rows: every a*b + c is a multiply and an add, the C run-time guard keeps 8 classes' worth of code alive, 24 IEEE divisions close
+// each pair -- 33 M wave-instructions per launch at B = 32 = 128 us of issue on 1024 SIMDs: it was VALU-bound (99-110 us), not
+// bandwidth-bound, which is why keeping the rows in registers alone changed nothing (101 us).  Here: a lane keeps its KV float4 of
+// each of the wave's two rows (k = 256 * KV floats: 2048 -> 32 VGPRs per row; the feature map is fetched once), the dots and the
+// centred squares are explicit fmaf chains, the class count is a template argument (6, 7; 0 = run time), the wave sums run on the DPP
+// path, and the two divisions per output are one hoisted reciprocal and one v_rcp_f32.  ~800 instructions per pair of rows.
+// The prototype centring (proto_center_kernel: a six-block launch of 19 us in front of every call) moves into the block's prologue:
+// wave w centres classes w, w + 4, ... straight into the LDS image.
+template <int CMAX, int CEX, bool INVERT, int KV>
+__global__ __launch_bounds__(256) void pearson_rows_kernel(const float* __restrict__ feat, const float* __restrict__ protos,
+                                                           float* __restrict__ out, int n, int C_) {
+    constexpr int k = 256 * KV;
+    const int C = CEX > 0 ? CEX : C_;
+    extern __shared__ __attribute__((aligned(16))) float pc[];   // [C][k]
+    __shared__ float pstd_s[CMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float eps = 1e-7f;
+    const float inv_k = 1.0f / (float)k, inv_km1 = 1.0f / (float)(k - 1), inv_km1e = 1.0f / ((float)(k - 1) + eps);
+    // the wave's first pair of rows is requested before anything else: the loads fly under the prologue
+    float4 a[KV], b[KV];
+    int r0 = (blockIdx.x * 4 + wave) * 2;
+    auto request = [&](int r) {
+        if (r < n) {
+            const float4* x0 = reinterpret_cast<const float4*>(feat + (size_t)r * k) + lane;
+            const float4* x1 = reinterpret_cast<const float4*>(feat + (size_t)((r + 1) < n ? r + 1 : r) * k) + lane;
+#pragma unroll
+            for (int i = 0; i < KV; ++i) { a[i] = x0[i * 64]; b[i] = x1[i * 64]; }
+        }
+    };
+    request(r0);
+    // prologue: wave w centres classes w, w + 4, ... into the LDS image (16-byte loads, the whole prototype in flight at once)
+    for (int c = wave; c < C; c += 4) {
+        const float4* p = reinterpret_cast<const float4*>(protos + (size_t)c * k) + lane;
+        float4 v[KV];
+#pragma unroll
+        for (int i = 0; i < KV; ++i) v[i] = p[i * 64];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum_dpp(s) * inv_k;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            ss = fmaf(v[i].x, v[i].x, fmaf(v[i].y, v[i].y, fmaf(v[i].z, v[i].z, fmaf(v[i].w, v[i].w, ss))));
+            *reinterpret_cast<float4*>(pc + (size_t)c * k + i * 256 + lane * 4) = v[i];
+        }
+        ss = wave_sum_dpp(ss);
+        if (lane == 0) pstd_s[c] = sqrtf(ss * inv_km1);
+    }
+    __syncthreads();
+    for (; r0 < n; r0 += gridDim.x * 8) {
+        const bool has1 = (r0 + 1) < n;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            s0 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+            s1 += (b[i].x + b[i].y) + (b[i].z + b[i].w);
+        }
+        const float m0 = wave_sum_dpp(s0) * inv_k, m1 = wave_sum_dpp(s1) * inv_k;
+        float ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {                             // centred in place
+            a[i].x -= m0; a[i].y -= m0; a[i].z -= m0; a[i].w -= m0;
+            b[i].x -= m1; b[i].y -= m1; b[i].z -= m1; b[i].w -= m1;
+            ss0 = fmaf(a[i].x, a[i].x, fmaf(a[i].y, a[i].y, fmaf(a[i].z, a[i].z, fmaf(a[i].w, a[i].w, ss0))));
+            ss1 = fmaf(b[i].x, b[i].x, fmaf(b[i].y, b[i].y, fmaf(b[i].z, b[i].z, fmaf(b[i].w, b[i].w, ss1))));
+        }
+        ss0 = wave_sum_dpp(ss0);
+        ss1 = wave_sum_dpp(ss1);
+        const float std0 = sqrtf(ss0 * inv_km1), std1 = sqrtf(ss1 * inv_km1);
+        float o0 = 0.f, o1 = 0.f;                                  // lane c keeps class c's two results: one store per row
+        // class by class, as a REAL loop: one prototype's KV fragments against both rows.  Unrolled (either loop order) the scheduler
+        // hoists all 6 x KV prototype reads to the top -- nothing orders an LDS read -- and the kernel comes out at 243-284 registers.
+#pragma unroll 1
+        for (int c = 0; c < C; ++c) {
+            {
+                float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < KV; ++i) {
+                    const float4 q = *reinterpret_cast<const float4*>(pc + (size_t)c * k + i * 256 + lane * 4);
+                    d0 = fmaf(a[i].x, q.x, fmaf(a[i].y, q.y, fmaf(a[i].z, q.z, fmaf(a[i].w, q.w, d0))));
+                    d1 = fmaf(b[i].x, q.x, fmaf(b[i].y, q.y, fmaf(b[i].z, q.z, fmaf(b[i].w, q.w, d1))));
+                }
+                const float c0 = wave_sum_dpp(d0), c1 = wave_sum_dpp(d1);
+                const float ps = pstd_s[c];
+                const float dist0 = (1.0f - (c0 * inv_km1e) * fast_rcp(std0 * ps + eps)) * 0.5f;
+                const float dist1 = (1.0f - (c1 * inv_km1e) * fast_rcp(std1 * ps + eps)) * 0.5f;
+                if (lane == c) { o0 = INVERT ? fast_rcp(dist0) : dist0; o1 = INVERT ? fast_rcp(dist1) : dist1; }
+            }
+        }
+        request(r0 + gridDim.x * 8);                                // the next pair's rows fly under this pair's stores and the loop edge
+        if (lane < C) {
+            out[(size_t)r0 * C + lane] = o0;
+            if (has1) out[(size_t)(r0 + 1) * C + lane] = o1;
+        }
+    }
+}
+
+template <int KV>
+static bool pearson_rows_launch(const float* a, const float* b, float* out, int n, int m, bool invert, hipStream_t st) {
+    const size_t lds = (size_t)m * 256 * KV * sizeof(float);
+    int grid = (int)uem_cdiv(n, 8);
+    if (grid > 256 * 3) grid = 256 * 3;
+#define LAUNCH_PR(CE, INV)                                                                               \
+    do {                                                                                                 \
+        if (!uem_allow_lds((const void*)pearson_rows_kernel<8, CE, INV, KV>, lds)) return false;         \
+        pearson_rows_kernel<8, CE, INV, KV><<<grid, 256, lds, st>>>(a, b, out, n, m);                    \
+    } while (0)
+    if (m == 6) { if (invert) LAUNCH_PR(6, true); else LAUNCH_PR(6, false); }
+    else if (m == 7) { if (invert) LAUNCH_PR(7, true); else LAUNCH_PR(7, false); }
+    else { if (invert) LAUNCH_PR(0, true); else LAUNCH_PR(0, false); }
+#undef LAUNCH_PR
+    return true;
+}
+
 static int pearson_launch(const float* a, const float* b, float* out, float* scratch, int n, int m, int k,
                           bool invert, hipStream_t st) {
+    // feature widths of the encoder stages (k = 256 * KV) with up to 8 classes: one pass over the features, rows in registers
+    static const bool rows_on = !(getenv("UEM_PEARSON_ROWS") && atoi(getenv("UEM_PEARSON_ROWS")) == 0);
+    if (rows_on && m <= 8 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        bool done = false;
+        if (k == 2048) done = pearson_rows_launch<8>(a, b, out, n, m, invert, st);
+        else if (k == 1024) done = pearson_rows_launch<4>(a, b, out, n, m, invert, st);
+        else if (k == 512) done = pearson_rows_launch<2>(a, b, out, n, m, invert, st);
+        else if (k == 256) done = pearson_rows_launch<1>(a, b, out, n, m, invert, st);
+        if (done) return uem_check_launch("pearson");
+    }
     // scratch: [m*k] centred b + [m] std
     float* pc = scratch;
     float* pstd = scratch + (size_t)m * k;
@@ -274,20 +402,22 @@ extern "C" int uem_segment_max_planar(const float* soft, const int64_t* sup, uin
 // ================================================================================================
 template <int CMAX>
 __device__ __forceinline__ void softmax_maxnorm(float (&v)[CMAX], int C, float inv_temp) {
-    // v <- softmax(v * inv_temp) / (max + 1e-7)     (alignment.py:221-222, 230-235, 252-253); one reciprocal per division row
+    // v <- softmax(v * inv_temp) / (max + 1e-7)     (alignment.py:221-222, 230-235, 252-253).  Round 5, fewer instructions (the
+    // refinement kernel is VALU-bound: 131 K wave-pixels x ~700 instructions x 4 cycles on 1024 SIMDs IS its 140 us): temperature and
+    // log2(e) are one factor (the exponent is exp2(t - max t), t = v * inv_temp * log2 e); the largest exponential is exp2(0) = 1
+    // exactly, so the softmax's maximum is 1 / sum and "softmax / (max + 1e-7)" is e * (rs * rcp(rs + 1e-7)), rs = 1 / sum: no second
+    // maximum, one multiply per class.
+    const float sc = inv_temp * 1.44269504088896340736f;
     float m = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= inv_temp; m = fmaxf(m, v[c]); }
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= sc; m = fmaxf(m, v[c]); }
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = fast_exp(v[c] - m); s += v[c]; }
+    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = __builtin_amdgcn_exp2f(v[c] - m); s += v[c]; }
     const float rs = fast_rcp(s);
-    float pm = 0.f;
+    const float kf = rs * fast_rcp(rs + 1e-7f);
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = v[c] * rs; pm = fmaxf(pm, v[c]); }
-    const float rd = fast_rcp(pm + 1e-7f);
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] * rd;
+    for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] * kf;
 }
 
 // One block = 256 consecutive pixels of ONE image row, so the vertical lerp is block-uniform and the strip only touches
@@ -303,39 +433,75 @@ __device__ __forceinline__ void xlerp_lds(const float* __restrict__ row, int C, 
 #pragma unroll
     for (int q = 0; q < CMAX / 4; ++q) {
         const float4 x0 = a0[q], x1 = a1[q];
-        v[4 * q + 0] = lx.l0 * x0.x + lx.l1 * x1.x; v[4 * q + 1] = lx.l0 * x0.y + lx.l1 * x1.y;
-        v[4 * q + 2] = lx.l0 * x0.z + lx.l1 * x1.z; v[4 * q + 3] = lx.l0 * x0.w + lx.l1 * x1.w;
+        v[4 * q + 0] = fmaf(lx.l1, x1.x, lx.l0 * x0.x); v[4 * q + 1] = fmaf(lx.l1, x1.y, lx.l0 * x0.y);
+        v[4 * q + 2] = fmaf(lx.l1, x1.z, lx.l0 * x0.z); v[4 * q + 3] = fmaf(lx.l1, x1.w, lx.l0 * x0.w);
     }
 }
 
 // CEX: the class count when it is one of the two the reference's datasets have (6: ISPRS, 7: LoveDA) -- every `c < C` guard of the
 // unrolled per-class loops then folds at compile time (with a run-time C they were 266 v_cndmask + their compares per pixel, a
 // quarter of the kernel's instructions); 0 = any C <= CMAX.
+//
+// Round 5.  (a) The superpixel view softmax(seg_max / T) / (max + 1e-7) is a function of the SEGMENT, not of the pixel: it is computed
+// once per table entry by segment_weight_kernel (B * S entries, ~4 us) and the pixel gathers 8 finished floats (two 16-byte loads)
+// instead of 6 keys + 6 exp + 2 rcp + ~50 other instructions -- same arithmetic, same values.  (b) A block owns LR_ROWS image rows of
+// its 256-pixel strip instead of one: the kernel was latency-bound, not bandwidth- or VALU-bound (counters of round 4: VALU active
+// 17 % of the wave cycles, 41 % of them parked on memory; 32768 blocks of three dependent round trips -- id, then the segment gather,
+// then the stores -- around ~700 instructions), so every thread now has its LR_ROWS pixels' ids and soft labels in flight at once,
+// then all their segment gathers, and the block's launch, barrier and per-(image, class) maximum are paid once per LR_ROWS rows.
+#define LR_ROWS 4
+template <int CMAX, int CEX>
+__global__ __launch_bounds__(256) void segment_weight_kernel(const uint32_t* __restrict__ seg, float* __restrict__ segw, int64_t nseg,
+                                                             int C_, float inv_temp) {
+    const int C = CEX > 0 ? CEX : C_;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nseg) return;
+    const uint32_t* sg = seg + (size_t)i * C;
+    float v[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        const uint32_t kv = c < C ? sg[c] : 0u;
+        v[c] = kv ? key2f(kv) : 0.f;
+    }
+    softmax_maxnorm<CMAX>(v, C, inv_temp);
+    float4* dst = reinterpret_cast<float4*>(segw + (size_t)i * CMAX);
+#pragma unroll
+    for (int q = 0; q < CMAX / 4; ++q)
+        dst[q] = make_float4(4 * q + 0 < C ? v[4 * q + 0] : 0.f, 4 * q + 1 < C ? v[4 * q + 1] : 0.f, 4 * q + 2 < C ? v[4 * q + 2] : 0.f,
+                             4 * q + 3 < C ? v[4 * q + 3] : 0.f);
+}
+
 template <int CMAX, int CEX>
 __global__ __launch_bounds__(256) void label_refine_kernel(
     const float* __restrict__ soft, const int64_t* __restrict__ sup, const float* __restrict__ sim,
-    const float* __restrict__ lg1, const float* __restrict__ lg2, const uint32_t* __restrict__ seg,
+    const float* __restrict__ lg1, const float* __restrict__ lg2, const float* __restrict__ segw,
     const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C_, int h,
     int w, int H, int W, int S, float inv_temp, int mode, int ncell) {
     const int C = CEX > 0 ? CEX : C_;
-    extern __shared__ __attribute__((aligned(16))) float lowres[];       // [3 maps][ncell][CMAX], interpolated in y
-    const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * 256;
+    extern __shared__ __attribute__((aligned(16))) float lowres[];       // [LR_ROWS][3 maps][ncell][CMAX], interpolated in y
+    const int b = blockIdx.z, Y0 = blockIdx.y * LR_ROWS, X0 = blockIdx.x * 256;
     const size_t plane = (size_t)H * W;
     const int X = X0 + threadIdx.x;
     const bool active = X < W;
-    const size_t p = (size_t)Y * W + X;
     const bool use_sup = mode == UEM_REFINE_ALL || mode == UEM_REFINE_S;
-    // ---- this pixel's operands: requested first, consumed last --------------------------------------------------------------
-    int64_t id = 0;
-    float sv[CMAX];
-    if (active) {
-        if (use_sup) id = sup[(size_t)b * plane + p];
+    // ---- this thread's pixels (one per row of the block): operands requested first, consumed last ---------------------------
+    int64_t id[LR_ROWS];
+    float sv[LR_ROWS][CMAX];
+    bool rowok[LR_ROWS];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) sv[c] = c < C ? soft[((size_t)b * C + c) * plane + p] : 0.f;
+    for (int r = 0; r < LR_ROWS; ++r) {
+        rowok[r] = active && (Y0 + r) < H;
+        id[r] = 0;
+        if (rowok[r] && use_sup) id[r] = sup[(size_t)b * plane + (size_t)(Y0 + r) * W + X];
     }
-    // ---- the strip's low-resolution cells, interpolated between the two source rows -----------------------------------------
+#pragma unroll
+    for (int r = 0; r < LR_ROWS; ++r) {
+        const size_t p = (size_t)(Y0 + r) * W + X;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) sv[r][c] = (rowok[r] && c < C) ? soft[((size_t)b * C + c) * plane + p] : 0.f;
+    }
+    // ---- the strip's low-resolution cells, interpolated between the two source rows of each image row ------------------------
     const float sy = lerp_scale_ac(h, H), sx = lerp_scale_ac(w, W);
-    const Lerp ly = lerp_ac(Y, h, sy);
     const int c0 = lerp_ac(X0, w, sx).i0;                                // first cell of the strip
     const int Xl = min(X0 + 255, W - 1);
     const int c1 = lerp_ac(Xl, w, sx).i1;                                // last cell of the strip
@@ -343,47 +509,59 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     const int ncc = ncell * CMAX;                                        // CMAX is 8 or 16: cell / class by shift and mask
     {
         const float* maps[3] = {sim, lg1, lg2};
-        for (int i = threadIdx.x; i < ncc; i += 256) {
-            const int cell = i / CMAX, c = i % CMAX;
-            const bool in = cell < nc && c < C;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                float v = 0.f;
-                if (maps[m] != nullptr && in) {
-                    const float r0 = maps[m][(((size_t)b * h + ly.i0) * w + (c0 + cell)) * C + c];
-                    const float r1 = maps[m][(((size_t)b * h + ly.i1) * w + (c0 + cell)) * C + c];
-                    v = ly.l0 * r0 + ly.l1 * r1;
+        for (int r = 0; r < LR_ROWS; ++r) {
+            const Lerp ly = lerp_ac(min(Y0 + r, H - 1), h, sy);
+            for (int i = threadIdx.x; i < ncc; i += 256) {
+                const int cell = i / CMAX, c = i % CMAX;
+                const bool in = cell < nc && c < C;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    float v = 0.f;
+                    if (maps[m] != nullptr && in) {
+                        const float r0 = maps[m][(((size_t)b * h + ly.i0) * w + (c0 + cell)) * C + c];
+                        const float r1 = maps[m][(((size_t)b * h + ly.i1) * w + (c0 + cell)) * C + c];
+                        v = fmaf(ly.l1, r1, ly.l0 * r0);
+                    }
+                    lowres[(r * 3 + m) * ncc + i] = v;
                 }
-                lowres[m * ncc + i] = v;
             }
         }
     }
-    // ---- the superpixel's class maxima: the gather can leave as soon as the id is here -------------------------------------
-    bool inrange = false, ignored = true;
-    uint32_t sk[CMAX];
+    // ---- the superpixels' finished class weights: the gathers can leave as soon as the ids are here -------------------------
+    bool ignored[LR_ROWS];
+    float sw[LR_ROWS][CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) sk[c] = 0u;
-    if (active && use_sup) {
-        inrange = id >= 0 && id < (int64_t)S;
-        // an id outside the table (reported by uem_segment_max_planar, the host raises) never borrows another
-        // segment's maxima: the pixel keeps its weight, as an ignored one does
-        ignored = (id == *ignore_id) || !inrange;
-        if (inrange) {
-            const uint32_t* sg = seg + ((size_t)b * S + (size_t)id) * C;
+    for (int r = 0; r < LR_ROWS; ++r) {
+        ignored[r] = true;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) if (c < C) sk[c] = sg[c];
+        for (int c = 0; c < CMAX; ++c) sw[r][c] = 1.0f;
+        if (rowok[r] && use_sup) {
+            const bool inrange = id[r] >= 0 && id[r] < (int64_t)S;
+            // an id outside the table (reported by uem_segment_max_planar, the host raises) never borrows another
+            // segment's maxima: the pixel keeps its weight, as an ignored one does
+            ignored[r] = (id[r] == *ignore_id) || !inrange;
+            if (inrange) {
+                const float4* sg = reinterpret_cast<const float4*>(segw + ((size_t)b * S + (size_t)id[r]) * CMAX);
+#pragma unroll
+                for (int q = 0; q < CMAX / 4; ++q) {
+                    const float4 t = sg[q];
+                    sw[r][4 * q + 0] = t.x; sw[r][4 * q + 1] = t.y; sw[r][4 * q + 2] = t.z; sw[r][4 * q + 3] = t.w;
+                }
+            }
         }
     }
     __syncthreads();
-    const float* s_sim = lowres;
-    const float* s_l1 = lowres + ncc;
-    const float* s_l2 = lowres + 2 * ncc;
-
-    float o[CMAX];
+    float omax[CMAX];
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) o[c] = 0.f;
-    if (active) {
-        const Lerp lx = lerp_ac(X, w, sx);
+    for (int c = 0; c < CMAX; ++c) omax[c] = 0.f;
+    const Lerp lx = lerp_ac(active ? X : 0, w, sx);
+#pragma unroll
+    for (int r = 0; r < LR_ROWS; ++r) {
+        if (!rowok[r]) continue;
+        const float* s_sim = lowres + (r * 3 + 0) * ncc;
+        const float* s_l1 = lowres + (r * 3 + 1) * ncc;
+        const float* s_l2 = lowres + (r * 3 + 2) * ncc;
         float wgt[CMAX];
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) wgt[c] = 0.f;
@@ -401,16 +579,17 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
                 float u[CMAX];
                 xlerp_lds<CMAX>(s_l2, C, c0, lx, u);
                 // 0.5 * (softmax(x1/T) + softmax(x2/T)), then max-normalise
+                const float sc = inv_temp * 1.44269504088896340736f;
                 float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= inv_temp; u[c] *= inv_temp; m1 = fmaxf(m1, v[c]); m2 = fmaxf(m2, u[c]); }
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] *= sc; u[c] *= sc; m1 = fmaxf(m1, v[c]); m2 = fmaxf(m2, u[c]); }
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = fast_exp(v[c] - m1); u[c] = fast_exp(u[c] - m2); s1 += v[c]; s2 += u[c]; }
-                const float r1 = fast_rcp(s1), r2 = fast_rcp(s2);
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = __builtin_amdgcn_exp2f(v[c] - m1); u[c] = __builtin_amdgcn_exp2f(u[c] - m2); s1 += v[c]; s2 += u[c]; }
+                const float r1 = fast_rcp(s1) * 0.5f, r2 = fast_rcp(s2) * 0.5f;
                 float pm = 0.f;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = (v[c] * r1 + u[c] * r2) * 0.5f; pm = fmaxf(pm, v[c]); }
+                for (int c = 0; c < CMAX; ++c) if (c < C) { v[c] = fmaf(v[c], r1, u[c] * r2); pm = fmaxf(pm, v[c]); }
                 const float rd = fast_rcp(pm + 1e-7f);
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) if (c < C) v[c] = v[c] * rd;
@@ -420,25 +599,23 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) wgt[c] += v[c];
         }
-        if (use_sup) {                                                 // superpixel view
-            float v[CMAX];
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c) v[c] = (c < C && sk[c]) ? key2f(sk[c]) : 0.f;
-            softmax_maxnorm<CMAX>(v, C, inv_temp);
+        if (use_sup) {                                                 // superpixel view (weights finished per segment)
             if (mode == UEM_REFINE_ALL) {
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) wgt[c] = ignored ? wgt[c] : wgt[c] * v[c];
+                for (int c = 0; c < CMAX; ++c) wgt[c] = ignored[r] ? wgt[c] : wgt[c] * sw[r][c];
             } else {
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) wgt[c] = ignored ? 1.0f : v[c];
+                for (int c = 0; c < CMAX; ++c) wgt[c] = ignored[r] ? 1.0f : sw[r][c];
             }
         }
+        float o[CMAX];
         float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = wgt[c] * sv[c]; sum += o[c]; }
+        for (int c = 0; c < CMAX; ++c) { o[c] = 0.f; if (c < C) { o[c] = wgt[c] * sv[r][c]; sum += o[c]; } }
         const float rd = fast_rcp(sum + 1e-7f);
+        const size_t p = (size_t)(Y0 + r) * W + X;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] * rd; out[((size_t)b * C + c) * plane + p] = o[c]; }
+        for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] * rd; out[((size_t)b * C + c) * plane + p] = o[c]; omax[c] = fmaxf(omax[c], o[c]); }
     }
     // per-(b,c) maximum for the selection pass: block maximum -> blockmax[b][block][c]; a second tiny kernel
     // reduces the blocks.  (One atomicMax per wave on the B*C result words serialised 0.8 M atomics on 192
@@ -446,7 +623,7 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     __shared__ float wmax[4][CMAX];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c) {
-        const float m = c < C ? wave_max(o[c]) : 0.f;
+        const float m = c < C ? wave_max_dpp(omax[c]) : 0.f;
         if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6][c] = m;
     }
     __syncthreads();
@@ -470,8 +647,10 @@ __global__ __launch_bounds__(256) void blockmax_reduce_kernel(const float* __res
     if (threadIdx.x == 0) plane_max[b * C + c] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
-extern "C" int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W) {
-    return (int64_t)B * uem_cdiv(W, 256) * H * (C <= 8 ? 8 : 16);
+extern "C" int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W, int S) {
+    // per-block maxima [B][strips][row groups][cmax] + the per-segment class weights [B][S][cmax]
+    const int cmax = C <= 8 ? 8 : 16;
+    return (int64_t)B * uem_cdiv(W, 256) * uem_cdiv(H, LR_ROWS) * cmax + (int64_t)B * (S > 0 ? S : 0) * cmax;
 }
 extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
                                 const float* logits2, const uint32_t* seg_keys, const int64_t* ignore_id,
@@ -479,30 +658,36 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
                                 int H, int W, int S, float temp, int mode, void* stream) {
     UEM_REQUIRE(soft && soft_out && plane_max && workspace, "label_refine: null pointer");
     UEM_REQUIRE(mode >= 0 && mode <= 3, "label_refine: bad mode %d", mode);
-    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w && H <= 65535, "label_refine: bad shape");
+    UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w && H <= 65535 * LR_ROWS, "label_refine: bad shape");
     UEM_REQUIRE(temp > 0.f, "label_refine: temp must be > 0");
+    const bool use_sup = mode == UEM_REFINE_ALL || mode == UEM_REFINE_S;
     if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_P) UEM_REQUIRE(sim, "label_refine: sim required");
     if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) UEM_REQUIRE(logits1, "label_refine: logits required");
-    if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_S) UEM_REQUIRE(sup && seg_keys && ignore_id && S > 0, "label_refine: superpixel inputs required");
+    if (use_sup) UEM_REQUIRE(sup && seg_keys && ignore_id && S > 0, "label_refine: superpixel inputs required");
     // cells touched by a 256-pixel strip: floor(255*(w-1)/(W-1)) + 3 covers every alignment
     const int ncell = (W > 1 ? (int)((255LL * (w - 1)) / (W - 1)) : 0) + 4;      // +1 slack for float rounding
     const int cmax = C <= 8 ? 8 : 16;
-    const size_t lds = (size_t)3 * ncell * cmax * sizeof(float);
+    const size_t lds = (size_t)LR_ROWS * 3 * ncell * cmax * sizeof(float);
     UEM_REQUIRE(lds <= 150 * 1024, "label_refine: low-resolution strip does not fit LDS");
-    dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)H, (unsigned)B);
+    dim3 grid((unsigned)uem_cdiv(W, 256), (unsigned)uem_cdiv(H, LR_ROWS), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
+    float* blockmax = workspace;
+    float* segw = workspace + (size_t)B * grid.x * grid.y * cmax;
+    const int64_t nseg = (int64_t)B * S;
 #define LAUNCH_LR(CM, CE)                                                                                                        \
     do {                                                                                                                         \
+        if (use_sup)                                                                                                             \
+            segment_weight_kernel<CM, CE><<<(unsigned)uem_cdiv(nseg, 256), 256, 0, st>>>(seg_keys, segw, nseg, C, 1.0f / temp);    \
         if (uem_allow_lds((const void*)label_refine_kernel<CM, CE>, lds))                                                         \
-            label_refine_kernel<CM, CE><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out, \
-                                                                workspace, C, h, w, H, W, S, 1.0f / temp, mode, ncell);         \
+            label_refine_kernel<CM, CE><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, segw, ignore_id, soft_out,     \
+                                                                blockmax, C, h, w, H, W, S, 1.0f / temp, mode, ncell);          \
     } while (0)
     if (C == 6) LAUNCH_LR(8, 6);
     else if (C == 7) LAUNCH_LR(8, 7);
     else if (C <= 8) LAUNCH_LR(8, 0);
     else LAUNCH_LR(16, 0);
 #undef LAUNCH_LR
-    blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(workspace, plane_max, (int)(grid.x * grid.y), C, cmax);
+    blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(blockmax, plane_max, (int)(grid.x * grid.y), C, cmax);
     return uem_check_launch("label_refine");
 }
 

@@ -133,7 +133,7 @@ class Aligner:
             self._report_superpixel_range(oor, S)
         out = torch.empty_like(soft)
         plane_max = torch.empty((B, C), device=dev, dtype=torch.int32)
-        ws = torch.empty(_lib.load().uem_label_refine_workspace_floats(B, C, H, W), device=dev, dtype=torch.float32)
+        ws = torch.empty(_lib.load().uem_label_refine_workspace_floats(B, C, H, W, S if seg is not None else 0), device=dev, dtype=torch.float32)
         call("uem_label_refine", ptr(soft), ptr(sup), ptr(sim), ptr(lg1), ptr(lg2), ptr(seg), ptr(ign), ptr(out),
              ptr(plane_max), ptr(ws), B, C, h, w, H, W, S, float(temp), _MODES[mode], stream())
         self._last_plane_max = plane_max
