@@ -96,6 +96,12 @@ int uem_conv2d_wgrad(const float* x, const float* dy, const float* in_scale, con
 int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw8, int N, int H, int W, void* stream);
 /* the same with an operand precision (0 or one UEM_CONV_PREC_* flag) */
 int uem_conv2d_stem_wgrad_prec(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream);
+/* bf16 storage (BASELINE config 5; round 5): the stem's conv output z -- 64 channels at half resolution, the network's largest
+ * tensor -- is a bf16 tensor: rounded (RNE) at the conv's store with the BatchNorm tile statistics taken over the rounded values,
+ * read as bf16 by the pool and by both passes of the BatchNorm backward, whose dz is bf16 too and is widened at the weight
+ * gradient's load.  bf16 operands on the bf16 matrix cores, fp32 accumulation.            uemda/_resnets.py:149-153,205-212 */
+int uem_conv2d_stem_fwd_stats_bf16(const float* x4, const float* w8, uint16_t* y, int N, int H, int W, float* tile_stats, void* stream);
+int uem_conv2d_stem_wgrad_bf16(const float* x4, const uint16_t* dy, float* dw8, int N, int H, int W, void* stream);
 /* weight re-layouts (tiny): transposed copy for dgrad; stem pack / unpack-add                     */
 int uem_weight_transpose(const float* w /*[Cout][KH][KW][Cin]*/, float* wt /*[Cin][KH][KW][Cout]*/, int Cout,
                          int KH, int KW, int Cin, void* stream);
@@ -169,6 +175,13 @@ int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, const uint8_t* 
 int uem_bn_bwd_apply_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
                           const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N, int H,
                           int W, int C, int relu, float* dx, void* stream);
+/* the same two passes on bf16 tensors (x = the stem's bf16 z, dy_pool / dx bf16; sums, scale / shift and the arithmetic fp32) */
+int uem_bn_bwd_reduce_pool_bf16(const uint16_t* x, const uint16_t* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                const float* save_mean, const float* save_invstd, int N, int H, int W, int C, int relu, float* dgamma,
+                                float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream);
+int uem_bn_bwd_apply_pool_bf16(const uint16_t* x, const uint16_t* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                               const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N, int H,
+                               int W, int C, int relu, uint16_t* dx, void* stream);
 /* eval-mode / frozen-statistics backward: dx = dp * scale, dp = dy masked as in uem_bn_bwd_apply (relu 0 / 1 / UEM_RELU_BITS) */
 int uem_affine_act_bwd(const float* x, const float* dy, const float* ymask, const float* scale,
                        const float* shift, int64_t M, int C, int relu, float* dx, float* dres, void* stream);
@@ -180,12 +193,20 @@ int uem_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx /* argmax tap 0.
  * normalised map is never written; same first-max-wins argmax as uem_maxpool3x3s2_fwd on the materialised tensor          */
 int uem_maxpool3x3s2_affine_fwd(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, int N, int H,
                                 int W, int C, void* stream);
+int uem_maxpool3x3s2_affine_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y, uint8_t* idx, int N,
+                                     int H, int W, int C, void* stream);      /* bf16 z in, bf16 pooled map out (bf16 storage) */
 int uem_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx /* = */, int N, int H, int W, int C,
                          void* stream);
 int uem_instnorm_fwd(const float* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,
                      float eps, void* stream);
 int uem_instnorm_bwd(const float* y, const float* dy, const float* save_invstd, float* dx, int N, int HW,
                      int C, void* stream);
+/* the InstanceNorm at the end of the bf16-storage region: bf16 layer4 output in, fp32 features out (what the heads and the
+ * mining read); its backward writes the bf16 gradient -- no cast passes on either side.               Encoder.py:123,146-147 */
+int uem_instnorm_fwd_bf16(const uint16_t* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,
+                          float eps, void* stream);
+int uem_instnorm_bwd_bf16(const float* y, const float* dy, const float* save_invstd, uint16_t* dx, int N, int HW,
+                          int C, void* stream);
 /* ---- PPM head pieces: adaptive avg-pool + bilinear (align_corners=False) (Encoder.py:18,48-51) ------ */
 int uem_adaptive_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int S, void* stream);
 int uem_adaptive_avgpool_bwd(const float* dy, float* dx /* += */, int N, int H, int W, int C, int S, void* stream);

@@ -21,14 +21,18 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["rule", "persistent"])
+@pytest.fixture(params=["rule", "persistent", "big", "big-persistent"])
 def persist(request):
-    """the conv kernel's persistent-block form by its dispatch rule (>= 1024 full tiles), and forced onto every full-tile launch"""
+    """the conv kernel's persistent-block form by its dispatch rule (>= 1024 full tiles), and forced onto every full-tile launch;
+    "big": the 256-row tiles (eight waves, round 5) forced onto every launch whose row count is a multiple of 256 -- by rule only
+    launches with >= 256 such tiles take them, which none of these small cases has"""
     from uemda_amd import _lib
     lib = _lib.load()
-    lib.uemdbg_conv_bf16_persist(1 if request.param == "persistent" else -1)
+    lib.uemdbg_conv_bf16_persist(1 if request.param.endswith("persistent") else -1)
+    lib.uemdbg_conv_bf16_big(1 if request.param.startswith("big") else -1)
     yield request.param
     lib.uemdbg_conv_bf16_persist(-1)
+    lib.uemdbg_conv_bf16_big(-1)
 
 
 def _bf(t):
@@ -726,3 +730,64 @@ def test_bf16_storage_encoder_options(tag):
         # a moved bf16 rounding of dz is amplified on the way down like any other bf16 rounding (0.11 on dx through seven
         # blocks); the tensors behind the checkpoint boundaries carry it
         assert med < 2e-2 and rels[worst] < 0.2, (med, worst, rels[worst])
+
+
+def test_bf16_stem_and_instnorm_ends_of_the_bf16_region():
+    """Round 5: the two ends of the bf16 region in bf16.  (a) Stem with a bf16 conv output z: z = RNE(the fp32 stem conv on bf16
+    operands), BatchNorm statistics of the ROUNDED values (checked against torch on the widened z), pooled map and argmax taps equal
+    to the fp32 pool kernel on the widened z (bit for bit after rounding), backward (pooled BatchNorm backward reading bf16 z / bf16
+    pooled gradient, bf16 dz, weight gradient from the bf16 dz) against the fp32 kernels on the same widened tensors.  (b) The
+    InstanceNorm reading bf16 and its backward writing bf16: the fp32 kernels' arithmetic on the widened input, rounded once."""
+    from uemda_amd import ops, ops_bf16 as ob
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 2, 64, 64
+    x = torch.randn(N, 3, H, W, generator=g).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).cuda().contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(64).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(64, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(64, generator=g) * 0.2)
+    bn2 = torch.nn.BatchNorm2d(64).cuda().train()
+    bn2.load_state_dict(bn.state_dict())
+    x4 = ops.nchw3_to_nhwc4(x)
+    w8 = torch.empty((64, 7, 8, 4), device="cuda")
+    ops.call("uem_stem_pack_weight", ops.ptr(ops.weight_ohwi(w)), ops.ptr(w8), ops.stream())
+    assert ob.stem_ok(x.shape, bn)
+    z, st = ob.stem_conv_bn(x4, w8, bn)
+    bn3 = torch.nn.BatchNorm2d(64).cuda().train()
+    with ops.conv_precision("bf16"):
+        z32, _ = ops.stem_conv_bn(x4, ops.weight_ohwi(w), bn3, w8=w8)            # the fp32 tensor of the same bf16-operand conv
+    assert z.dtype == torch.bfloat16 and torch.equal(z, z32.to(torch.bfloat16))
+    zw = z.float()
+    st_ref = ops.bn_stats(zw, bn2.weight.detach(), bn2.bias.detach(), bn2.running_mean, bn2.running_var, True)
+    for a, b in ((st.mean, st_ref.mean), (st.invstd, st_ref.invstd), (st.scale, st_ref.scale), (st.shift, st_ref.shift),
+                 (bn.running_mean, bn2.running_mean), (bn.running_var, bn2.running_var)):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+    y, idx = ob.maxpool_affine_fwd(z, st, True)
+    y_ref, idx_ref = ops.maxpool_affine_fwd(zw, st, True)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, y_ref.to(torch.bfloat16)) and torch.equal(idx, idx_ref)
+    dy = (torch.randn(y.shape, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    gg, gb = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dz = ob.bn_backward_pooled(z, dy, idx, st, gg, gb)
+    gg2, gb2 = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dz_ref = ops.bn_backward_pooled(zw, dy.float(), idx, st, gg2, gb2)
+    torch.testing.assert_close(gg, gg2, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(gb, gb2, rtol=1e-5, atol=1e-4)
+    assert dz.dtype == torch.bfloat16
+    torch.testing.assert_close(dz.float(), dz_ref, rtol=2 ** -8, atol=1e-6)     # one bf16 rounding of the same fp32 value
+    dw = torch.zeros(64, 7, 7, 3, device="cuda")
+    ob.stem_wgrad(x4, dz, dw)
+    dw_ref = torch.zeros(64, 7, 7, 3, device="cuda")
+    with ops.conv_precision("bf16"):
+        ops.stem_wgrad(x4, dz.float(), dw_ref)
+    torch.testing.assert_close(dw, dw_ref, rtol=1e-4, atol=1e-4 * float(dw_ref.abs().max()))
+    # (b) InstanceNorm
+    xi = (torch.randn(2, 8, 8, 128, generator=g) * 2 + 0.5).cuda().to(torch.bfloat16)
+    yi, inv = ob.instnorm_fwd(xi)
+    yi_ref, inv_ref = ops.instnorm_fwd(xi.float())
+    torch.testing.assert_close(yi, yi_ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(inv, inv_ref, rtol=1e-6, atol=1e-7)
+    dyi = torch.randn(yi.shape, generator=g).cuda()
+    dxi = ob.instnorm_bwd(yi, dyi, inv)
+    assert dxi.dtype == torch.bfloat16
+    torch.testing.assert_close(dxi.float(), ops.instnorm_bwd(yi_ref, dyi, inv_ref), rtol=2 ** -8, atol=1e-6)

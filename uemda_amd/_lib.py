@@ -110,6 +110,13 @@ SIGNATURES = {
     "uem_pcl_workspace_floats": [I, I],
     "uem_coral_finish": [P, P, P, P, I, I, I, P, P, P, P, P],
     "uem_negate": [P, P, I, P],
+    "uem_conv2d_stem_fwd_stats_bf16": [P, P, P, I, I, I, P, P],
+    "uem_conv2d_stem_wgrad_bf16": [P, P, P, I, I, I, P],
+    "uem_bn_bwd_reduce_pool_bf16": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P],
+    "uem_bn_bwd_apply_pool_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P],
+    "uem_maxpool3x3s2_affine_fwd_bf16": [P, P, P, P, P, I, I, I, I, P],
+    "uem_instnorm_fwd_bf16": [P, P, P, P, I, I, I, F, P],
+    "uem_instnorm_bwd_bf16": [P, P, P, P, I, I, I, P],
     "uem_conv2d_bf16": [P, P, P, POINTER(ConvShape), I, P, P],
     "uem_conv2d_dgrad_tail_bf16": [P, P, P, POINTER(ConvShape), P, P, P, P, P, P, I, P],
     "uem_conv2d_wgrad_bf16": [P, P, P, POINTER(ConvShape), P],

@@ -59,6 +59,8 @@ struct ConvP {
     unsigned wg_stride;
     int dbg;                          // diagnostic builds of the schedule (uemdbg_conv_dbg); 0 in production
     unsigned long long tapmask;       // 4 bits per walked tap: tap id = ky*KW + kx (3x3 at most)
+    int y_bf16;                       // stem only (MODE 2, full tiles): y is a bf16 tensor -- values rounded (RNE) at the store, the
+                                      // BatchNorm tile statistics taken over the ROUNDED values (what the max-pool will read)
 };
 
 // Schedule-ablation hooks (diagnostic builds that skip loads / stores and give WRONG results) exist only under
@@ -192,7 +194,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
                         }
                         v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w;
                     }
-                    *reinterpret_cast<float4*>(p.y + row_off(m0 + hm * 64 + row) + n0 + sc4) = v;
+                    if (MODE == 2 && p.y_bf16) {
+                        const __bf16 b0 = (__bf16)v.x, b1 = (__bf16)v.y, b2 = (__bf16)v.z, b3 = (__bf16)v.w;
+                        const unsigned u0 = __builtin_bit_cast(unsigned short, b0), u1 = __builtin_bit_cast(unsigned short, b1);
+                        const unsigned u2 = __builtin_bit_cast(unsigned short, b2), u3 = __builtin_bit_cast(unsigned short, b3);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + row_off(m0 + hm * 64 + row) + n0 + sc4) =
+                            make_uint2(u0 | (u1 << 16), u2 | (u3 << 16));
+                        v = make_float4(__uint_as_float(u0 << 16), __uint_as_float(u1 << 16), __uint_as_float(u2 << 16), __uint_as_float(u3 << 16));
+                    } else {
+                        *reinterpret_cast<float4*>(p.y + row_off(m0 + hm * 64 + row) + n0 + sc4) = v;
+                    }
                     if (stats_on) {
                         bb.x += v.x; bb.y += v.y; bb.z += v.z; bb.w += v.w;
                         bg.x = fmaf(v.x, v.x, bg.x); bg.y = fmaf(v.y, v.y, bg.y); bg.z = fmaf(v.z, v.z, bg.z); bg.w = fmaf(v.w, v.w, bg.w);
@@ -840,9 +851,15 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB, PERSIST>::BPC)) void conv_
 // of tile t -- on the short-k layers (K = 64 ... 256: one to four k-steps) a block used to spend most of its life waiting for its first
 // operand tile.  The epilogue then stages in the stage tile t consumed last (the other one is being filled), so a stage holds at least
 // the 64 x (BN + 4) floats of an epilogue half.
-template <int BN, bool PERSIST = false>
+// BMT (round 5): rows of the block's tile, 128 (four waves, two blocks per CU) or 256 (eight waves as 4 x 2, ONE block per CU).  The
+// pointwise layers of a ResNet run a handful of 64-channel k-steps per tile and every k-step exposes one L2 / HBM round trip (the
+// next operand tile is requested under ~0.2 us of MFMAs and waited for at the next barrier: ~1.3 us per k-step, measured as tile time
+// = k-steps x 1.3 us + epilogue): a 256-row tile does twice (BN = 128) or four times (BN = 256) the MFMA work per round trip and
+// moves half the operand bytes per flop from L2 into LDS; its wave tile 64 x 128 (BN = 256) reads 0.75 KB of LDS per MFMA where
+// 64 x 64 reads 1 KB.
+template <int BN, bool PERSIST = false, int BMT = 128>
 struct ConvBf16Cfg {
-    static constexpr int A_ELEMS = BM * KBH, B_ELEMS = BN * KBH;          // bf16 elements per stage
+    static constexpr int A_ELEMS = BMT * KBH, B_ELEMS = BN * KBH;         // bf16 elements per stage
     static constexpr int RAW_STAGE_BYTES = (A_ELEMS + B_ELEMS) * 2;
     static constexpr int EPI_BYTES = 64 * (BN + 4) * 4;
     static constexpr int STAGE_BYTES = PERSIST && RAW_STAGE_BYTES < EPI_BYTES ? EPI_BYTES : RAW_STAGE_BYTES;
@@ -858,10 +875,12 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // epilogue that tests its options per row keeps the compiler from batching the LDS reads, conversions and stores:
 //   0  full dense tiles, plain store;  1  full dense tiles + BatchNorm tile statistics (forward) / the residual tail and
 //   BatchNorm-backward options (data gradient);  -1  anything (ragged last tile, strided output rows, accumulate in forward)
-template <int BN, int MODE, int EPI, bool PERSIST>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes, const int ntiles) {
-    using C = ConvBf16Cfg<BN, PERSIST>;
-    constexpr int WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32, BR = BN / 32;
+template <int BN, int MODE, int EPI, bool PERSIST, int BMT = 128>
+__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes, const int ntiles) {
+    using C = ConvBf16Cfg<BN, PERSIST, BMT>;
+    constexpr int NTH = 2 * BMT, NW = NTH / 64, RPS = NTH / 8;            // threads, waves, rows per DMA pass (8 lanes per 128-B row)
+    constexpr int WM = BMT / 64, WN = 2, MT = BMT / WM / 32, NT = BN / WN / 32, BR = BN / RPS;
+    static_assert(MT == 2 && BMT / RPS == 4, "a wave owns 64 rows; four A pieces per thread and k-step");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
     const unsigned short* const xh = reinterpret_cast<const unsigned short*>(p.x);
@@ -870,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = p.Cout / BN;
     int m0 = 0, n0 = 0;                                                  // compute side: the tile whose accumulators the block holds
-    const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + 32*j
+    const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + RPS*j
     const int lc8 = ((tid & 7) ^ ((lrow >> 1) & 7)) * 8;                 // swizzled source chunk (elements) of this lane
     const i32x4 rs_x = conv_rsrc(p.x, x_bytes), rs_w = conv_rsrc(p.w, w_bytes);
     (void)xh;
@@ -885,17 +904,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     int gy[4], gx[4], gpix[4];
     auto issue_tile_setup = [&]() {
         const int tile = xcd_remap(vi, ntiles);
-        const int im0 = (tile / tiles_n) * BM;
+        const int im0 = (tile / tiles_n) * BMT;
         in0 = (tile % tiles_n) * BN;
         if (pointwise) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { gy[j] = gx[j] = 0; gpix[j] = (im0 + lrow + 32 * j < p.M) ? im0 + lrow + 32 * j : -1; }
+            for (int j = 0; j < 4; ++j) { gy[j] = gx[j] = 0; gpix[j] = (im0 + lrow + RPS * j < p.M) ? im0 + lrow + RPS * j : -1; }
         } else {
             const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
             const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int m = im0 + lrow + 32 * j;
+                const int m = im0 + lrow + RPS * j;
                 if (m < p.M) {
                     const int n = m / HoWo, rem = m - n * HoWo;
                     const int oy = rem / Wrow, ox = rem - oy * Wrow;
@@ -919,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 tapok |= (gpix[j] >= 0 ? 1u : 0u) << j;
             }
 #pragma unroll
-            for (int j = 0; j < BR; ++j) boff[j] = ((unsigned)(in0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)lc8) * 2u;
+            for (int j = 0; j < BR; ++j) boff[j] = ((unsigned)(in0 + lrow + RPS * j) * (unsigned)Ktot + (unsigned)lc8) * 2u;
             return;
         }
         const int tap = (MODE == 1) ? (int)((p.tapmask >> (4 * t)) & 0xF) : t;
@@ -944,11 +963,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            boff[j] = ((unsigned)(in0 + lrow + 32 * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc8)) * 2u;
+            boff[j] = ((unsigned)(in0 + lrow + RPS * j) * (unsigned)Ktot + (unsigned)(tap * p.Cin + lc8)) * 2u;
     };
 
     f32x16 acc[MT][NT];
-    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
+    const int wm = (wave / WN) * (BMT / WM), wn = (wave % WN) * (BN / WN);
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
 
@@ -965,11 +984,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         auto piece = [&](const int j) {
             if (j < 4) {
                 const bool ok = live && ((tapok >> j) & 1u);
-                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(fAs + (j * 4 + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
+                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(fAs + (j * NW + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
                 aoff[j] += KBH * 2;
             } else if (j < NPC) {
                 const int jb = j - 4;
-                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(fBs + (jb * 4 + wave) * 512), 16, (int)(live ? boff[jb] : CONV_OOB), 0, 0, 0);
+                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(fBs + (jb * NW + wave) * 512), 16, (int)(live ? boff[jb] : CONV_OOB), 0, 0, 0);
                 boff[jb] += KBH * 2;
             }
         };
@@ -1025,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
         const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
         return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
     };
-    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = 256 / TPR, NRP = 64 / RPP;
+    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = NTH / TPR, NRP = 64 / RPP, NCH = BMT / 64;     // the epilogue walks NCH chunks of 64 rows
     float* stg = smem;                                                   // PERSIST: the stage the tile consumed last
     const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
     // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
@@ -1038,23 +1057,25 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     const unsigned short* const ah = p.acc_src != nullptr ? reinterpret_cast<const unsigned short*>(p.acc_src) : yh;
     float pb[8], pg[8], bsc[8], bsh[8], bmu[8], bis[8];
     // what the epilogue reads besides the accumulators -- the tensor accumulated into, its gate bits, the BatchNorm input and
-    // its mask bits -- is fetched one 64-row half ahead: half 0 before the main loop, half 1 while half 0 is written out
+    // its mask bits -- is fetched one 64-row chunk ahead: chunk 0 before the main loop, chunk c + 1 while chunk c is written out
+    // (two register sets, indexed by the chunk's parity)
     uint4 eo[2][NRP], ez[2][NRP];
     unsigned eab[2][NRP], ebb[2][NRP];
     const bool has_ab = MODE == 1 && p.acc_bits != nullptr, has_zb = MODE == 1 && p.bn_bits != nullptr;
     auto epi_fetch = [&](const int hm) {
+        const int hb = hm & 1;
 #pragma unroll
         for (int u = 0; u < NRP; ++u) {
             const int m = m0 + hm * 64 + srow + u * RPP;
-            eab[hm][u] = 0xffffffffu; ebb[hm][u] = 0u;                   // RAW words: shifted where they are used (see conv_epilogue)
+            eab[hb][u] = 0xffffffffu; ebb[hb][u] = 0u;                   // RAW words: shifted where they are used (see conv_epilogue)
             if (!FULL && m >= p.M) continue;
-            if (acc_on) eo[hm][u] = *reinterpret_cast<const uint4*>(ah + row_off(m) + n0 + sc8);
+            if (acc_on) eo[hb][u] = *reinterpret_cast<const uint4*>(ah + row_off(m) + n0 + sc8);
             if (MODE == 1) {
                 const size_t e0 = (size_t)m * p.Cout + n0 + sc8;           // dense rows whenever bits / bn_z are given
-                if (has_ab) eab[hm][u] = p.acc_bits[e0 >> 5];
+                if (has_ab) eab[hb][u] = p.acc_bits[e0 >> 5];
                 if (fuse_bn) {
-                    ez[hm][u] = *reinterpret_cast<const uint4*>(zh + e0);
-                    if (has_zb) ebb[hm][u] = p.bn_bits[e0 >> 5];
+                    ez[hb][u] = *reinterpret_cast<const uint4*>(zh + e0);
+                    if (has_zb) ebb[hb][u] = p.bn_bits[e0 >> 5];
                 }
             }
         }
@@ -1069,7 +1090,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
     for (int vc = blockIdx.x; vc < ntiles; vc += gridDim.x) {
         {
             const int tile = xcd_remap(vc, ntiles);
-            m0 = (tile / tiles_n) * BM; n0 = (tile % tiles_n) * BN;
+            m0 = (tile / tiles_n) * BMT; n0 = (tile % tiles_n) * BN;
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -1101,7 +1122,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
 
         // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
 #pragma unroll
-        for (int hm = 0; hm < 2; ++hm) {
+        for (int hm = 0; hm < NCH; ++hm) {
             if (wm / 64 == hm && !ablate_stage) {
                 const int rbase = wm % 64;
 #pragma unroll
@@ -1113,18 +1134,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                             stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
             }
             __syncthreads();
-            if (hm == 0 && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(1);
+            if (hm + 1 < NCH && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(hm + 1);
             bool rok[NRP];
 #pragma unroll
             for (int u = 0; u < NRP; ++u) rok[u] = FULL || m0 + hm * 64 + srow + u * RPP < p.M;
-            const uint4 (&o)[NRP] = eo[hm];
-            const uint4 (&zq)[NRP] = ez[hm];
+            const uint4 (&o)[NRP] = eo[hm & 1];
+            const uint4 (&zq)[NRP] = ez[hm & 1];
             unsigned abyte[NRP], bbyte[NRP];
 #pragma unroll
             for (int u = 0; u < NRP; ++u) {
                 const unsigned bshift = (unsigned)(((size_t)(m0 + hm * 64 + srow + u * RPP) * p.Cout + n0 + sc8) & 31);
-                abyte[u] = has_ab ? (eab[hm][u] >> bshift) & 0xffu : 0xffu;
-                bbyte[u] = has_zb ? (ebb[hm][u] >> bshift) & 0xffu : 0u;
+                abyte[u] = has_ab ? (eab[hm & 1][u] >> bshift) & 0xffu : 0xffu;
+                bbyte[u] = has_zb ? (ebb[hm & 1][u] >> bshift) & 0xffu : 0u;
             }
 #pragma unroll
             for (int u = 0; u < NRP; ++u) {
@@ -1167,21 +1188,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p, const 
                 }
             }
             __syncthreads();
-        }
-        float* const tile_out = fuse_bn ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
-        if (tile_out != nullptr) {                                           // column sums over the tile's 128 rows
-            // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
-            float* const red = stg;                                          // [2][RPP][BN]
+            // column sums over 128 rows = two chunks: the partial-sum tensors keep one entry per 128 rows whatever the block's tile
+            // (the finalize kernels merge 128-row groups)
+            float* const tile_out = fuse_bn ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
+            if ((hm & 1) && tile_out != nullptr) {
+                // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
+                float* const red = stg;                                      // [2][RPP][BN]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; }
-            __syncthreads();
-            if (tid < 2 * BN) {
-                const int which = tid / BN, col = tid % BN;
-                float a = 0.f;
+                for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; pb[e] = pg[e] = 0.f; }
+                __syncthreads();
+                for (int i = tid; i < 2 * BN; i += NTH) {
+                    const int which = i / BN, col = i % BN;
+                    float a = 0.f;
 #pragma unroll 8
-                for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + col];
-                const size_t tiles_m = (size_t)(p.M / BM);
-                tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / BM)] = a;
+                    for (int r = 0; r < RPP; ++r) a += red[(which * RPP + r) * BN + col];
+                    const size_t tiles_m = (size_t)(p.M / 128);
+                    tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / 128 + (hm >> 1))] = a;
+                }
+                if (hm + 1 < NCH) __syncthreads();                           // red is the next chunk's staging area
             }
         }
         if (!PERSIST) break;
@@ -1405,7 +1429,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* bias, co
     p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0;
     p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0; p.wg_rows = 0; p.wg_stride = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = 0; p.y_bf16 = 0; p.wg_rows = 0; p.wg_stride = 0;
     p.tile_stats = tile_stats;
     p.bn_z = bnbwd ? bnbwd->z : nullptr; p.bn_vec = bnbwd ? bnbwd->vec : nullptr; p.tile_bnbwd = bnbwd ? bnbwd->tiles : nullptr;
     p.acc_src = bnbwd ? bnbwd->acc_src : nullptr; p.acc_bits = bnbwd ? bnbwd->acc_bits : nullptr; p.bn_bits = bnbwd ? bnbwd->bn_bits : nullptr;
@@ -1464,7 +1488,7 @@ extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, i
     p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.x_ld = K; p.y_ld = N;
     p.accumulate = 0; p.relu = 0; p.tile_stats = nullptr; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr;
     p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 1; p.tapmask = 0; p.dbg = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 1; p.tapmask = 0; p.dbg = 0; p.y_bf16 = 0;
     p.wg_rows = T; p.wg_stride = (unsigned)((size_t)N * K * 4);
     p.M = npos * T;
     // data_gradient: the same pointwise product through the data-gradient instantiation (MODE 1: its tile rules, and a kernel name
@@ -1474,9 +1498,10 @@ extern "C" int uem_wino_gemm(const float* V, const float* U, float* Mt, int T, i
     return uem_check_launch("wino_gemm");
 }
 
-static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream);
+static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream,
+                         int y_bf16);
 extern "C" int uem_conv2d_stem_fwd(const float* x4, const float* w8, float* y, int N, int H, int W, void* stream) {
-    return stem_fwd_impl(x4, w8, y, N, H, W, nullptr, 0, stream);
+    return stem_fwd_impl(x4, w8, y, N, H, W, nullptr, 0, stream, 0);
 }
 extern "C" int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags,
                                          void* stream) {
@@ -1484,9 +1509,20 @@ extern "C" int uem_conv2d_stem_fwd_stats(const float* x4, const float* w8, float
     UEM_REQUIRE((flags & ~UEM_CONV_PREC_BF16) == 0, "conv2d_stem_fwd_stats: only precision flags are accepted");
     const int64_t M = (int64_t)N * ((H + 6 - 7) / 2 + 1) * ((W + 6 - 7) / 2 + 1);
     if (M % 128 != 0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_stem_fwd_stats: needs N*Ho*Wo %% 128 == 0");
-    return stem_fwd_impl(x4, w8, y, N, H, W, tile_stats, flags, stream);
+    return stem_fwd_impl(x4, w8, y, N, H, W, tile_stats, flags, stream, 0);
 }
-static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream) {
+static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream,
+                         int y_bf16 = 0);
+// bf16 storage: z leaves as a bf16 tensor (rounded at the store, statistics of the rounded values); bf16 operands
+extern "C" int uem_conv2d_stem_fwd_stats_bf16(const float* x4, const float* w8, uint16_t* y, int N, int H, int W, float* tile_stats,
+                                              void* stream) {
+    UEM_REQUIRE(tile_stats, "conv2d_stem_fwd_stats_bf16: null pointer");
+    const int64_t M = (int64_t)N * ((H + 6 - 7) / 2 + 1) * ((W + 6 - 7) / 2 + 1);
+    if (M % 128 != 0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_stem_fwd_stats_bf16: needs N*Ho*Wo %% 128 == 0");
+    return stem_fwd_impl(x4, w8, reinterpret_cast<float*>(y), N, H, W, tile_stats, UEM_CONV_PREC_BF16, stream, 1);
+}
+static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int H, int W, float* tile_stats, int flags, void* stream,
+                         int y_bf16) {
     UEM_REQUIRE(x4 && w8 && y && N > 0 && H >= 7 && W >= 7, "conv2d_stem_fwd: bad arguments");
     ConvP p;
     p.x = x4; p.w = w8; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = y;
@@ -1494,7 +1530,7 @@ static int stem_fwd_impl(const float* x4, const float* w8, float* y, int N, int 
     p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.y_ld = 64;
     p.accumulate = 0; p.relu = 0; p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0; p.dbg = 0; p.wg_rows = 0; p.wg_stride = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = 7; p.tapmask = 0; p.dbg = 0; p.y_bf16 = y_bf16; p.wg_rows = 0; p.wg_stride = 0;
     p.M = N * p.Ho * p.Wo;
     return conv_launch<2>(p, false, (hipStream_t)stream, (flags & UEM_CONV_PREC_BF16) ? 2 : 0);
 }
@@ -1514,6 +1550,7 @@ struct WgradP {
     float* dw;
     int M, N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, x_ld, dy_ld, relu;
     int rows_per_split;
+    int dy_bf16;           // stem only (MODE 2): dy is a bf16 tensor (bf16 storage: the stem's dz), widened at the load
     int dbg;               // UEM_WGRAD_DBG (diagnostic builds of the schedule only; results are wrong when non-zero):
                            // 1 = no global loads in the loop, 2 = no LDS stores in the loop, 4 = no atomics
 };
@@ -1597,7 +1634,14 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgradP p) {
             const int r = drow + j * DRPP;
             const int m = mb + r;
             const bool ok = r < BK && m < mend && (co0 + dc4) < p.Cout;
-            rd[j] = *reinterpret_cast<const float4*>(p.dy + (ok ? (size_t)m * p.dy_ld + co0 + dc4 : (size_t)0));
+            const size_t doff = ok ? (size_t)m * p.dy_ld + co0 + dc4 : (size_t)0;
+            if (MODE == 2 && p.dy_bf16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.dy) + doff);
+                rd[j] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                    __uint_as_float(u.y & 0xffff0000u));
+            } else {
+                rd[j] = *reinterpret_cast<const float4*>(p.dy + doff);
+            }
             dok |= (ok ? 1u : 0u) << j;
         }
 #pragma unroll
@@ -1824,7 +1868,7 @@ extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in
     p.x = x; p.dy = dy; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
     p.M = s->N * s->Ho * s->Wo; p.N = s->N; p.H = s->H; p.W = s->W; p.Cin = s->Cin; p.Ho = s->Ho; p.Wo = s->Wo;
     p.Cout = s->Cout; p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
-    p.x_ld = s->x_ld; p.dy_ld = s->y_ld; p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0; p.rows_per_split = 0;
+    p.x_ld = s->x_ld; p.dy_ld = s->y_ld; p.relu = (flags & UEM_CONV_IN_RELU) ? 1 : 0; p.rows_per_split = 0; p.dy_bf16 = 0;
     hipStream_t st = (hipStream_t)stream;
     UEM_REQUIRE(!(flags & 16), "conv2d_wgrad: flag 16 (the split-bf16 operand mode of rounds 1-3) is retired");
     const int prec = (flags & UEM_CONV_PREC_BF16) ? 2 : 0;
@@ -1841,7 +1885,10 @@ extern "C" int uem_conv2d_wgrad(const float* x, const float* dy, const float* in
     return uem_check_launch("conv2d_wgrad");
 }
 
-static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream);
+static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream, int dy_bf16 = 0);
+extern "C" int uem_conv2d_stem_wgrad_bf16(const float* x4, const uint16_t* dy, float* dw8, int N, int H, int W, void* stream) {
+    return stem_wgrad_impl(x4, reinterpret_cast<const float*>(dy), dw8, N, H, W, UEM_CONV_PREC_BF16, stream, 1);
+}
 extern "C" int uem_conv2d_stem_wgrad(const float* x4, const float* dy, float* dw8, int N, int H, int W, void* stream) {
     return stem_wgrad_impl(x4, dy, dw8, N, H, W, 0, stream);
 }
@@ -1849,9 +1896,10 @@ extern "C" int uem_conv2d_stem_wgrad_prec(const float* x4, const float* dy, floa
     UEM_REQUIRE((flags & ~UEM_CONV_PREC_BF16) == 0, "conv2d_stem_wgrad_prec: only precision flags are accepted");
     return stem_wgrad_impl(x4, dy, dw8, N, H, W, flags, stream);
 }
-static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream) {
+static int stem_wgrad_impl(const float* x4, const float* dy, float* dw8, int N, int H, int W, int flags, void* stream, int dy_bf16) {
     UEM_REQUIRE(x4 && dy && dw8 && N > 0 && H >= 7 && W >= 7, "conv2d_stem_wgrad: bad arguments");
     WgradP p;
+    p.dy_bf16 = dy_bf16;
     p.x = x4; p.dy = dy; p.in_scale = p.in_shift = nullptr; p.dw = dw8;
     p.N = N; p.H = H; p.W = W; p.Cin = 32; p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1; p.Cout = 64;
     p.KH = 7; p.KW = 1; p.stride = 2; p.pad = 3; p.dil = 1; p.x_ld = 4; p.dy_ld = 64; p.relu = 0; p.rows_per_split = 0;
@@ -2113,37 +2161,76 @@ extern "C" int uem_aspp_unpack_grad(const float* dwall, const float* db, void* c
 // =========================================================================================================
 static int g_bf16_persist = -1;  // tuning override: 1 / 0 = persistent blocks on / off, -1 = rule
 extern "C" void uemdbg_conv_bf16_persist(int v) { g_bf16_persist = v; }
-template <int BN_, int MODE, int EPI, bool PERSIST>
+template <int BN_, int MODE, int EPI, bool PERSIST, int BMT = 128>
 static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
-    using C = ConvBf16Cfg<BN_, PERSIST>;
-    const int ntiles = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
-    // persistent: one block per resident-block slot (LDS: two 128-wide or three 64-wide blocks per CU; a multiple of 8, so a block's
-    // tiles stay on its XCD's share)
-    const int slots = 256 * (160 * 1024 / C::LDS_BYTES > 3 ? 3 : 160 * 1024 / C::LDS_BYTES);
+    using C = ConvBf16Cfg<BN_, PERSIST, BMT>;
+    const int ntiles = (int)uem_cdiv(p.M, BMT) * (p.Cout / BN_);
+    // persistent: one block per resident-block slot (LDS: one 256-row, two 128-wide or three 64-wide blocks per CU; a multiple of 8,
+    // so a block's tiles stay on its XCD's share)
+    const int per_cu = BMT == 256 ? 1 : (160 * 1024 / C::LDS_BYTES > 3 ? 3 : 160 * 1024 / C::LDS_BYTES);
+    const int slots = 256 * per_cu;
     const int grid = PERSIST && ntiles > slots ? slots : ntiles;
-    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST>;
-    if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 256, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
+    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT>;
+    if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 2 * BMT, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
 }
-template <int BN_, int MODE>
+static int g_bf16_big = -1;      // tuning override: 0 = never the 256-row tiles, 1 = wherever they are legal, -1 = rule
+extern "C" void uemdbg_conv_bf16_big(int v) { g_bf16_big = v; }
+template <int BN_, int MODE, int BMT = 128>
 static void conv_bf16_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
-    const bool full = p.M % BM == 0 && (MODE == 0 || p.sub == 1) && UEM_DBG(p.dbg) == 0;
+    const bool full = p.M % BMT == 0 && (MODE == 0 || p.sub == 1) && UEM_DBG(p.dbg) == 0;
     const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
     static const int penv = getenv("UEM_CONV_BF16_PERSIST") ? atoi(getenv("UEM_CONV_BF16_PERSIST")) : -1;
     const int pset = g_bf16_persist >= 0 ? g_bf16_persist : penv;
-    const int ntiles = (int)uem_cdiv(p.M, BM) * (p.Cout / BN_);
+    const int ntiles = (int)uem_cdiv(p.M, BMT) * (p.Cout / BN_);
     // persistent blocks: full tiles, at least two tiles per block
     // Rule (profiles/r04_q_conv_bf16_persist.txt): the short k-loops (at most 12 k-steps: the pointwise layers up to K = 768 and the
     // 64-channel 3x3) with at least two rounds of tiles, except the fused data-gradient epilogues -- their prefetched operands (the
     // tensor accumulated into, z, the packed bits) are older than the operand DMA of the next tile, retire before it, and the block
     // loses what persistence hides (residual tails +15 ... 50 %).  pset: 1 = every full-tile launch, 2 = all but those epilogues.
-    constexpr int slots = 256 * (160 * 1024 / ConvBf16Cfg<BN_, true>::LDS_BYTES > 3 ? 3 : 160 * 1024 / ConvBf16Cfg<BN_, true>::LDS_BYTES);
+    constexpr int per_cu = BMT == 256 ? 1 : (160 * 1024 / ConvBf16Cfg<BN_, true, BMT>::LDS_BYTES > 3 ? 3 : 160 * 1024 / ConvBf16Cfg<BN_, true, BMT>::LDS_BYTES);
+    constexpr int slots = 256 * per_cu;
     const int KT = p.ntaps * (p.Cin / KBH);
     const bool persist = full && !(MODE == 0 && p.accumulate) && p.ntaps > 0 &&
                          (pset == 1 || (pset == 2 && !(MODE == 1 && extras)) ||
                           (pset < 0 && !(MODE == 1 && extras) && KT <= 12 && ntiles >= 2 * slots));
-    if (!full || (MODE == 0 && p.accumulate)) conv_bf16_launch<BN_, MODE, -1, false>(p, xb, wb, st);
-    else if (extras) { if (persist) conv_bf16_launch<BN_, MODE, 1, true>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 1, false>(p, xb, wb, st); }
-    else { if (persist) conv_bf16_launch<BN_, MODE, 0, true>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 0, false>(p, xb, wb, st); }
+    if constexpr (BMT == 256) {
+        // the 256-row tiles are dispatched for full tiles only (conv_bf16_big_bn); 256 x 256 keeps 128 accumulator registers per lane:
+        // no room for the persistent form's cross-tile state or the fused data-gradient epilogues' prefetch (they spill) -> never
+        // persistent, and the fused data-gradient epilogues stay at BN = 128
+        if constexpr (BN_ == 256) {
+            if (extras) { if constexpr (MODE == 0) conv_bf16_launch<BN_, MODE, 1, false, BMT>(p, xb, wb, st); }
+            else conv_bf16_launch<BN_, MODE, 0, false, BMT>(p, xb, wb, st);
+        } else {
+            if (extras) { if (persist) conv_bf16_launch<BN_, MODE, 1, true, BMT>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 1, false, BMT>(p, xb, wb, st); }
+            else { if (persist) conv_bf16_launch<BN_, MODE, 0, true, BMT>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 0, false, BMT>(p, xb, wb, st); }
+        }
+    } else {
+        if (!full || (MODE == 0 && p.accumulate)) conv_bf16_launch<BN_, MODE, -1, false, BMT>(p, xb, wb, st);
+        else if (extras) { if (persist) conv_bf16_launch<BN_, MODE, 1, true, BMT>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 1, false, BMT>(p, xb, wb, st); }
+        else { if (persist) conv_bf16_launch<BN_, MODE, 0, true, BMT>(p, xb, wb, st); else conv_bf16_launch<BN_, MODE, 0, false, BMT>(p, xb, wb, st); }
+    }
+}
+// 256-row tiles (eight waves, one block per CU): when do they pay?  Measured per shape at B = 32 (scripts/sweep_conv_bf16_big.py,
+// profiles/r05_*_conv_bf16_big_sweep.txt): the MFMA-heavy launches gain -- layer4's 3x3 convs -9 ... -11 %, its 1024 -> 2048
+// downsample -5 ... -8 %, the other layer4 pointwise layers 0 ... -6 % -- and everything with a short reduction loses (one block per
+// CU has nobody to overlap a tile's prologue and epilogue with: layer3's 256 -> 1024 +4 ... +52 %, its 3x3 at 256 tiles +46 %).  Rule:
+// full tiles, at least 16 k-steps of 64 channels (K >= 1024), at least one tile per CU; 256 columns where that still holds, else 128;
+// the fused data-gradient epilogues at 128 columns only (their prefetch registers beside 128 accumulators spill).  Returns 0 (the
+// 128-row kernel), 128 or 256.  UEM_CONV_BF16_BIG: 0 never, 1 wherever legal (tests), default the rule.
+template <int MODE>
+static int conv_bf16_big_bn(const ConvP& p) {
+    static const int env = getenv("UEM_CONV_BF16_BIG") ? atoi(getenv("UEM_CONV_BF16_BIG")) : -1;
+    const int set = g_bf16_big >= 0 ? g_bf16_big : env;
+    if (set == 0 || p.M % 256 != 0 || (MODE == 1 && p.sub != 1) || p.Cout % 128 != 0 || UEM_DBG(p.dbg) != 0) return 0;
+    if (MODE == 0 && p.accumulate) return 0;
+    const int rows = p.M / 256, KT = p.ntaps * (p.Cin / KBH);
+    static const int min_tiles = getenv("UEM_CONV_BF16_BIG_MIN_TILES") ? atoi(getenv("UEM_CONV_BF16_BIG_MIN_TILES")) : 256;
+    static const int min_kt = getenv("UEM_CONV_BF16_BIG_MIN_KT") ? atoi(getenv("UEM_CONV_BF16_BIG_MIN_KT")) : 16;
+    const bool extras = MODE == 1 && (p.accumulate || p.acc_src || p.tile_bnbwd);
+    if (set == 1) return (!extras && p.Cout % 256 == 0) ? 256 : 128;
+    if (KT < min_kt) return 0;
+    if (!extras && p.Cout % 256 == 0 && rows * (p.Cout / 256) >= min_tiles) return 256;
+    return rows * (p.Cout / 128) >= min_tiles ? 128 : 0;
 }
 struct BnBwdFuseH { const uint16_t* z; const float* vec; float* tiles; const uint16_t* acc_src; const uint32_t* acc_bits; const uint32_t* bn_bits; };
 static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, const uem_conv_shape* s, int flags, float* tile_stats,
@@ -2182,7 +2269,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
     p.x = (const float*)x; p.w = (const float*)w; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = (float*)y;
     p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0; p.relu = 0;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = g_conv_dbg; p.wg_rows = 0; p.wg_stride = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = g_conv_dbg; p.y_bf16 = 0; p.wg_rows = 0; p.wg_stride = 0;
     p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     if (fuse != nullptr) {
         p.bn_z = (const float*)fuse->z; p.bn_vec = fuse->vec; p.tile_bnbwd = fuse->tiles;
@@ -2195,7 +2282,10 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
         p.x_ld = s->x_ld; p.y_ld = s->y_ld; p.M = s->N * s->Ho * s->Wo;
         const double xb = (double)p.N * p.H * p.W * p.x_ld * 2.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 2.0;
         if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
-        if (p.Cout % 128 == 0) conv_bf16_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        const int big = conv_bf16_big_bn<0>(p);
+        if (big == 256) conv_bf16_go<256, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
+        else if (big == 128) conv_bf16_go<128, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
+        else if (p.Cout % 128 == 0) conv_bf16_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
         else conv_bf16_go<64, 0>(p, (unsigned)xb, (unsigned)wb, st);
         return uem_check_launch("conv2d_bf16");
     }
@@ -2231,7 +2321,10 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
             static const int wt_env = getenv("UEM_BF16_WIDE_TAIL") ? atoi(getenv("UEM_BF16_WIDE_TAIL")) : 0;
             const bool wide_tail = wt_env != 0 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout &&
                                    (wt_env != 2 || p.Cin <= 256);
-            if (p.Cout % 128 == 0 && !wide_tail) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            const int big = wide_tail ? 0 : conv_bf16_big_bn<1>(p);
+            if (big == 256) conv_bf16_go<256, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
+            else if (big == 128) conv_bf16_go<128, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
+            else if (p.Cout % 128 == 0 && !wide_tail) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
             else conv_bf16_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);
         }
     }

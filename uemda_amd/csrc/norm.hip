@@ -937,7 +937,8 @@ __device__ __forceinline__ float4 tap_sel(const uchar4 bi, const float4 g, const
     return make_float4(bi.x == k ? g.x : 0.f, bi.y == k ? g.y : 0.f, bi.z == k ? g.z : 0.f, bi.w == k ? g.w : 0.f);
 }
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-__device__ __forceinline__ Pool2x2 pool_grad_2x2(const float* __restrict__ dy, const uint8_t* __restrict__ idx, int n, int k, int j, int c,
+template <typename TG>
+__device__ __forceinline__ Pool2x2 pool_grad_2x2(const TG* __restrict__ dy, const uint8_t* __restrict__ idx, int n, int k, int j, int c,
                                                  int C, int Ho, int Wo) {
     uchar4 bi[2][2];
     float4 g[2][2];
@@ -948,7 +949,7 @@ __device__ __forceinline__ Pool2x2 pool_grad_2x2(const float* __restrict__ dy, c
             const bool ok = k + a < Ho && j + b < Wo;
             const size_t o = (((size_t)n * Ho + (ok ? k + a : k)) * Wo + (ok ? j + b : j)) * C + c;
             bi[a][b] = *reinterpret_cast<const uchar4*>(idx + o);
-            g[a][b] = *reinterpret_cast<const float4*>(dy + o);
+            g[a][b] = ld4<TG>(dy + o);
             if (!ok) bi[a][b] = make_uchar4(255, 255, 255, 255);       // no such window: matches no tap
         }
     Pool2x2 r;
@@ -961,7 +962,10 @@ __device__ __forceinline__ Pool2x2 pool_grad_2x2(const float* __restrict__ dy, c
     return r;
 }
 // rows of the reduction = 2x2 blocks; the partial sums are accumulated pixel by pixel in the row-major order of the block's rows
-__global__ __launch_bounds__(256) void bn_bwd_partial_pool_kernel(const float* __restrict__ x, const float* __restrict__ dyp,
+// T: storage type of x (the stem's conv output z) and of the pooled gradient -- float, or bf16 under bf16 storage (round 5: the
+// stem's 64-channel half-resolution map is the network's largest tensor; in bf16 every pass over it moves half the bytes)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_partial_pool_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
                                                                   const uint8_t* __restrict__ idx, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ smean,
                                                                   const float* __restrict__ sinv, int N, int H, int W, int C, int relu,
@@ -978,11 +982,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool_kernel(const float* _
     for (int b = b0 + cm.rg; b < b1; b += cm.rpp) {
         const int n = b / (Hb * Wb), rem = b - n * (Hb * Wb);
         const int k = rem / Wb, j = rem - k * Wb;
-        const Pool2x2 pg = pool_grad_2x2(dyp, idx, n, k, j, cm.c0, C, Ho, Wo);
+        const Pool2x2 pg = pool_grad_2x2<T>(dyp, idx, n, k, j, cm.c0, C, Ho, Wo);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t off = (((size_t)n * H + 2 * k + (q >> 1)) * W + 2 * j + (q & 1)) * C + cm.c0;
-            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            const float4 xv = ld4<T>(x + off);
             float4 d = pg.d[q];
             if (relu) d = relu_mask4(d, xv, sc, sh, nullptr, off, 1);
             sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
@@ -1008,12 +1012,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_pool_kernel(const float* _
         for (int q = 0; q < 4; ++q) { w[cm.c0 + q] = a[q]; w[C + cm.c0 + q] = a[4 + q]; }
     }
 }
-__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ dyp,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ x, const T* __restrict__ dyp,
                                                                 const uint8_t* __restrict__ idx, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, const float* __restrict__ smean,
                                                                 const float* __restrict__ sinv, const float* __restrict__ dgamma,
                                                                 const float* __restrict__ dbeta, int N, int H, int W, int C, float invM,
-                                                                int relu, float* __restrict__ dx) {
+                                                                int relu, T* __restrict__ dx) {
     const int Hb = H >> 1, Wb = W >> 1, cv = C >> 2;
     const int64_t total = (int64_t)N * Hb * Wb * cv;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -1022,14 +1027,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __r
         const int j = (int)(t % Wb); t /= Wb;
         const int k = (int)(t % Hb);
         const int n = (int)(t / Hb);
-        const Pool2x2 pg = pool_grad_2x2(dyp, idx, n, k, j, c, C, Hb, Wb);
+        const Pool2x2 pg = pool_grad_2x2<T>(dyp, idx, n, k, j, c, C, Hb, Wb);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(smean + c), is = *reinterpret_cast<const float4*>(sinv + c);
         const float4 dg = *reinterpret_cast<const float4*>(dgamma + c), db = *reinterpret_cast<const float4*>(dbeta + c);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t off = (((size_t)n * H + 2 * k + (q >> 1)) * W + 2 * j + (q & 1)) * C + c;
-            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            const float4 xv = ld4<T>(x + off);
             float4 d = pg.d[q];
             if (relu) d = relu_mask4(d, xv, sc, sh, nullptr, off, 1);
             float4 o;
@@ -1037,13 +1042,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const float* __r
             o.y = sc.y * (d.y - db.y * invM - ((xv.y - mu.y) * is.y) * (dg.y * invM));
             o.z = sc.z * (d.z - db.z * invM - ((xv.z - mu.z) * is.z) * (dg.z * invM));
             o.w = sc.w * (d.w - db.w * invM - ((xv.w - mu.w) * is.w) * (dg.w * invM));
-            *reinterpret_cast<float4*>(dx + off) = o;
+            st4<T>(dx + off, o);
         }
     }
 }
-extern "C" int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
-                                      const float* save_mean, const float* save_invstd, int N, int H, int W, int C, int relu,
-                                      float* dgamma, float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
+template <typename T>
+static int bn_bwd_reduce_pool_impl(const T* x, const T* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                   const float* save_mean, const float* save_invstd, int N, int H, int W, int C, int relu,
+                                   float* dgamma, float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
     UEM_REQUIRE(x && dy_pool && idx && scale && shift && save_mean && save_invstd && dgamma && dbeta && workspace, "bn_bwd_reduce_pool: null pointer");
     UEM_REQUIRE(N > 0 && H > 1 && W > 1 && col_shape_ok(C) && (int64_t)N * H * W < 2147483647LL, "bn_bwd_reduce_pool: unsupported shape");
     if ((H | W) & 1) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_reduce_pool: H and W must be even");
@@ -1053,21 +1059,45 @@ extern "C" int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, cons
     int chunks, bpc;
     col_chunks(nb, C, &chunks, &bpc);                 // never more chunks than uem_bn_workspace_floats(N*H*W, C) provides for
     dim3 grid((unsigned)uem_cdiv(C, 256), (unsigned)chunks);
-    bn_bwd_partial_pool_kernel<<<grid, 256, 0, st>>>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, N, H, W, C, relu, bpc, workspace);
+    bn_bwd_partial_pool_kernel<T><<<grid, 256, 0, st>>>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, N, H, W, C, relu, bpc, workspace);
     bn_bwd_finalize_kernel<<<C, 256, 0, st>>>(workspace, chunks, C, dgamma, dbeta, grad_gamma, grad_beta);
     return uem_check_launch("bn_bwd_reduce_pool");
 }
-extern "C" int uem_bn_bwd_apply_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
-                                     const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N,
-                                     int H, int W, int C, int relu, float* dx, void* stream) {
+template <typename T>
+static int bn_bwd_apply_pool_impl(const T* x, const T* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                  const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N,
+                                  int H, int W, int C, int relu, T* dx, void* stream) {
     UEM_REQUIRE(x && dy_pool && idx && scale && shift && save_mean && save_invstd && dgamma && dbeta && dx, "bn_bwd_apply_pool: null pointer");
     UEM_REQUIRE(N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0 && (int64_t)N * H * W < 2147483647LL, "bn_bwd_apply_pool: bad shape");
     if ((H | W) & 1) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pool: H and W must be even");
     UEM_REQUIRE(relu == 0 || relu == 1, "bn_bwd_apply_pool: relu is 0 or 1 (mask recomputed from x)");
     const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
-    bn_bwd_apply_pool_kernel<<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(
+    bn_bwd_apply_pool_kernel<T><<<uem_stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(
         x, dy_pool, idx, scale, shift, save_mean, save_invstd, dgamma, dbeta, N, H, W, C, 1.0f / (float)((int64_t)N * H * W), relu, dx);
     return uem_check_launch("bn_bwd_apply_pool");
+}
+extern "C" int uem_bn_bwd_reduce_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                      const float* save_mean, const float* save_invstd, int N, int H, int W, int C, int relu,
+                                      float* dgamma, float* dbeta, float* grad_gamma, float* grad_beta, float* workspace, void* stream) {
+    return bn_bwd_reduce_pool_impl<float>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, N, H, W, C, relu, dgamma, dbeta, grad_gamma,
+                                          grad_beta, workspace, stream);
+}
+extern "C" int uem_bn_bwd_apply_pool(const float* x, const float* dy_pool, const uint8_t* idx, const float* scale, const float* shift,
+                                     const float* save_mean, const float* save_invstd, const float* dgamma, const float* dbeta, int N,
+                                     int H, int W, int C, int relu, float* dx, void* stream) {
+    return bn_bwd_apply_pool_impl<float>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, dgamma, dbeta, N, H, W, C, relu, dx, stream);
+}
+extern "C" int uem_bn_bwd_reduce_pool_bf16(const uint16_t* x, const uint16_t* dy_pool, const uint8_t* idx, const float* scale,
+                                           const float* shift, const float* save_mean, const float* save_invstd, int N, int H, int W, int C,
+                                           int relu, float* dgamma, float* dbeta, float* grad_gamma, float* grad_beta, float* workspace,
+                                           void* stream) {
+    return bn_bwd_reduce_pool_impl<bf16_t>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, N, H, W, C, relu, dgamma, dbeta, grad_gamma,
+                                           grad_beta, workspace, stream);
+}
+extern "C" int uem_bn_bwd_apply_pool_bf16(const uint16_t* x, const uint16_t* dy_pool, const uint8_t* idx, const float* scale,
+                                          const float* shift, const float* save_mean, const float* save_invstd, const float* dgamma,
+                                          const float* dbeta, int N, int H, int W, int C, int relu, uint16_t* dx, void* stream) {
+    return bn_bwd_apply_pool_impl<bf16_t>(x, dy_pool, idx, scale, shift, save_mean, save_invstd, dgamma, dbeta, N, H, W, C, relu, dx, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1118,9 +1148,9 @@ extern "C" int uem_affine_act_bwd(const float* x, const float* dy, const float* 
 // ---------------------------------------------------------------------------------------------------------
 // MaxPool 3x3 stride 2 pad 1 (first max in row-major window order wins, like torch CPU); idx in 0..8
 // ---------------------------------------------------------------------------------------------------------
-template <bool AFFINE>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float* __restrict__ y,
+template <bool AFFINE, typename T = float>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, T* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
     // AFFINE: the pooled tensor is relu(x*scale + shift) (the stem's BatchNorm + ReLU), never written to memory
     const int cv = C >> 2;
@@ -1142,7 +1172,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= W) continue;
-                float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + iy) * W + ix) * C + c);
+                float4 v = ld4<T>(x + (((size_t)n * H + iy) * W + ix) * C + c);
                 if (AFFINE) {
                     const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
                     v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
@@ -1159,7 +1189,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
             }
         }
         const size_t o = (((size_t)n * Ho + oy) * Wo + ox) * C + c;
-        *reinterpret_cast<float4*>(y + o) = best;
+        st4<T>(y + o, best);
         if (idx) *reinterpret_cast<uchar4*>(idx + o) = bi;
     }
 }
@@ -1177,6 +1207,14 @@ extern "C" int uem_maxpool3x3s2_affine_fwd(const float* x, const float* scale, c
     const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
     maxpool_fwd_kernel<true><<<uem_flat_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, idx, N, H, W, C, Ho, Wo);
     return uem_check_launch("maxpool_affine_fwd");
+}
+extern "C" int uem_maxpool3x3s2_affine_fwd_bf16(const uint16_t* x, const float* scale, const float* shift, uint16_t* y, uint8_t* idx, int N,
+                                                int H, int W, int C, void* stream) {
+    UEM_REQUIRE(x && scale && shift && y && N > 0 && H > 1 && W > 1 && C > 0 && (C % 4) == 0, "maxpool_affine_fwd_bf16: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+    maxpool_fwd_kernel<true, bf16_t><<<uem_flat_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, y, idx, N, H, W, C, Ho, Wo);
+    return uem_check_launch("maxpool_affine_fwd_bf16");
 }
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
@@ -1204,17 +1242,18 @@ extern "C" int uem_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* 
 // ---------------------------------------------------------------------------------------------------------
 // InstanceNorm2d (no affine, no running stats): block = (image n, 64-channel tile), 4 pixel groups
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename TX>
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const TX* __restrict__ x, float* __restrict__ y,
                                                            float* __restrict__ smean, float* __restrict__ sinv, int HW, int C,
                                                            float eps) {
     // 16 lanes x float4 = the block's 64 channels, 16 pixel groups: 16-byte accesses, 1 KiB per wave instruction (the scalar
     // version ran at 2.1 TB/s).  One pass of shifted sums per thread (K = its first pixel), Chan merge across the 16 groups.
     const int n = blockIdx.y, l = threadIdx.x & 15, g = threadIdx.x >> 4, c = blockIdx.x * 64 + l * 4;
-    const float* xb = x + (size_t)n * HW * C + c;
+    const TX* xb = x + (size_t)n * HW * C + c;
     float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
     float cnt = 0.f;
     for (int p = g; p < HW; p += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+        const float4 v = ld4<TX>(xb + (size_t)p * C);
         if (cnt == 0.f) K = v;
         const float4 d = make_float4(v.x - K.x, v.y - K.y, v.z - K.z, v.w - K.w);
         s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
@@ -1246,7 +1285,7 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
     }
     float* yb = y + (size_t)n * HW * C + c;
     for (int p = g; p < HW; p += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)p * C);
+        const float4 v = ld4<TX>(xb + (size_t)p * C);
         *reinterpret_cast<float4*>(yb + (size_t)p * C) = make_float4((v.x - mean4[0]) * is4[0], (v.y - mean4[1]) * is4[1],
                                                                      (v.z - mean4[2]) * is4[2], (v.w - mean4[3]) * is4[3]);
     }
@@ -1254,11 +1293,20 @@ __global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* __restri
 extern "C" int uem_instnorm_fwd(const float* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,
                                 float eps, void* stream) {
     UEM_REQUIRE(x && y && save_mean && save_invstd && N > 0 && HW > 0 && C > 0 && (C % 64) == 0, "instnorm_fwd: bad arguments (C %% 64)");
-    instnorm_fwd_kernel<<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(x, y, save_mean, save_invstd, HW, C, eps);
+    instnorm_fwd_kernel<float><<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(x, y, save_mean, save_invstd, HW, C, eps);
     return uem_check_launch("instnorm_fwd");
 }
+// bf16 storage: the InstanceNorm at the end of the bf16 region reads the bf16 layer4 output directly and writes the fp32 feature map the
+// heads and the mining read (no separate cast pass), and its backward writes the bf16 gradient directly
+extern "C" int uem_instnorm_fwd_bf16(const uint16_t* x, float* y, float* save_mean, float* save_invstd, int N, int HW, int C,
+                                     float eps, void* stream) {
+    UEM_REQUIRE(x && y && save_mean && save_invstd && N > 0 && HW > 0 && C > 0 && (C % 64) == 0, "instnorm_fwd_bf16: bad arguments (C %% 64)");
+    instnorm_fwd_kernel<bf16_t><<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(x, y, save_mean, save_invstd, HW, C, eps);
+    return uem_check_launch("instnorm_fwd_bf16");
+}
+template <typename TO>
 __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                                           const float* __restrict__ sinv, float* __restrict__ dx, int HW, int C) {
+                                                           const float* __restrict__ sinv, TO* __restrict__ dx, int HW, int C) {
     const int n = blockIdx.y, l = threadIdx.x & 15, g = threadIdx.x >> 4, c = blockIdx.x * 64 + l * 4;
     const size_t base = (size_t)n * HW * C + c;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
@@ -1287,15 +1335,21 @@ __global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* __restri
         const size_t o = base + (size_t)p * C;
         const float4 d = *reinterpret_cast<const float4*>(dy + o);
         const float4 v = *reinterpret_cast<const float4*>(y + o);
-        *reinterpret_cast<float4*>(dx + o) = make_float4(is.x * (d.x - m1[0] - v.x * m2[0]), is.y * (d.y - m1[1] - v.y * m2[1]),
-                                                         is.z * (d.z - m1[2] - v.z * m2[2]), is.w * (d.w - m1[3] - v.w * m2[3]));
+        st4<TO>(dx + o, make_float4(is.x * (d.x - m1[0] - v.x * m2[0]), is.y * (d.y - m1[1] - v.y * m2[1]),
+                                    is.z * (d.z - m1[2] - v.z * m2[2]), is.w * (d.w - m1[3] - v.w * m2[3])));
     }
 }
 extern "C" int uem_instnorm_bwd(const float* y, const float* dy, const float* save_invstd, float* dx, int N, int HW, int C,
                                 void* stream) {
     UEM_REQUIRE(y && dy && save_invstd && dx && N > 0 && HW > 0 && (C % 64) == 0, "instnorm_bwd: bad arguments");
-    instnorm_bwd_kernel<<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(y, dy, save_invstd, dx, HW, C);
+    instnorm_bwd_kernel<float><<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(y, dy, save_invstd, dx, HW, C);
     return uem_check_launch("instnorm_bwd");
+}
+extern "C" int uem_instnorm_bwd_bf16(const float* y, const float* dy, const float* save_invstd, uint16_t* dx, int N, int HW, int C,
+                                     void* stream) {
+    UEM_REQUIRE(y && dy && save_invstd && dx && N > 0 && HW > 0 && (C % 64) == 0, "instnorm_bwd_bf16: bad arguments");
+    instnorm_bwd_kernel<bf16_t><<<dim3(C / 64, N), 256, 0, (hipStream_t)stream>>>(y, dy, save_invstd, dx, HW, C);
+    return uem_check_launch("instnorm_bwd_bf16");
 }
 
 // ---------------------------------------------------------------------------------------------------------

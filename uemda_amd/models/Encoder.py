@@ -225,7 +225,9 @@ class Deeplabv2(nn.Module):
         if self._arena is None:
             raise UemError("Deeplabv2: move the model to the MI355X device first (model.cuda())")
         cfg = self.config
-        stages = self.encoder.forward_nhwc(x)
+        # bf16 storage: the InstanceNorm reads the bf16 layer4 output itself (no cast pass in front of it)
+        fuse_in = bool(cfg.is_ins_norm) and not (cfg.multi_layer and cfg.cascade)
+        stages = self.encoder.forward_nhwc(x, last_bf16=fuse_in)
         if cfg.multi_layer and cfg.cascade:                                       # Encoder.py:129-143
             if self.encoder.storage != "fp32":
                 raise UemError("Deeplabv2(cascade=True) reads the layer3 output as an fp32 map: use fp32 storage")
@@ -239,8 +241,12 @@ class Deeplabv2(nn.Module):
                 return ops.as_nchw_view(x1), ops.as_nchw_view(feat1), ops.as_nchw_view(x2), ops.as_nchw_view(feat2)
             return self._prob(x1, x2, x.shape[-2:])
         feat = stages[-1]                                                         # Encoder.py:145
-        if cfg.is_ins_norm:
-            feat = blocks.InstNormFn.apply(feat, self.instance_norm.eps)          # Encoder.py:146-147
+        if cfg.is_ins_norm:                                                       # Encoder.py:146-147
+            if feat.dtype == torch.bfloat16:
+                from .blocks_bf16 import InstNormBf16Fn
+                feat = InstNormBf16Fn.apply(feat, self.instance_norm.eps)
+            else:
+                feat = blocks.InstNormFn.apply(feat, self.instance_norm.eps)
         if not cfg.multi_layer:                                                   # Encoder.py:156-165
             x1 = self._head(feat, self.cls_pred)
             if self.training:

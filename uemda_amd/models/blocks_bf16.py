@@ -26,6 +26,50 @@ class CastFn(Function):
         return (ob.to_f32(dy) if ctx.to_bf16 else ob.to_bf16(dy)), None
 
 
+class StemBf16Fn(Function):
+    """conv7x7 s2 -> BN -> ReLU -> maxpool3x3 s2 with the conv output z, the pooled map and their gradients stored in bf16 (round 5).
+    z -- 64 channels at half resolution -- is the largest tensor of the network: written once and read once forward, read twice and its
+    gradient written once backward; in bf16 each of those passes moves half the bytes, and the cast in front of layer1 is gone.
+    Same reference lines as blocks.StemFn (uemda/_resnets.py:149-153,205-212)."""
+
+    @staticmethod
+    def forward(ctx, x, resnet, *params):
+        x4 = ops.nchw3_to_nhwc4(x)
+        z, st = ob.stem_conv_bn(x4, ops.stem_weight_packed(resnet.conv1.weight), resnet.bn1)
+        need = any(ctx.needs_input_grad)
+        y, idx = ob.maxpool_affine_fwd(z, st, need)
+        ops.nbt_inc(resnet.bn1)
+        if need:
+            ctx.resnet = resnet
+            ctx.save_for_backward(x4, z, _st_tensor(st), idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x4, z, stbuf, idx = ctx.saved_tensors
+        resnet = ctx.resnet
+        st = _st_from(stbuf, True)
+        dz = ob.bn_backward_pooled(z, dy.contiguous(), idx, st, grad_buffer(resnet.bn1.weight), grad_buffer(resnet.bn1.bias))
+        ob.stem_wgrad(x4, dz, grad_ohwi(resnet.conv1.weight))
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class InstNormBf16Fn(Function):
+    """nn.InstanceNorm2d at the end of the bf16 region: bf16 layer4 output in, fp32 features out; bf16 gradient back (Encoder.py:123,147)"""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, invstd = ob.instnorm_fwd(x.contiguous(), eps)
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(y, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, invstd = ctx.saved_tensors
+        return ob.instnorm_bwd(y, dy.contiguous(), invstd), None
+
+
 class BottleneckBf16Fn(Function):
     @staticmethod
     def forward(ctx, x, blk, *params):

@@ -126,6 +126,83 @@ def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1):
         ops.conv2d_wgrad(to_f32(x), to_f32(dy), dw_ohwi, stride=stride, pad=pad, dil=dil)
 
 
+# ---- the two ends of the bf16 region in bf16 (round 5): stem and InstanceNorm ----------------------------------------
+def stem_ok(x_shape, bn):
+    """Can the stem run with a bf16 conv output?  Training-mode statistics out of the conv epilogue (full 128-pixel tiles) and the
+    pooled form of the BatchNorm backward (even map size)."""
+    n, _, h, w = x_shape
+    ho, wo = conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1)
+    return (bn.training or bn.running_mean is None) and (n * ho * wo) % 128 == 0 and ho % 2 == 0 and wo % 2 == 0 and ops.FUSE_BN_STATS
+
+
+def stem_conv_bn(x4, w8, bn):
+    """7x7/s2 stem conv (bf16 operands) -> bf16 z + training-mode BatchNorm statistics of the rounded values -> (z, BNState)."""
+    n, h, w, _ = x4.shape
+    ho, wo = conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1)
+    M = n * ho * wo
+    z = torch.empty((n, ho, wo, 64), device=x4.device, dtype=torch.bfloat16)
+    ts = torch.empty((M // 128, 2, 64), device=x4.device, dtype=torch.float32)
+    ops.PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats_bf16", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), stream()))
+    st = ops.BNState()
+    st.training = True
+    buf = torch.empty((4, 64), device=x4.device, dtype=torch.float32)
+    st.scale, st.shift, st.mean, st.invstd = buf[0], buf[1], buf[2], buf[3]
+    call("uem_bn_stats_from_tiles", ptr(ts), M // 128, M, 64, ptr(bn.weight.detach()), ptr(bn.bias.detach()), float(bn.eps),
+         float(bn.momentum if bn.momentum is not None else 0.1), ptr(bn.running_mean), ptr(bn.running_var),
+         ptr(st.mean), ptr(st.invstd), ptr(st.scale), ptr(st.shift), stream())
+    return z, st
+
+
+def maxpool_affine_fwd(z, st, want_idx):
+    """maxpool3x3s2(relu(z*scale + shift)) on the bf16 z -> bf16 pooled map (+ argmax taps)."""
+    n, h, w, c = z.shape
+    ho, wo = conv_out_size(h, 3, 2, 1, 1), conv_out_size(w, 3, 2, 1, 1)
+    y = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.bfloat16)
+    idx = torch.empty((n, ho, wo, c), device=z.device, dtype=torch.uint8) if want_idx else None
+    call("uem_maxpool3x3s2_affine_fwd_bf16", ptr(z), ptr(st.scale), ptr(st.shift), ptr(y), ptr(idx), n, h, w, c, stream())
+    return y, idx
+
+
+def bn_backward_pooled(z, dy_pool, idx, st, gamma_grad, beta_grad):
+    """ops.bn_backward_pooled on bf16 tensors: z bf16, pooled gradient bf16 -> dz bf16."""
+    n, h, w, c = z.shape
+    tmp = torch.empty((2, c), device=z.device, dtype=torch.float32)
+    ws = torch.empty(_lib.load().uem_bn_workspace_floats(n * h * w, c), device=z.device, dtype=torch.float32)
+    call("uem_bn_bwd_reduce_pool_bf16", ptr(z), ptr(dy_pool), ptr(idx), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         n, h, w, c, 1, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), ptr(ws), stream())
+    dz = torch.empty_like(z)
+    call("uem_bn_bwd_apply_pool_bf16", ptr(z), ptr(dy_pool), ptr(idx), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
+         ptr(tmp[0]), ptr(tmp[1]), n, h, w, c, 1, ptr(dz), stream())
+    return dz
+
+
+def stem_wgrad(x4, dz, dw_ohwi):
+    if dw_ohwi is None:                      # frozen stem
+        return
+    n, h, w, _ = x4.shape
+    dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+    ops.PROF.run("conv_wgrad", 2.0 * dz.numel() * 147, lambda: call("uem_conv2d_stem_wgrad_bf16", ptr(x4), ptr(dz), ptr(dw8), n, h, w, stream()))
+    call("uem_stem_unpack_grad", ptr(dw8), ptr(dw_ohwi), stream())
+
+
+def instnorm_fwd(x, eps=1e-5):
+    """InstanceNorm of the bf16 layer4 output -> fp32 features (+ invstd for the backward)."""
+    n, h, w, c = x.shape
+    _bf16c(x, "instnorm_fwd_bf16 x")
+    y = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32)
+    stats = torch.empty((2, n, c), device=x.device, dtype=torch.float32)
+    call("uem_instnorm_fwd_bf16", ptr(x), ptr(y), ptr(stats[0]), ptr(stats[1]), n, h * w, c, eps, stream())
+    return y, stats[1]
+
+
+def instnorm_bwd(y, dy, invstd):
+    """-> the bf16 gradient of the InstanceNorm's bf16 input"""
+    n, h, w, c = y.shape
+    dx = torch.empty((n, h, w, c), device=y.device, dtype=torch.bfloat16)
+    call("uem_instnorm_bwd_bf16", ptr(y), ptr(dy), ptr(invstd), ptr(dx), n, h * w, c, stream())
+    return dx
+
+
 # ---- fp32 <-> bf16 ---------------------------------------------------------------------------------------------
 def to_bf16(x, out=None):
     need_gpu(x)

@@ -181,26 +181,33 @@ class ResNetEncoder(nn.Module):
     # bf16 matrix cores with fp32 accumulation, fp32 master weights (BASELINE config 5; training mode only)
     storage = "fp32"
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, last_bf16=False):
+        """-> the four stage outputs (NHWC).  last_bf16 (bf16 storage only): leave the layer4 output in bf16 for a consumer that
+        reads bf16 itself (Deeplabv2's InstanceNorm: blocks_bf16.InstNormBf16Fn); otherwise it is cast to fp32 here."""
         r = self.resnet
         params = [r.conv1.weight, r.bn1.weight, r.bn1.bias]
         # bf16 storage: the training step, and (round 3) inference under torch.no_grad() -- the offline pseudo-label pass and
         # evaluation; an eval-mode forward that records a graph stays fp32
         bf16 = self.storage == "bf16" and (self.training or not torch.is_grad_enabled())
-        blocks.StemFn.prec = "bf16" if (bf16 and self.training) else None   # bf16 operands for the stem conv in training (fp32 in memory)
-        try:
-            y = blocks.StemFn.apply(x, r, *params)
-        finally:
-            blocks.StemFn.prec = None
         if bf16:
-            from .models.blocks_bf16 import CastFn
-            y = CastFn.apply(y, True)
+            from .models.blocks_bf16 import CastFn, StemBf16Fn
+            from . import ops_bf16 as ob
+        if bf16 and self.training and ob.stem_ok(x.shape, r.bn1):
+            y = StemBf16Fn.apply(x, r, *params)            # round 5: the stem's z, pooled map and gradients in bf16 (no cast)
+        else:
+            blocks.StemFn.prec = "bf16" if (bf16 and self.training) else None   # bf16 operands for the stem conv in training (fp32 in memory)
+            try:
+                y = blocks.StemFn.apply(x, r, *params)
+            finally:
+                blocks.StemFn.prec = None
+            if bf16:
+                y = CastFn.apply(y, True)
         outs = []
         for layer, with_cp in zip((r.layer1, r.layer2, r.layer3, r.layer4), self.config.with_cp):
             y = self._run_layer(layer, y, with_cp)
             outs.append(y)
-        if bf16:
-            outs[-1] = CastFn.apply(outs[-1], False)       # InstanceNorm and the heads stay fp32
+        if bf16 and not last_bf16:
+            outs[-1] = CastFn.apply(outs[-1], False)       # the heads stay fp32
         return outs
 
     def forward(self, inputs):                                                  # resnet.py:140-166
