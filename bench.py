@@ -272,13 +272,30 @@ def roofline_of(prof, peak, traffic_for=None):
 def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
     """The same step captured in ONE hipGraph and replayed (uemda_amd.step.GraphedStep): device time per step and what the host
     spends per step.  An extra leg: never the headline `value`, and never allowed to cost the line."""
+    from uemda_amd.step import GraphedStep, ssl_step as _ssl, src_step as _src
+    gs, err = None, None
     try:
-        from uemda_amd.step import GraphedStep, ssl_step as _ssl, src_step as _src
         kw = dict(sup_ignore_id=s.sup_ignore) if workload == "ssl" else {}
         if s.wrapper is not None:
             kw["dp"] = s.wrapper                   # the data-parallel step: RCCL's all-reduces are captured with it
         gs = GraphedStep(_ssl if workload == "ssl" else _src, s.model, s.aligner if workload == "ssl" else None, s.opt, s.state,
                          s.batch, warmup=1, lr=s.lr_at(step0), **kw)
+    except Exception as e:                    # noqa: BLE001
+        err = repr(e)[:300]
+    # data parallel: replay only a graph that EVERY rank holds (a rank replaying alone would launch collectives nobody joins); the
+    # ranks agree through one eager all-reduce of a flag, and fall back to "no graph leg" together
+    if s.wrapper is not None and not GraphedStep.all_ranks_ok(gs is not None):
+        s.opt.lr_device = None
+        del gs
+        gc.collect()
+        torch.cuda.empty_cache()
+        return dict(skipped="the capture did not succeed on every rank: no rank replays", error_on_this_rank=err)
+    if gs is None:
+        s.opt.lr_device = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        return dict(error=err)
+    try:
         gs(s.lr_at(step0))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -358,7 +375,8 @@ def main():
     ap.add_argument("--no-other-precisions", action="store_true", help="accepted and ignored (the operand-precision legs are retired)")
     ap.add_argument("--unique-batches", type=int, default=2, help="distinct seeded batches alternating step by step")
     ap.add_argument("--no-hipgraph", action="store_true", help="skip the short leg that replays the step as one hipGraph")
-    ap.add_argument("--hipgraph-dp", action="store_true", help="run the hipGraph leg under data parallel too (nccl backend: the all-reduces are captured)")
+    ap.add_argument("--hipgraph-dp", action="store_true", help="accepted and ignored: the hipGraph leg now runs under data parallel by default "
+                    "(nccl backend: the all-reduces are captured; the ranks agree on the capture's success before anyone replays)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configurations (bf16 storage, PPM head, R101 1024^2; N=1 only)")
     args = ap.parse_args()
@@ -469,9 +487,10 @@ def main():
     ops.PROF.records = []
 
     graph_leg = None
-    # data parallel: RCCL's all-reduces are captured with the step (GraphedStep(dp=...)); under N > 1 the leg is opt-in (--hipgraph-dp):
-    # a capture that fails on one rank only would leave the others waiting in a collective, and no multi-GPU box exists to rehearse it
-    if not args.no_hipgraph and (wrapper is None or (args.hipgraph_dp and wrapper.capturable)):
+    # data parallel: RCCL's all-reduces are captured with the step (GraphedStep(dp=...)).  Every rank attempts the capture, the ranks
+    # agree on its success (GraphedStep.all_ranks_ok: one eager MIN all-reduce) and replay only a graph all of them hold, so the leg is
+    # on by default under N > 1 too (round 4: opt-in); gloo groups (host round trip) have nothing to capture and skip it
+    if not args.no_hipgraph and (wrapper is None or wrapper.capturable):
         graph_leg = replay_leg(s, args.workload, args.warmup + args.steps, tiles_per_step)
         if rank == 0:
             note(f"hipGraph replay: {graph_leg}")

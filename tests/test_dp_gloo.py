@@ -285,3 +285,29 @@ def test_weak_scaling_accounting():
     """bench.py counts source + target tiles of every rank per step (value = whole-job tiles/s)."""
     B, world, steps, elapsed = 32, 8, 5, 2.0
     assert (2 * B) * world * steps / elapsed == 1280.0
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from uemda_amd import dp
+    from uemda_amd.step import GraphedStep
+    dp.init("gloo")
+    every = GraphedStep.all_ranks_ok(True)
+    one_failed = GraphedStep.all_ranks_ok(rank != world - 1)          # the last rank's capture "raised"
+    none = GraphedStep.all_ranks_ok(False)
+    out.put((rank, every, one_failed, none))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", WORLDS)
+def test_graph_capture_agreement_across_ranks(world):
+    """GraphedStep.all_ranks_ok (VERDICT r4 item 7): a captured data-parallel step may be replayed only if EVERY rank holds the graph;
+    one rank whose capture failed turns the answer to False on all of them, so they fall back to the eager step together."""
+    res = _spawn(_agree_worker, world)
+    assert all(r[1] is True and r[2] is False and r[3] is False for r in res)
+
+
+def test_graph_capture_agreement_without_a_process_group():
+    from uemda_amd.step import GraphedStep
+    assert GraphedStep.all_ranks_ok(True) is True and GraphedStep.all_ranks_ok(False) is False

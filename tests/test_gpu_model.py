@@ -260,8 +260,9 @@ def test_batchnorm_stats_apply_backward(Cn, M):
         dx = ops.bn_backward(xd, gy.cuda(), st, gg, gb, relu=True, **kw)
         torch.testing.assert_close(dx.cpu()[:, calm][away[:, calm]], x.grad[:, calm][away[:, calm]], rtol=1e-3, atol=1e-4)
         assert away.float().mean() > 0.999
-        torch.testing.assert_close(gg.cpu(), gamma.grad, rtol=5e-3, atol=1e-3)   # a flipped mask moves one channel's sum
-        torch.testing.assert_close(gb.cpu(), beta.grad, rtol=5e-3, atol=1e-3)
+        # (a channel with a pre-activation on the kink may flip one mask: its two sums move by that element's gradient)
+        torch.testing.assert_close(gg.cpu()[calm], gamma.grad[calm], rtol=5e-3, atol=1e-3)
+        torch.testing.assert_close(gb.cpu()[calm], beta.grad[calm], rtol=5e-3, atol=1e-3)
 
 
 def test_maxpool_and_instnorm_vs_torch():

@@ -2228,7 +2228,9 @@ static int conv_bf16_big_bn(const ConvP& p) {
     static const int min_kt = getenv("UEM_CONV_BF16_BIG_MIN_KT") ? atoi(getenv("UEM_CONV_BF16_BIG_MIN_KT")) : 16;
     const bool extras = MODE == 1 && (p.accumulate || p.acc_src || p.tile_bnbwd);
     if (set == 1) return (!extras && p.Cout % 256 == 0) ? 256 : 128;
-    if (KT < min_kt) return 0;
+    // the fused data-gradient epilogues (residual tail, BatchNorm-backward partial sums) LOSE on 256-row tiles: with one block per CU
+    // nothing covers their three extra streams (R101 1024^2 step: forward family 46.9 -> 44.9 ms, data gradient 54.4 -> 56.4)
+    if (KT < min_kt || extras) return 0;
     if (!extras && p.Cout % 256 == 0 && rows * (p.Cout / 256) >= min_tiles) return 256;
     return rows * (p.Cout / 128) >= min_tiles ? 128 : 0;
 }

@@ -114,18 +114,21 @@ __global__ __launch_bounds__(256) void pearson_rows_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float eps = 1e-7f;
     const float inv_k = 1.0f / (float)k, inv_km1 = 1.0f / (float)(k - 1), inv_km1e = 1.0f / ((float)(k - 1) + eps);
-    // the wave's first pair of rows is requested before anything else: the loads fly under the prologue
-    float4 a[KV], b[KV];
+    // Two register sets: the wave's NEXT pair of rows is requested before the current pair is computed on, so each wave always has
+    // 16 KB in flight (the one-set form left a wave with nothing outstanding for the ~1100 instructions of its compute phase; at
+    // three waves per SIMD the HBM stream was ~3.8 TB/s).  The first pair is requested before the prologue.
+    float4 a[KV], b[KV], a2[KV], b2[KV];
+    const int stride = gridDim.x * 8;
     int r0 = (blockIdx.x * 4 + wave) * 2;
-    auto request = [&](int r) {
+    auto request = [&](int r, float4 (&ra)[KV], float4 (&rb)[KV]) {
         if (r < n) {
             const float4* x0 = reinterpret_cast<const float4*>(feat + (size_t)r * k) + lane;
             const float4* x1 = reinterpret_cast<const float4*>(feat + (size_t)((r + 1) < n ? r + 1 : r) * k) + lane;
 #pragma unroll
-            for (int i = 0; i < KV; ++i) { a[i] = x0[i * 64]; b[i] = x1[i * 64]; }
+            for (int i = 0; i < KV; ++i) { ra[i] = x0[i * 64]; rb[i] = x1[i * 64]; }
         }
     };
-    request(r0);
+    request(r0, a, b);
     // prologue: wave w centres classes w, w + 4, ... into the LDS image (16-byte loads, the whole prototype in flight at once)
     for (int c = wave; c < C; c += 4) {
         const float4* p = reinterpret_cast<const float4*>(protos + (size_t)c * k) + lane;
@@ -147,22 +150,22 @@ __global__ __launch_bounds__(256) void pearson_rows_kernel(const float* __restri
         if (lane == 0) pstd_s[c] = sqrtf(ss * inv_km1);
     }
     __syncthreads();
-    for (; r0 < n; r0 += gridDim.x * 8) {
-        const bool has1 = (r0 + 1) < n;
+    auto compute = [&](const int r, float4 (&ra)[KV], float4 (&rb)[KV]) {
+        const bool has1 = (r + 1) < n;
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < KV; ++i) {
-            s0 += (a[i].x + a[i].y) + (a[i].z + a[i].w);
-            s1 += (b[i].x + b[i].y) + (b[i].z + b[i].w);
+            s0 += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+            s1 += (rb[i].x + rb[i].y) + (rb[i].z + rb[i].w);
         }
         const float m0 = wave_sum_dpp(s0) * inv_k, m1 = wave_sum_dpp(s1) * inv_k;
         float ss0 = 0.f, ss1 = 0.f;
 #pragma unroll
         for (int i = 0; i < KV; ++i) {                             // centred in place
-            a[i].x -= m0; a[i].y -= m0; a[i].z -= m0; a[i].w -= m0;
-            b[i].x -= m1; b[i].y -= m1; b[i].z -= m1; b[i].w -= m1;
-            ss0 = fmaf(a[i].x, a[i].x, fmaf(a[i].y, a[i].y, fmaf(a[i].z, a[i].z, fmaf(a[i].w, a[i].w, ss0))));
-            ss1 = fmaf(b[i].x, b[i].x, fmaf(b[i].y, b[i].y, fmaf(b[i].z, b[i].z, fmaf(b[i].w, b[i].w, ss1))));
+            ra[i].x -= m0; ra[i].y -= m0; ra[i].z -= m0; ra[i].w -= m0;
+            rb[i].x -= m1; rb[i].y -= m1; rb[i].z -= m1; rb[i].w -= m1;
+            ss0 = fmaf(ra[i].x, ra[i].x, fmaf(ra[i].y, ra[i].y, fmaf(ra[i].z, ra[i].z, fmaf(ra[i].w, ra[i].w, ss0))));
+            ss1 = fmaf(rb[i].x, rb[i].x, fmaf(rb[i].y, rb[i].y, fmaf(rb[i].z, rb[i].z, fmaf(rb[i].w, rb[i].w, ss1))));
         }
         ss0 = wave_sum_dpp(ss0);
         ss1 = wave_sum_dpp(ss1);
@@ -172,25 +175,30 @@ __global__ __launch_bounds__(256) void pearson_rows_kernel(const float* __restri
         // hoists all 6 x KV prototype reads to the top -- nothing orders an LDS read -- and the kernel comes out at 243-284 registers.
 #pragma unroll 1
         for (int c = 0; c < C; ++c) {
-            {
-                float d0 = 0.f, d1 = 0.f;
+            float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < KV; ++i) {
-                    const float4 q = *reinterpret_cast<const float4*>(pc + (size_t)c * k + i * 256 + lane * 4);
-                    d0 = fmaf(a[i].x, q.x, fmaf(a[i].y, q.y, fmaf(a[i].z, q.z, fmaf(a[i].w, q.w, d0))));
-                    d1 = fmaf(b[i].x, q.x, fmaf(b[i].y, q.y, fmaf(b[i].z, q.z, fmaf(b[i].w, q.w, d1))));
-                }
-                const float c0 = wave_sum_dpp(d0), c1 = wave_sum_dpp(d1);
-                const float ps = pstd_s[c];
-                const float dist0 = (1.0f - (c0 * inv_km1e) * fast_rcp(std0 * ps + eps)) * 0.5f;
-                const float dist1 = (1.0f - (c1 * inv_km1e) * fast_rcp(std1 * ps + eps)) * 0.5f;
-                if (lane == c) { o0 = INVERT ? fast_rcp(dist0) : dist0; o1 = INVERT ? fast_rcp(dist1) : dist1; }
+            for (int i = 0; i < KV; ++i) {
+                const float4 q = *reinterpret_cast<const float4*>(pc + (size_t)c * k + i * 256 + lane * 4);
+                d0 = fmaf(ra[i].x, q.x, fmaf(ra[i].y, q.y, fmaf(ra[i].z, q.z, fmaf(ra[i].w, q.w, d0))));
+                d1 = fmaf(rb[i].x, q.x, fmaf(rb[i].y, q.y, fmaf(rb[i].z, q.z, fmaf(rb[i].w, q.w, d1))));
             }
+            const float c0 = wave_sum_dpp(d0), c1 = wave_sum_dpp(d1);
+            const float ps = pstd_s[c];
+            const float dist0 = (1.0f - (c0 * inv_km1e) * fast_rcp(std0 * ps + eps)) * 0.5f;
+            const float dist1 = (1.0f - (c1 * inv_km1e) * fast_rcp(std1 * ps + eps)) * 0.5f;
+            if (lane == c) { o0 = INVERT ? fast_rcp(dist0) : dist0; o1 = INVERT ? fast_rcp(dist1) : dist1; }
         }
-        request(r0 + gridDim.x * 8);                                // the next pair's rows fly under this pair's stores and the loop edge
         if (lane < C) {
-            out[(size_t)r0 * C + lane] = o0;
-            if (has1) out[(size_t)(r0 + 1) * C + lane] = o1;
+            out[(size_t)r * C + lane] = o0;
+            if (has1) out[(size_t)(r + 1) * C + lane] = o1;
+        }
+    };
+    for (; r0 < n; r0 += 2 * stride) {                              // two pairs per trip: set A, then set B
+        request(r0 + stride, a2, b2);
+        compute(r0, a, b);
+        if (r0 + stride < n) {
+            request(r0 + 2 * stride, a, b);
+            compute(r0 + stride, a2, b2);
         }
     }
 }

@@ -183,6 +183,23 @@ class GraphedStep:
             self.out = run()
         optimizer._steps = steps_before                  # the capture pass ran the host side of step() without taking a step
 
+    @staticmethod
+    def all_ranks_ok(ok, device=None):
+        """Data parallel: did the capture succeed on EVERY rank?  One MIN all-reduce of a flag, eagerly, outside any capture.  A graph
+        that exists on some ranks only must never be replayed -- its ranks would launch collectives the others never join -- so callers
+        do `gs = try: GraphedStep(...)`, then `if not GraphedStep.all_ranks_ok(gs is not None): gs = None` and every rank falls back
+        to the eager step together (bench.py's replay leg).  The capture itself executes no collective (RCCL's
+        launches are recorded, not run), so a rank whose capture raised leaves nobody waiting."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return bool(ok)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
     def _after_replay(self):
         from . import ops
         self.optimizer._steps += 1
