@@ -36,6 +36,17 @@ if [ -z "$EXTRA" ]; then
   echo "[measure] pmc GRBM"; timeout -k 10 900 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d "$OUT/pmc_grbm" -- python3 bench.py $ARGS --no-kernel-events > "$OUT/pmc_grbm.json" 2> "$OUT/pmc_grbm.err" || exit 1
   python3 scripts/pmc_summary.py "$OUT/pmc_grbm" >> "$OUT/pmc_mfma_busy.txt" 2>&1
 fi
+if [ -z "$EXTRA" ]; then
+  # HBM bytes per conv launch BY SHAPE: the same two counters over ONE timed step whose conv ops are preceded by marker launches
+  echo "[measure] pmc per op"
+  export UEM_PROF_MARK=1
+  PARGS="--steps 1 --warmup 2 --no-cpu-baseline --no-other-configs --no-hipgraph"
+  timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_op_fetch" -- python3 bench.py $PARGS --dump-conv-events "$OUT/ev_fetch.json" > "$OUT/pmc_op_fetch.json" 2> "$OUT/pmc_op_fetch.err" || exit 1
+  timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_op_write" -- python3 bench.py $PARGS --dump-conv-events "$OUT/ev_write.json" > "$OUT/pmc_op_write.json" 2> "$OUT/pmc_op_write.err" || exit 1
+  unset UEM_PROF_MARK
+  python3 scripts/pmc_per_op.py "$OUT/pmc_op_fetch" "$OUT/pmc_op_write" "$OUT/ev_fetch.json" > "$OUT/pmc_traffic_per_shape.txt" 2>&1
+  rm -rf "$OUT/pmc_op_fetch" "$OUT/pmc_op_write"
+fi
 # the raw counter dumps are large: keep the summaries only
 rm -rf "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_grbm" "$OUT/trace"
 echo "[measure] done"

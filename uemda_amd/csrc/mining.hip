@@ -479,18 +479,24 @@ __global__ __launch_bounds__(256) void segment_weight_kernel(const uint32_t* __r
                              4 * q + 3 < C ? v[4 * q + 3] : 0.f);
 }
 
-template <int CMAX, int CEX>
+// MODE_T: the refinement mode when it is `all` with two prediction heads (the training step's call: the mode tests, the absent views'
+// zero fills and the single-head branch fold away); -1 = mode / head count read at run time
+// FULLT: W is a multiple of 256 and H of LR_ROWS -- every thread has a pixel in every row, no validity tests
+template <int CMAX, int CEX, int MODE_T = -1, bool FULLT = false>
 __global__ __launch_bounds__(256) void label_refine_kernel(
     const float* __restrict__ soft, const int64_t* __restrict__ sup, const float* __restrict__ sim,
-    const float* __restrict__ lg1, const float* __restrict__ lg2, const float* __restrict__ segw,
+    const float* __restrict__ lg1, const float* __restrict__ lg2_, const float* __restrict__ segw,
     const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C_, int h,
-    int w, int H, int W, int S, float inv_temp, int mode, int ncell) {
+    int w, int H, int W, int S, float inv_temp, int mode_, int ncell) {
     const int C = CEX > 0 ? CEX : C_;
+    const int mode = MODE_T >= 0 ? MODE_T : mode_;
+    const float* const lg2 = lg2_;
+    const bool two_heads = MODE_T >= 0 ? true : lg2_ != nullptr;
     extern __shared__ __attribute__((aligned(16))) float lowres[];       // [LR_ROWS][3 maps][ncell][CMAX], interpolated in y
     const int b = blockIdx.z, Y0 = blockIdx.y * LR_ROWS, X0 = blockIdx.x * 256;
     const size_t plane = (size_t)H * W;
     const int X = X0 + threadIdx.x;
-    const bool active = X < W;
+    const bool active = FULLT || X < W;
     const bool use_sup = mode == UEM_REFINE_ALL || mode == UEM_REFINE_S;
     // ---- this thread's pixels (one per row of the block): operands requested first, consumed last ---------------------------
     int64_t id[LR_ROWS];
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     bool rowok[LR_ROWS];
 #pragma unroll
     for (int r = 0; r < LR_ROWS; ++r) {
-        rowok[r] = active && (Y0 + r) < H;
+        rowok[r] = FULLT || (active && (Y0 + r) < H);
         id[r] = 0;
         if (rowok[r] && use_sup) id[r] = sup[(size_t)b * plane + (size_t)(Y0 + r) * W + X];
     }
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
         if (mode == UEM_REFINE_ALL || mode == UEM_REFINE_L) {          // prediction view
             float v[CMAX];
             xlerp_lds<CMAX>(s_l1, C, c0, lx, v);
-            if (lg2 != nullptr) {
+            if (two_heads) {
                 float u[CMAX];
                 xlerp_lds<CMAX>(s_l2, C, c0, lx, u);
                 // 0.5 * (softmax(x1/T) + softmax(x2/T)), then max-normalise
@@ -682,18 +688,23 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
     float* blockmax = workspace;
     float* segw = workspace + (size_t)B * grid.x * grid.y * cmax;
     const int64_t nseg = (int64_t)B * S;
-#define LAUNCH_LR(CM, CE)                                                                                                        \
+#define LAUNCH_LR(CM, CE, MT, FT)                                                                                                \
     do {                                                                                                                         \
         if (use_sup)                                                                                                             \
             segment_weight_kernel<CM, CE><<<(unsigned)uem_cdiv(nseg, 256), 256, 0, st>>>(seg_keys, segw, nseg, C, 1.0f / temp);    \
-        if (uem_allow_lds((const void*)label_refine_kernel<CM, CE>, lds))                                                         \
-            label_refine_kernel<CM, CE><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, segw, ignore_id, soft_out,     \
-                                                                blockmax, C, h, w, H, W, S, 1.0f / temp, mode, ncell);          \
+        if (uem_allow_lds((const void*)label_refine_kernel<CM, CE, MT, FT>, lds))                                                 \
+            label_refine_kernel<CM, CE, MT, FT><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, segw, ignore_id,       \
+                                                                        soft_out, blockmax, C, h, w, H, W, S, 1.0f / temp, mode, \
+                                                                        ncell);                                                 \
     } while (0)
-    if (C == 6) LAUNCH_LR(8, 6);
-    else if (C == 7) LAUNCH_LR(8, 7);
-    else if (C <= 8) LAUNCH_LR(8, 0);
-    else LAUNCH_LR(16, 0);
+    // train_ssl_uem.py:209-214: all three views, two heads, on whole 256 x LR_ROWS pixel blocks
+    const bool train_call = mode == UEM_REFINE_ALL && logits2 != nullptr && W % 256 == 0 && H % LR_ROWS == 0;
+#define LAUNCH_LR3(CM, CE, MT) LAUNCH_LR(CM, CE, MT, false)
+    if (C == 6) { if (train_call) LAUNCH_LR(8, 6, UEM_REFINE_ALL, true); else LAUNCH_LR3(8, 6, -1); }
+    else if (C == 7) { if (train_call) LAUNCH_LR(8, 7, UEM_REFINE_ALL, true); else LAUNCH_LR3(8, 7, -1); }
+    else if (C <= 8) LAUNCH_LR3(8, 0, -1);
+    else LAUNCH_LR3(16, 0, -1);
+#undef LAUNCH_LR3
 #undef LAUNCH_LR
     blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(blockmax, plane_max, (int)(grid.x * grid.y), C, cmax);
     return uem_check_launch("label_refine");

@@ -92,11 +92,20 @@ class _Profiler:
         self.enabled = False
         self.records = []          # (family, algorithmic flops, start event, end event)
 
+    # UEM_PROF_MARK=1: a one-element marker launch (scale_kernel) in front of every profiled conv op, so that a rocprofv3 --pmc pass of
+    # the same command can be cut into ops by dispatch order (scripts/pmc_per_op.py: HBM bytes per conv launch BY SHAPE)
+    MARK = os.environ.get("UEM_PROF_MARK", "0") != "0"
+    _mark = None
+
     def run(self, family, flops, launch, executed=None):
         """flops: ALGORITHMIC flops of the op (2*M*Cout*k*k*Cin); executed: the multiplies actually issued where they differ
         (Winograd: algorithmic / 2.25)."""
         if not self.enabled:
             return launch()
+        if self.MARK:
+            if self._mark is None:
+                _Profiler._mark = torch.ones(1, device="cuda")
+            call("uem_scale", ptr(self._mark), 1, 1.0, stream())
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = launch()
@@ -104,6 +113,10 @@ class _Profiler:
         fr = sys._getframe(1)
         t = fr.f_locals.get("dy", fr.f_locals.get("x"))               # label for per_call(): calling op + its input's shape
         who = fr.f_code.co_name + ("" if t is None else " " + "x".join(str(d) for d in t.shape))
+        if self.MARK:                                                 # ... and, for the byte table, the other side's channels and taps
+            lo = fr.f_locals
+            if "cout" in lo and "cin" in lo:
+                who += f" ->{lo['cout'] if fr.f_code.co_name.find('dgrad') < 0 else lo['cin']} k{lo.get('kh', 3)}"
         self.records.append((family, flops, s, e, flops if executed is None else executed, who))
         return out
 
