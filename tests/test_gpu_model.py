@@ -657,6 +657,48 @@ def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage
     assert int(m1.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == int(m2.state_dict()["encoder.resnet.bn1.num_batches_tracked"]) == 10
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_side_stream_weight_gradients_equal_the_serial_backward(storage):
+    """Round 5: the weight gradients run on a side stream beside the data-gradient chain (ops.on_side).  The same step with the side
+    stream on and off, from the same state, must give the same losses, labels and update -- to the order of the fp32 atomics the
+    weight-gradient kernels accumulate with, which two SERIAL runs differ by as well -- and the allocator must not hand a tensor the
+    side stream still reads to the main stream (a NaN-filled allocation pattern between the steps would show)."""
+    from oracle import synth
+    from uemda_amd import ops, ops_bf16 as ob
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, ssl_step
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
+
+    def run(side):
+        saved = ops.SIDE_WGRAD_F32, ob.SIDE_WGRAD
+        ops.SIDE_WGRAD_F32 = ob.SIDE_WGRAD = side
+        try:
+            model = _model(False).set_storage(storage)
+            al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+            al.prototypes = batch["prototypes"].clone()
+            opt = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4)
+            n = model.flat_parameters()[2]
+            w0 = model.flat_parameters()[0][:n].clone()
+            # ONE step: its forward is deterministic, so losses and labels must be equal and the update differs by the order of the
+            # weight-gradient atomics only (a second step on this B = 2 network amplifies that to percents, serial or not)
+            out = ssl_step(model, al, opt, StepState(C), batch, 3e-3, sup_ignore_id=256)
+            torch.cuda.synchronize()
+            return out, (model.flat_parameters()[0][:n] - w0).double(), al.prototypes.clone()
+        finally:
+            ops.SIDE_WGRAD_F32, ob.SIDE_WGRAD = saved
+    o1, u1, p1 = run(True)
+    o0, u0, p0 = run(False)
+    o0b, u0b, _ = run(False)                                          # how far two serial runs are from each other
+    noise = float((u0 - u0b).norm() / u0.norm())
+    diff = float((u1 - u0).norm() / u0.norm())
+    print(f"{storage}: side-stream against serial update {diff:.2e}; serial against serial {noise:.2e}")
+    assert torch.isfinite(u1).all() and diff < max(5.0 * noise, 1e-5), (diff, noise)
+    assert float(o1["loss_source"]) == float(o0["loss_source"]) and float(o1["loss_target"]) == float(o0["loss_target"])
+    assert torch.equal(o1["label_t_hard"], o0["label_t_hard"])
+    torch.testing.assert_close(p1, p0, rtol=1e-4, atol=1e-5)
+
+
 def test_graphed_step_outlives_another_model_whose_filter_banks_its_refresh_launch_covers():
     """the ONE weight-preparation launch a graph captures covers every live job on the device -- also those of a second
     model (a teacher, an evaluation copy) that was alive at capture time.  When that model is dropped afterwards and an eager request

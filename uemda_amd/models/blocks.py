@@ -207,7 +207,7 @@ class BottleneckFn(Function):
         else:
             kw = dict(ymask_bits=ybits) if packed else dict(ymask=ybits)
             dz3 = ops.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=True, dres=dp, **kw)
-        ops.conv2d_wgrad(z2, dz3, G(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True)
+        ops.conv2d_wgrad(z2, dz3, G(blk.conv3.weight), in_scale=st2.scale, in_shift=st2.shift, in_relu=True, side=True)
         dz2 = ops.conv2d_dgrad_bn_backward(dz3, ops.weight_transpose_cached(blk.conv3.weight), z2, st2, gb(blk.bn2.weight),
                                            gb(blk.bn2.bias))
         del dz3
@@ -215,11 +215,11 @@ class BottleneckFn(Function):
         if plan is not None and plan.mb:
             mb = plan.mb
             if plan.keep_v:
-                ops.conv3x3_wino_wgrad(sv[-1], dz2, G(blk.conv2.weight), d)
+                ops.conv3x3_wino_wgrad(sv[-1], dz2, G(blk.conv2.weight), d, side=True)
             elif plan.wgrad:
-                ops.conv3x3_wino_wgrad(None, dz2, G(blk.conv2.weight), d, x=z1, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, m=mb)
+                ops.conv3x3_wino_wgrad(None, dz2, G(blk.conv2.weight), d, x=z1, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, m=mb, side=True)
             else:
-                ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
+                ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, side=True)
             if not plan.dgrad:
                 dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose_cached(blk.conv2.weight), z1, st1, gb(blk.bn1.weight),
                                                    gb(blk.bn1.bias), stride=s, pad=d, dil=d)
@@ -229,11 +229,11 @@ class BottleneckFn(Function):
                 da1, _ = ops.conv3x3_wino_dgrad(dz2, blk.conv2.weight, d, m=mb)
                 dz1 = ops.bn_backward(z1, da1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias), None, True, dx=da1)
         else:
-            ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True)
+            ops.conv2d_wgrad(z1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, in_scale=st1.scale, in_shift=st1.shift, in_relu=True, side=True)
             dz1 = ops.conv2d_dgrad_bn_backward(dz2, ops.weight_transpose_cached(blk.conv2.weight), z1, st1, gb(blk.bn1.weight),
                                                gb(blk.bn1.bias), stride=s, pad=d, dil=d)
         del dz2
-        ops.conv2d_wgrad(x, dz1, G(blk.conv1.weight))
+        ops.conv2d_wgrad(x, dz1, G(blk.conv1.weight), side=True)
         wt1 = ops.weight_transpose_cached(blk.conv1.weight)
         # the previous block's bn3 reduction rides in OUR last data-gradient launch when that launch has full dense tiles
         li = ctx.link_in
@@ -245,7 +245,7 @@ class BottleneckFn(Function):
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
             kw = dict(ymask_bits=ybits) if packed else dict(ymask=ybits)
             dzd = ops.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=True, dx=dy if own else None, **kw)
-            ops.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s)
+            ops.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s, side=True)
             wtd = ops.weight_transpose_cached(ds_conv.weight)
             if s == 1 and tail_ok:
                 dx = ops.conv2d_dgrad(dzd, wtd, x.shape)
@@ -263,6 +263,7 @@ class BottleneckFn(Function):
             li.hand_over(dx, tp)
         cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
         if cb is not None:
+            ops.side_join()                                 # side-stream weight gradients (if any) land before a bucket goes out
             cb()
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 

@@ -127,14 +127,14 @@ class BottleneckBf16Fn(Function):
             dz3, dp = ob.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits, want_dres=True)
         else:
             dz3 = ob.bn_backward(z3, dy, st3, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits)
-        ob.conv2d_wgrad(a2, dz3, G(blk.conv3.weight))
+        ob.conv2d_wgrad(a2, dz3, G(blk.conv3.weight), side=True)
         dz2 = ob.conv2d_dgrad_bn_backward(dz3, ob.weight_t(blk.conv3.weight), z2, st2, gb(blk.bn2.weight), gb(blk.bn2.bias))
         del dz3
-        ob.conv2d_wgrad(a1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d)
+        ob.conv2d_wgrad(a1, dz2, G(blk.conv2.weight), stride=s, pad=d, dil=d, side=True)
         dz1 = ob.conv2d_dgrad_bn_backward(dz2, ob.weight_t(blk.conv2.weight), z1, st1, gb(blk.bn1.weight), gb(blk.bn1.bias),
                                           stride=s, pad=d, dil=d)
         del dz2
-        ob.conv2d_wgrad(x, dz1, G(blk.conv1.weight))
+        ob.conv2d_wgrad(x, dz1, G(blk.conv1.weight), side=True)
         wt1 = ob.weight_t(blk.conv1.weight)
         li = ctx.link_in
         fuse = li is not None and li.z3.shape == x.shape and tail_ok
@@ -144,7 +144,7 @@ class BottleneckBf16Fn(Function):
             zd, std = sv[10], _st_from(sv[11], ctx.training)
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
             dzd = ob.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=2, bits=bits, dx=dy if own else None)
-            ob.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s)
+            ob.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s, side=True)
             wtd = ob.weight_t(ds_conv.weight)
             if s == 1 and tail_ok:
                 dx = ob.conv2d_dgrad(dzd, wtd, x.shape)
@@ -161,5 +161,6 @@ class BottleneckBf16Fn(Function):
             li.hand_over(dx, tp)
         cb = getattr(blk, "_uem_after_backward", None)      # data-parallel bucket trigger (uemda_amd.dp)
         if cb is not None:
+            ob.side_join()                                  # the bucket may go out now: this block's weight gradients first
             cb()
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -97,9 +97,9 @@ class _Profiler:
     MARK = os.environ.get("UEM_PROF_MARK", "0") != "0"
     _mark = None
 
-    def run(self, family, flops, launch, executed=None):
+    def run(self, family, flops, launch, executed=None, who=None):
         """flops: ALGORITHMIC flops of the op (2*M*Cout*k*k*Cin); executed: the multiplies actually issued where they differ
-        (Winograd: algorithmic / 2.25)."""
+        (Winograd: algorithmic / 2.25); who: the op's label when the caller is not the op's own function (a launch closure)."""
         if not self.enabled:
             return launch()
         if self.MARK:
@@ -112,7 +112,7 @@ class _Profiler:
         e.record()
         fr = sys._getframe(1)
         t = fr.f_locals.get("dy", fr.f_locals.get("x"))               # label for per_call(): calling op + its input's shape
-        who = fr.f_code.co_name + ("" if t is None else " " + "x".join(str(d) for d in t.shape))
+        who = (who or fr.f_code.co_name) + ("" if t is None else " " + "x".join(str(d) for d in t.shape))
         if self.MARK:                                                 # ... and, for the byte table, the other side's channels and taps
             lo = fr.f_locals
             if "cout" in lo and "cin" in lo:
@@ -168,6 +168,74 @@ if TRACE_NONFINITE:
         if dirty:
             print(f"[uem trace] {name}: non-finite in {dirty}", flush=True)
         return rc
+
+
+# ---- side stream for the weight gradients (round 5) ---------------------------------------------------------------------------
+# The weight gradients are leaves of the backward graph: nothing downstream reads them before the optimizer or the gradient
+# all-reduce.  ops_bf16 runs them beside the data-gradient / BatchNorm chain (every bf16 conv launch is short and latency-bound: two
+# side by side fill each other's ramps and tails, -1.0 ms of 39.6); the fp32 kernels are long and matrix-bound and gain less (-0.5 ms
+# of 101: the Winograd weight gradient's HBM-bound transforms run under the main chain's GEMMs); UEM_SIDE_WGRAD=0 / UEM_BF16_SIDE_WGRAD=0
+# switch it off.  Ordering: the side stream waits for everything the main stream has queued at the call, the tensors the launch reads
+# are recorded on it (the caching allocator will not hand their memory out again before the launch has run), and the main stream waits
+# for the side stream once per backward pass -- an autograd end-of-backward callback -- and before a data-parallel bucket goes out.
+SIDE_WGRAD_F32 = os.environ.get("UEM_SIDE_WGRAD", "1") != "0"
+
+
+class _Side:
+    by_device = {}
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.queued = False              # an end-of-backward join is pending
+        self.dirty = False               # work was queued since the last join
+
+    @classmethod
+    def get(cls):
+        dev = torch.cuda.current_device()
+        st = cls.by_device.get(dev)
+        if st is None:
+            st = cls.by_device[dev] = _Side()
+        return st
+
+    def join(self):
+        self.queued = False
+        if self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+
+
+def side_join():
+    """main stream waits for the side stream's weight gradients (no-op when none are pending): the data-parallel bucket trigger calls
+    this before a slice of the gradient arena goes out; the end-of-backward callback is the same call"""
+    st = _Side.by_device.get(torch.cuda.current_device())
+    if st is not None:
+        st.join()
+
+
+def on_side(launch, tensors):
+    st = _Side.get()
+    main = torch.cuda.current_stream()
+    if main == st.stream:
+        return launch()
+    st.stream.wait_stream(main)
+    with torch.cuda.stream(st.stream):
+        launch()
+    for t in tensors:
+        t.record_stream(st.stream)
+    st.dirty = True
+    if not st.queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(st.join)
+            st.queued = True
+        except RuntimeError:             # not inside a backward pass (a direct call from a test or a script): join right away
+            st.join()
+
+
+
+def in_backward():
+    """inside an autograd backward pass -- and not under per-launch event timing: `PROF` prices a family by the events around its
+    launches, which means something only while the launches run one after the other, so the one profiled step of bench.py runs serially"""
+    return (not torch.is_grad_enabled()) and torch._C._current_graph_task_id() >= 0 and not PROF.enabled
 
 
 def need_gpu(*tensors):
@@ -357,9 +425,11 @@ def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, ymask_bits, 
 
 
 def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift=None, in_relu=False,
-                 algo_cout=None):
+                 algo_cout=None, side=False):
     """dw (Cout,KH,KW,Cin) += dy^T * im2col(prologue(x)).  dw must be contiguous (atomics land in it); None (a frozen
-    weight, blocks.grad_ohwi) skips the launch."""
+    weight, blocks.grad_ohwi) skips the launch.  side: the launch may run on the side stream (on_side) -- ONLY for a dw that nothing on
+    the main stream touches before the end of the backward pass, i.e. a view of the gradient arena (the bottleneck blocks); a
+    temporary that the caller unpacks right away (the ASPP heads' dwall, the PPM classifier's dw4) must stay on the main stream."""
     if dw_ohwi is None:
         return
     need_gpu(x, dy, dw_ohwi)
@@ -370,8 +440,14 @@ def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, in_scale=None, in_shift
         raise UemError("conv2d_wgrad: dy spatial size mismatch")
     flags = (CONV_IN_AFFINE if in_scale is not None else 0) | (CONV_IN_RELU if in_relu else 0) | CONV_PREC_BWD
     flops = 2.0 * s.N * s.Ho * s.Wo * (algo_cout or cout) * kh * kw * cin
-    PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad", ptr(x), ptr(dy), ptr(in_scale), ptr(in_shift),
-                                               ptr(dw_ohwi), ctypes.byref(s), flags, stream()))
+
+    def launch():
+        PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad", ptr(x), ptr(dy), ptr(in_scale), ptr(in_shift),
+                                                   ptr(dw_ohwi), ctypes.byref(s), flags, stream()), who="conv2d_wgrad")
+    if side and SIDE_WGRAD_F32 and in_backward():
+        on_side(launch, [t for t in (x, dy, in_scale, in_shift) if t is not None])
+    else:
+        launch()
 
 
 def weight_transpose(w_ohwi):
@@ -724,7 +800,7 @@ def conv3x3_wino_dgrad_bn_backward(dy, param, z, st, gamma_grad, beta_grad, dil,
     return da
 
 
-def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None, in_relu=False, m=None):
+def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None, in_relu=False, m=None, side=False):
     """dw (Cout,3,3,Cin) += weight gradient from dy (N,H,W,Cout) and the transformed input V (npos, T, Cin) the forward saved; with
     v None, V is recomputed from the conv input x (through the producer's BatchNorm affine + ReLU) at tile edge m."""
     if dw_ohwi is None:
@@ -748,7 +824,11 @@ def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None
         call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, m, stream())
 
     alg, exe = _wino_flops(n * h * w, cout, cin, m)
-    PROF.run("conv_wgrad", alg, run, executed=exe)
+    if side and SIDE_WGRAD_F32 and in_backward():             # side: as in conv2d_wgrad
+        on_side(lambda: PROF.run("conv_wgrad", alg, run, executed=exe, who="conv3x3_wino_wgrad"),
+                [t for t in (v, dy, x, in_scale, in_shift) if t is not None])
+    else:
+        PROF.run("conv_wgrad", alg, run, executed=exe)
 
 
 def nchw3_to_nhwc4(x):

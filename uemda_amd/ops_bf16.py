@@ -9,6 +9,22 @@ from ._lib import CONV_ACCUMULATE, CONV_TRANSPOSED, ConvShape, UemError, call
 from .ops import conv_out_size, need_gpu, ptr, stream
 
 
+import os
+
+# Round 5: the bf16 weight gradients run on a SIDE stream beside the data-gradient / BatchNorm chain of the backward pass.  They
+# are leaves of the backward graph (nothing downstream reads them before the optimizer or the gradient all-reduce), and under bf16
+# storage every conv launch is short (30-90 us, one to four rounds of blocks) and bound by operand delivery and latency, not by HBM or
+# the matrix pipe: two such launches side by side fill each other's ramps and tails.  (The fp32 path dropped the same mechanism in
+# round 2 -- its kernels are 4x longer and matrix-bound: 136.1 against 136.4 ms.)  Ordering: the side stream waits for everything the
+# main stream has queued at the call (the gradient it reads), the tensors it reads are recorded on it (the caching allocator will not
+# hand their memory out again before the launch has run), and the main stream waits for the side stream once per backward pass --
+# an autograd end-of-backward callback -- and before a data-parallel bucket goes out.  UEM_BF16_SIDE_WGRAD=0 switches it off.
+SIDE_WGRAD = os.environ.get("UEM_BF16_SIDE_WGRAD", "1") != "0"
+
+
+_Side, side_join, _on_side = ops._Side, ops.side_join, ops.on_side
+
+
 def _bf16c(t, what):
     if t.dtype != torch.bfloat16 or not t.is_contiguous():
         raise UemError(f"{what}: expected a contiguous bfloat16 tensor, got {t.dtype} strides={t.stride()}")
@@ -100,7 +116,7 @@ def conv2d_dgrad_bn_backward(dy, w_t, z, st, gamma_grad, beta_grad, stride=1, pa
     return bn_backward_from_partials(z, da, st, tp, gamma_grad, beta_grad, relu=1, dx=da)
 
 
-def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1):
+def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, side=False):
     """dw (Cout,KH,KW,Cin) fp32 += dy^T * im2col(x) with bf16 x (N,H,W,Cin) and dy (N,Ho,Wo,Cout)."""
     if dw_ohwi is None:                      # frozen weight (blocks.grad_ohwi)
         return
@@ -117,7 +133,13 @@ def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1):
     s.x_ld, s.y_ld = cin, cout
     flops = 2.0 * n * s.Ho * s.Wo * cout * kh * kw * cin
     try:
-        ops.PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad_bf16", ptr(x), ptr(dy), ptr(dw_ohwi), ctypes.byref(s), stream()))
+        def launch():
+            ops.PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad_bf16", ptr(x), ptr(dy), ptr(dw_ohwi), ctypes.byref(s), stream()),
+                         who="conv2d_wgrad")
+        if side and SIDE_WGRAD and ops.in_backward():            # side: only for gradient-arena views (ops.conv2d_wgrad)
+            _on_side(launch, (x, dy))
+        else:
+            launch()
     except UemError as e:
         if "code -2" not in str(e):
             raise
