@@ -318,8 +318,10 @@ def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
     return leg
 
 
-def short_leg(cfg, steps=3, warmup=2):
-    """One of the `other_configs`: fresh model, `warmup` untimed + `steps` timed steps, per-launch events on the last one."""
+def short_leg(cfg, steps=6, warmup=2):
+    """One of the `other_configs`: fresh model, `warmup` untimed + `steps` timed steps, per-launch events on the last one (that one step
+    runs its weight gradients serially -- ops.in_backward -- so that the family fractions mean something: six steps keep its share of
+    the average at a sixth)."""
     from uemda_amd import ops
     s = Setup(cfg, 0, 1, None)
     for i in range(warmup):
@@ -486,12 +488,22 @@ def main():
             json.dump(ops.PROF.per_call(), f)
     ops.PROF.records = []
 
+    # everything the line reads off the device is read NOW, before the optional legs: a leg that fails badly (a capture left
+    # invalidated took a rehearsal of round 5 down at `float(out["loss_source"])`) must never cost the measured line
+    loss_source_f = float(out["loss_source"])
+    steps_ms_f = [round(a.elapsed_time(b), 2) for a, b in zip(step_events[:-1], step_events[1:])]
+    phases_f = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])} if marks else {}
+    mem_f = torch.cuda.memory_stats()
+
     graph_leg = None
     # data parallel: RCCL's all-reduces are captured with the step (GraphedStep(dp=...)).  Every rank attempts the capture, the ranks
     # agree on its success (GraphedStep.all_ranks_ok: one eager MIN all-reduce) and replay only a graph all of them hold, so the leg is
     # on by default under N > 1 too (round 4: opt-in); gloo groups (host round trip) have nothing to capture and skip it
     if not args.no_hipgraph and (wrapper is None or wrapper.capturable):
-        graph_leg = replay_leg(s, args.workload, args.warmup + args.steps, tiles_per_step)
+        try:
+            graph_leg = replay_leg(s, args.workload, args.warmup + args.steps, tiles_per_step)
+        except Exception as e:                    # noqa: BLE001  (the leg's own clean-up failed: report, keep the line)
+            graph_leg = dict(error=repr(e)[:300])
         if rank == 0:
             note(f"hipGraph replay: {graph_leg}")
 
@@ -532,19 +544,19 @@ def main():
                        "collective": None if wrapper is None else f"torch.distributed {args.backend}",
                        "collective_bytes_per_step": None if wrapper is None else arena_bytes + 4 * (6 * 2048 + 6),
                        "host_cores_per_rank": cores},
-            "loss_source": round(float(out["loss_source"]), 5),
+            "loss_source": round(loss_source_f, 5),
             "roofline": roof,
         }
         if replicas is not None:
             line["replicas_identical"] = replicas["identical"]
             line["replicas"] = replicas
         # device time of every timed step (one HIP event per step boundary) and when the host had finished enqueuing it
-        line["steps_ms"] = [round(a.elapsed_time(b), 2) for a, b in zip(step_events[:-1], step_events[1:])]
+        line["steps_ms"] = steps_ms_f
         line["host_enqueued_at_ms"] = [round(1e3 * t, 1) for t in step_host]
         if marks:
             # per-phase wall time of the last timed step (HIP events on the compute stream) and, for the HBM-bound
             # phases, algorithmic bytes (SURVEY 8d per-tile figures x tiles) over that time
-            ph = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
+            ph = phases_f
             mb = {"label_refine_select": 25.2 * B, "prototype_update": 10.5 * B, "losses_forward": (8.4 + 2.1) * B,
                   "clip_sgd": 5 * 4 * model.flat_parameters()[2] / 1e6}
             line["phases_ms"] = ph
@@ -559,7 +571,7 @@ def main():
                                             measured="HIP events on the compute stream around the phase in the last timed step; bytes = "
                                                      "SURVEY 8(d)'s 25.2 MB per target tile (soft 6.29 + superpixels 2.10 + features 8.39 read, "
                                                      "refined soft 6.29 + hard labels 2.10 written) x tiles")
-        ms = torch.cuda.memory_stats()
+        ms = mem_f
         line["device_memory"] = {"peak_allocated_GB": round(ms.get("allocated_bytes.all.peak", 0) / 1e9, 1),
                                  "peak_reserved_GB": round(ms.get("reserved_bytes.all.peak", 0) / 1e9, 1),
                                  "alloc_retries": int(ms.get("num_alloc_retries", 0))}

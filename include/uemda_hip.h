@@ -118,12 +118,15 @@ int uem_aspp_gather_fwd(const float* G, const float* bias /* [nd][K2] */, float*
                         int R, int nd, const int* dil, void* stream);
 int uem_aspp_gather_bwd(const float* dout, const float* dout2 /* as out2 */, float* dG, int N, int h, int w, int K2, int R, int nd,
                         const int* dil, void* stream);
-/* The heads' filters <-> the GEMM's filter bank in one launch each way: w / b (HOST arrays of 2*nd device pointers, index
+/* The heads' filters <-> the GEMM's filter bank in one launch each way: w / b (HOST arrays of nheads*nd device pointers, index
  * head*nd + d) are the (C,3,3,cin) OHWI filters and (C,) biases of Classifier_Module.conv2d_list (Encoder.py:74-78).
- * pack: wall (R,cin) row (d*9+tap)*2C + head*C + c = w[head][d][c][tap][:], rows >= nd*18*C zero; bias [nd][2][C].
+ * nheads: 2 = the layer5 / layer6 pair of the multi-layer model, 1 = one Classifier_Module (Deeplabv2's single-head default
+ * `cls_pred` and each head of its cascade branch, Encoder.py:93-102,129-143,156-165).
+ * pack: wall (R,cin) row (d*9+tap)*nheads*C + head*C + c = w[head][d][c][tap][:], rows >= nd*9*nheads*C zero; bias [nd][nheads][C].
  * unpack_grad: gw[..] += the matching rows of dwall; gb[head][d][:] += db[head*C ..] (every dilation's bias sees the same gradient). */
-int uem_aspp_pack(void* const* w, void* const* b, float* wall, float* bias, int C, int cin, int nd, int R, void* stream);
-int uem_aspp_unpack_grad(const float* dwall, const float* db, void* const* gw, void* const* gb, int C, int cin, int nd, void* stream);
+int uem_aspp_pack(void* const* w, void* const* b, float* wall, float* bias, int C, int cin, int nd, int R, int nheads, void* stream);
+int uem_aspp_unpack_grad(const float* dwall, const float* db, void* const* gw, void* const* gb, int C, int cin, int nd, int nheads,
+                         void* stream);
 
 /* ---- BatchNorm2d (training + eval), fused ReLU / residual -- _resnets.py:96-110, Encoder.py:20,37 --
  * stats: per-channel batch mean / biased var of x[M][C]; also updates running stats

@@ -51,8 +51,8 @@ SIGNATURES = {
     "uem_bias_grad": [P, P, I, I, I, P],
     "uem_aspp_gather_fwd": [P, P, P, P, I, I, I, I, I, I, POINTER(c_int), P],
     "uem_aspp_gather_bwd": [P, P, P, I, I, I, I, I, I, POINTER(c_int), P],
-    "uem_aspp_pack": [POINTER(c_void_p), POINTER(c_void_p), P, P, I, I, I, I, P],
-    "uem_aspp_unpack_grad": [P, P, POINTER(c_void_p), POINTER(c_void_p), I, I, I, P],
+    "uem_aspp_pack": [POINTER(c_void_p), POINTER(c_void_p), P, P, I, I, I, I, I, P],
+    "uem_aspp_unpack_grad": [P, P, POINTER(c_void_p), POINTER(c_void_p), I, I, I, I, P],
     "uem_bn_stats": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P, P],
     "uem_bn_workspace_floats": [I, I],
     "uem_bn_stats_from_tiles": [P, I, I, I, P, P, F, F, P, P, P, P, P, P, P],

@@ -2091,68 +2091,71 @@ struct AsppPtrs {
     float* b[8];        // (C,) biases / their gradients
 };
 __global__ __launch_bounds__(256) void aspp_pack_kernel(const AsppPtrs ptrs, float* __restrict__ wall, float* __restrict__ bias,
-                                                        const int C, const int cin, const int nd, const int R) {
+                                                        const int C, const int cin, const int nd, const int R, const int nh) {
+    // nh heads (1: Deeplabv2's single-head default and its cascade branch; 2: the layer5 / layer6 pair): row (d*9 + tap)*nh*C + head*C + c
     const int cq = cin / 4;
     const int64_t total = (int64_t)R * cq;
-    const int used = nd * 9 * 2 * C;
+    const int used = nd * 9 * nh * C;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / cq), ci = (int)(i - (int64_t)r * cq) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                        // rows beyond the used columns: zero filters
         if (r < used) {
-            const int c = r % C, head = (r / C) & 1, tap = (r / (2 * C)) % 9, d = r / (18 * C);
+            const int c = r % C, head = (r / C) % nh, tap = (r / (nh * C)) % 9, d = r / (9 * nh * C);
             v = *reinterpret_cast<const float4*>(ptrs.w[head * nd + d] + ((size_t)c * 9 + tap) * cin + ci);
         }
         *reinterpret_cast<float4*>(wall + (size_t)r * cin + ci) = v;
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < nd * 2 * C) {
-        const int t = threadIdx.x, c = t % C, head = (t / C) & 1, d = t / (2 * C);
+    if (blockIdx.x == 0 && (int)threadIdx.x < nd * nh * C) {
+        const int t = threadIdx.x, c = t % C, head = (t / C) % nh, d = t / (nh * C);
         bias[t] = ptrs.b[head * nd + d][c];
     }
 }
 __global__ __launch_bounds__(256) void aspp_unpack_grad_kernel(const float* __restrict__ dwall, const float* __restrict__ db,
-                                                               const AsppPtrs ptrs, const int C, const int cin, const int nd) {
+                                                               const AsppPtrs ptrs, const int C, const int cin, const int nd, const int nh) {
     const int cq = cin / 4;
-    const int used = nd * 9 * 2 * C;
+    const int used = nd * 9 * nh * C;
     const int64_t total = (int64_t)used * cq;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / cq), ci = (int)(i - (int64_t)r * cq) * 4;
-        const int c = r % C, head = (r / C) & 1, tap = (r / (2 * C)) % 9, d = r / (18 * C);
-        // atomics: the two heads may be ONE module (a caller passing the same Classifier_Module twice), their rows then add into
+        const int c = r % C, head = (r / C) % nh, tap = (r / (nh * C)) % 9, d = r / (9 * nh * C);
+        // atomics: two heads may be ONE module (a caller passing the same Classifier_Module twice), their rows then add into
         // the same gradient buffer from different threads
         float* dst = ptrs.w[head * nd + d] + ((size_t)c * 9 + tap) * cin + ci;
         const float4 g = *reinterpret_cast<const float4*>(dwall + (size_t)r * cin + ci);
         atomicAdd(dst + 0, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z); atomicAdd(dst + 3, g.w);
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < nd * 2 * C) {                 // every dilation's bias sees the same output gradient
-        const int t = threadIdx.x, c = t % C, head = (t / C) & 1, d = t / (2 * C);
+    if (blockIdx.x == 0 && (int)threadIdx.x < nd * nh * C) {                // every dilation's bias sees the same output gradient
+        const int t = threadIdx.x, c = t % C, head = (t / C) % nh, d = t / (nh * C);
         atomicAdd(&ptrs.b[head * nd + d][c], db[head * C + c]);
     }
 }
-static int aspp_ptrs(AsppPtrs* q, void* const* w, void* const* b, int C, int cin, int nd, const char* what) {
-    if (!w || !b || C <= 0 || cin <= 0 || cin % 4 != 0 || nd <= 0 || nd > 4 || nd * 2 * C > 256)
-        return uem_fail(UEM_ERR_INVALID, "%s: bad arguments (nd <= 4, nd*2*C <= 256, cin %% 4 == 0)", what);
+static int aspp_ptrs(AsppPtrs* q, void* const* w, void* const* b, int C, int cin, int nd, int nh, const char* what) {
+    if (!w || !b || C <= 0 || cin <= 0 || cin % 4 != 0 || nd <= 0 || nd > 4 || nh < 1 || nh > 2 || nd * nh * C > 256)
+        return uem_fail(UEM_ERR_INVALID, "%s: bad arguments (nd <= 4, 1 <= heads <= 2, nd*heads*C <= 256, cin %% 4 == 0)", what);
     for (int i = 0; i < 8; ++i) {
-        q->w[i] = i < 2 * nd ? (float*)w[i] : nullptr;
-        q->b[i] = i < 2 * nd ? (float*)b[i] : nullptr;
-        if (i < 2 * nd && (!q->w[i] || !q->b[i] || ((uintptr_t)q->w[i] & 15))) return uem_fail(UEM_ERR_INVALID, "%s: null or misaligned filter pointer", what);
+        q->w[i] = i < nh * nd ? (float*)w[i] : nullptr;
+        q->b[i] = i < nh * nd ? (float*)b[i] : nullptr;
+        if (i < nh * nd && (!q->w[i] || !q->b[i] || ((uintptr_t)q->w[i] & 15))) return uem_fail(UEM_ERR_INVALID, "%s: null or misaligned filter pointer", what);
     }
     return UEM_OK;
 }
-extern "C" int uem_aspp_pack(void* const* w, void* const* b, float* wall, float* bias, int C, int cin, int nd, int R, void* stream) {
-    UEM_REQUIRE(wall && bias && R >= nd * 18 * C, "aspp_pack: bad arguments");
+extern "C" int uem_aspp_pack(void* const* w, void* const* b, float* wall, float* bias, int C, int cin, int nd, int R, int nheads,
+                             void* stream) {
+    UEM_REQUIRE(wall && bias && nheads >= 1 && nheads <= 2 && R >= nd * 9 * nheads * C, "aspp_pack: bad arguments");
     AsppPtrs q;
-    const int rc = aspp_ptrs(&q, w, b, C, cin, nd, "aspp_pack");
+    const int rc = aspp_ptrs(&q, w, b, C, cin, nd, nheads, "aspp_pack");
     if (rc) return rc;
-    aspp_pack_kernel<<<uem_stream_grid((int64_t)R * (cin / 4), 256), 256, 0, (hipStream_t)stream>>>(q, wall, bias, C, cin, nd, R);
+    aspp_pack_kernel<<<uem_stream_grid((int64_t)R * (cin / 4), 256), 256, 0, (hipStream_t)stream>>>(q, wall, bias, C, cin, nd, R, nheads);
     return uem_check_launch("aspp_pack");
 }
 extern "C" int uem_aspp_unpack_grad(const float* dwall, const float* db, void* const* gw, void* const* gb, int C, int cin, int nd,
-                                    void* stream) {
+                                    int nheads, void* stream) {
     UEM_REQUIRE(dwall && db, "aspp_unpack_grad: null pointer");
     AsppPtrs q;
-    const int rc = aspp_ptrs(&q, gw, gb, C, cin, nd, "aspp_unpack_grad");
+    const int rc = aspp_ptrs(&q, gw, gb, C, cin, nd, nheads, "aspp_unpack_grad");
     if (rc) return rc;
-    aspp_unpack_grad_kernel<<<uem_stream_grid((int64_t)nd * 18 * C * (cin / 4), 256), 256, 0, (hipStream_t)stream>>>(dwall, db, q, C, cin, nd);
+    aspp_unpack_grad_kernel<<<uem_stream_grid((int64_t)nd * 9 * nheads * C * (cin / 4), 256), 256, 0, (hipStream_t)stream>>>(dwall, db, q, C, cin, nd,
+                                                                                                                       nheads);
     return uem_check_launch("aspp_unpack_grad");
 }
 

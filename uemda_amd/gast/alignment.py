@@ -175,6 +175,8 @@ class Aligner:
         pend = getattr(self, "_oor_pending", None)
         if pend is None or _NO_SUP_CHECK:
             return
+        if torch.cuda.is_current_stream_capturing():
+            return                           # no event may be queried or waited for while a hipGraph is being captured
         ev, host, S, _keep = pend
         if not wait and not ev.query():
             return

@@ -182,12 +182,11 @@ class Deeplabv2(nn.Module):
                 return ppm.ppm_head(feat, head)
             finally:
                 ppm.PPMHeadFn.prec = None
-        # the two-head GEMM with the same module on both sides: the second head's gradient is zero and both halves add into the one
-        # set of parameters (uem_aspp_unpack_grad accumulates with atomics for exactly this case)
+        # one Classifier_Module: the heads' GEMM with half the columns and one output (rounds 1-4 ran the two-head GEMM with
+        # the same module on both sides and discarded the second output)
         blocks.ASPPHeadsFn.prec = "bf16" if bf16 else None
         try:
-            x1, _ = blocks.ASPPHeadsFn.apply(feat, head, head, *list(head.parameters()))
-            return x1
+            return blocks.ASPPHeadsFn.apply(feat, head, None, *list(head.parameters()))
         finally:
             blocks.ASPPHeadsFn.prec = None
 

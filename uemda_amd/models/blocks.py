@@ -289,27 +289,30 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * 8)(*([t.data_ptr() for t in tensors] + [None] * (8 - len(tensors))))
 
 
-def _aspp_pack(head5, head6, feat):
-    """Wall (R, 1, 1, cin): row (d*9 + tap)*2C + head*C + c = W_head,d[c, tap, :]; bias (nd, 2, C) -- one kernel launch."""
-    C = head5.conv2d_list[0].weight.shape[0]
+def _aspp_pack(heads, feat):
+    """Wall (R, 1, 1, cin): row (d*9 + tap)*nh*C + head*C + c = W_head,d[c, tap, :]; bias (nd, nh, C) -- one kernel launch.
+    heads: one or two Classifier_Modules."""
+    nh = len(heads)
+    C = heads[0].conv2d_list[0].weight.shape[0]
     cin = feat.shape[3]
-    nd = len(head5.dilations)
-    used = nd * 9 * 2 * C
+    nd = len(heads[0].dilations)
+    used = nd * 9 * nh * C
     R = (used + 63) // 64 * 64                       # GEMM N tile (64) and dgrad K block (32)
-    if nd > 4 or nd * 2 * C > 256:
-        raise UemError("ASPP heads: at most 4 dilations and 2 * nd * classes <= 256")
+    if nd > 4 or nd * nh * C > 256:
+        raise UemError("ASPP heads: at most 4 dilations and heads * nd * classes <= 256")
     wall = torch.empty((R, cin), device=feat.device, dtype=torch.float32)
-    bias = torch.empty((nd, 2, C), device=feat.device, dtype=torch.float32)
-    convs = [head.conv2d_list[i] for head in (head5, head6) for i in range(nd)]
+    bias = torch.empty((nd, nh, C), device=feat.device, dtype=torch.float32)
+    convs = [head.conv2d_list[i] for head in heads for i in range(nd)]
     ops.call("uem_aspp_pack", _ptr_array([ops.weight_ohwi(c.weight) for c in convs]), _ptr_array([c.bias.detach() for c in convs]),
-             ops.ptr(wall), ops.ptr(bias), C, cin, nd, R, ops.stream())
+             ops.ptr(wall), ops.ptr(bias), C, cin, nd, R, nh, ops.stream())
     return wall.view(R, 1, 1, cin), bias, C, nd, R, used
 
 
 class ASPPHeadsFn(Function):
     """Both Classifier_Module heads (Encoder.py:68-84): the 2 heads x 4 dilations x 9 taps are the columns of
     ONE 1x1 GEMM G = feat x Wall on the MFMA kernel (feat is read once), then a 36-term gather rebuilds the
-    dilated 3x3 sums; see uem_aspp_gather_* in include/uemda_hip.h."""
+    dilated 3x3 sums; see uem_aspp_gather_* in include/uemda_hip.h.  head6 = None: ONE head (the class's single-head default and
+    the cascade branch) -- half the columns, one output (round 5; rounds 1-4 ran the pair with the same module twice)."""
 
     # operand precision of the heads' GEMMs (None = the global setting); Deeplabv2 sets "bf16" for the bf16-storage model
     prec = None
@@ -317,47 +320,53 @@ class ASPPHeadsFn(Function):
     @staticmethod
     def forward(ctx, feat, head5, head6, *params):
         import ctypes
-        wall, bias, C, nd, R, used = _aspp_pack(head5, head6, feat)
+        heads = (head5,) if head6 is None else (head5, head6)
+        nh = len(heads)
+        wall, bias, C, nd, R, used = _aspp_pack(heads, feat)
         n, h, w, cin = feat.shape
         dil = (ctypes.c_int * nd)(*head5.dilations)
         ctx.prec = ASPPHeadsFn.prec
         with ops.conv_precision(ctx.prec):
             G = ops.conv2d(feat, wall, algo_cout=used)
         x1 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32)
-        x2 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32)
-        ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(x1), ops.ptr(x2), n, h, w, 2 * C, R, nd, dil, ops.stream())
+        x2 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32) if nh == 2 else None
+        ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(x1), ops.ptr(x2), n, h, w, nh * C, R, nd, dil, ops.stream())
         if any(ctx.needs_input_grad):
-            ctx.heads = (head5, head6)
+            ctx.heads = heads
             ctx.save_for_backward(feat, wall)
-        return x1, x2
+        return (x1, x2) if nh == 2 else x1
 
     @staticmethod
-    def backward(ctx, d1, d2):
+    def backward(ctx, d1, d2=None):
         import ctypes
         feat, wall = ctx.saved_tensors
-        head5, head6 = ctx.heads
+        heads = ctx.heads
+        nh = len(heads)
+        head5 = heads[0]
         C = head5.conv2d_list[0].weight.shape[0]
         nd = len(head5.dilations)
         n, h, w, cin = feat.shape
         R = wall.shape[0]
-        used = nd * 9 * 2 * C
-        d1, d2 = d1.contiguous(), d2.contiguous()
-        db = torch.zeros(2 * C, device=feat.device, dtype=torch.float32)
+        used = nd * 9 * nh * C
+        d1 = d1.contiguous()
+        d2 = d2.contiguous() if nh == 2 else None
+        db = torch.zeros(nh * C, device=feat.device, dtype=torch.float32)
         ops.bias_grad(d1, db[:C], C, C)
-        ops.bias_grad(d2, db[C:], C, C)
+        if nh == 2:
+            ops.bias_grad(d2, db[C:], C, C)
         dG = torch.empty((n, h, w, R), device=feat.device, dtype=torch.float32)
         dil = (ctypes.c_int * nd)(*head5.dilations)
-        ops.call("uem_aspp_gather_bwd", ops.ptr(d1), ops.ptr(d2), ops.ptr(dG), n, h, w, 2 * C, R, nd, dil, ops.stream())
+        ops.call("uem_aspp_gather_bwd", ops.ptr(d1), ops.ptr(d2), ops.ptr(dG), n, h, w, nh * C, R, nd, dil, ops.stream())
         dwall = torch.zeros((R, 1, 1, cin), device=feat.device, dtype=torch.float32)
         with ops.conv_precision(ctx.prec):
             ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
             dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
-        convs = [head.conv2d_list[i] for head in (head5, head6) for i in range(nd)]
+        convs = [head.conv2d_list[i] for head in heads for i in range(nd)]
         gws, gbs = [grad_ohwi(c.weight) for c in convs], [grad_buffer(c.bias) for c in convs]
         if all(g is not None for g in gws + gbs):
-            ops.call("uem_aspp_unpack_grad", ops.ptr(dwall), ops.ptr(db), _ptr_array(gws), _ptr_array(gbs), C, cin, nd, ops.stream())
+            ops.call("uem_aspp_unpack_grad", ops.ptr(dwall), ops.ptr(db), _ptr_array(gws), _ptr_array(gbs), C, cin, nd, nh, ops.stream())
         else:                                              # a frozen head parameter: per-tensor adds for the trainable ones
-            dwv = dwall.view(R, cin)[:used].view(nd, 9, 2, C, cin)
+            dwv = dwall.view(R, cin)[:used].view(nd, 9, nh, C, cin)
             for k, conv in enumerate(convs):
                 hd, i = divmod(k, nd)
                 if gws[k] is not None:

@@ -232,10 +232,17 @@ def on_side(launch, tensors):
 
 
 
+SIDE_OFF = 0            # > 0: no side stream (GraphedStep raises it around its warm-up steps and its capture)
+
+
 def in_backward():
     """inside an autograd backward pass -- and not under per-launch event timing: `PROF` prices a family by the events around its
     launches, which means something only while the launches run one after the other, so the one profiled step of bench.py runs serially"""
-    return (not torch.is_grad_enabled()) and torch._C._current_graph_task_id() >= 0 and not PROF.enabled
+    # (... and not while a hipGraph is being captured: the Winograd weight gradient allocates its temporaries inside the launch, and an
+    # allocation on a second stream during a capture invalidates it -- hipErrorStreamCaptureInvalidated, which took the whole bench line
+    # down in a rehearsal of this round; a replayed graph serialises the side stream's nodes anyway: bf16 39.4 ms without, 40.0 with)
+    return ((not torch.is_grad_enabled()) and torch._C._current_graph_task_id() >= 0 and not PROF.enabled and SIDE_OFF == 0
+            and not torch.cuda.is_current_stream_capturing())
 
 
 def need_gpu(*tensors):
