@@ -40,7 +40,7 @@ HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s
 def kernel_source_hash():
     """sha256 (16 hex digits) over the conv kernel sources: profiles/traffic_latest.json is valid for ONE build of them."""
     h = hashlib.sha256()
-    for f in ("conv.hip", "wgrad.hip", "winograd.hip"):
+    for f in ("conv.hip", "stem.hip", "wgrad.hip", "winograd.hip"):
         with open(os.path.join(ROOT, "uemda_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -102,6 +102,17 @@ int uem_conv2d_stem_wgrad_prec(const float* x4, const float* dy, float* dw8, int
  * gradient's load.  bf16 operands on the bf16 matrix cores, fp32 accumulation.            uemda/_resnets.py:149-153,205-212 */
 int uem_conv2d_stem_fwd_stats_bf16(const float* x4, const float* w8, uint16_t* y, int N, int H, int W, float* tile_stats, void* stream);
 int uem_conv2d_stem_wgrad_bf16(const float* x4, const uint16_t* dy, float* dw8, int N, int H, int W, void* stream);
+/* The stem as its own kernels (round 5, csrc/stem.hip): conv1 = Conv2d(3, 64, 7, stride 2, padding 3), uemda/_resnets.py:149-153,205-212.
+ * x4: the NHWC4 image; w_ohwi / dw_ohwi: the (64, 7, 7, 3) filter bank and its gradient as the model holds them (no packed copy);
+ * exact fp32 arithmetic, 148 reduction elements walked for 147.  The output must be whole 8 x 32 pixel tiles (Ho % 8 == 0,
+ * Wo % 32 == 0): UEM_ERR_UNSUPPORTED otherwise, nothing launched, the caller takes uem_conv2d_stem_fwd[_stats] / _wgrad.
+ *   fwd   : z (N, Ho, Wo, 64); tile_stats (optional) = the partial sums of uem_conv2d_fwd_stats, [2][64][N*Ho*Wo/128].
+ *   wgrad : dw_ohwi += sum over pixels; dz fp32 or bf16 (bf16 storage); deterministic (per-block banks summed in a fixed order);
+ *           workspace: uem_stem_conv_wgrad_workspace_floats() floats, 16-byte aligned.                                        */
+int uem_stem_conv_fwd(const float* x4, const float* w_ohwi, float* z, int N, int H, int W, float* tile_stats, void* stream);
+int64_t uem_stem_conv_wgrad_workspace_floats(void);
+int uem_stem_conv_wgrad(const float* x4, const float* dz, float* dw_ohwi, float* workspace, int N, int H, int W, void* stream);
+int uem_stem_conv_wgrad_bf16(const float* x4, const uint16_t* dz, float* dw_ohwi, float* workspace, int N, int H, int W, void* stream);
 /* weight re-layouts (tiny): transposed copy for dgrad; stem pack / unpack-add                     */
 int uem_weight_transpose(const float* w /*[Cout][KH][KW][Cin]*/, float* wt /*[Cin][KH][KW][Cout]*/, int Cout,
                          int KH, int KW, int Cin, void* stream);

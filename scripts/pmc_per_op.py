@@ -14,7 +14,7 @@ import os
 import re
 import sys
 
-CONV = re.compile(r"conv_dma_kernel|conv_fwd_kernel|conv_wgrad_kernel|wgrad_dma_kernel|wino4?_|conv_bf16_kernel|wgrad_bf16_kernel")
+CONV = re.compile(r"conv_dma_kernel|conv_fwd_kernel|conv_wgrad_kernel|wgrad_dma_kernel|wino4?_|conv_bf16_kernel|wgrad_bf16_kernel|stem_fwd_kernel|stem_wgrad")
 
 
 def ops_of(dirname, counter, nops):

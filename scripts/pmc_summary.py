@@ -10,7 +10,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("conv_wgrad_kernel", "conv_fwd_kernel", "wgrad_dma_kernel", "conv_dma_kernel"):
+    for key in ("conv_wgrad_kernel", "conv_fwd_kernel", "wgrad_dma_kernel", "conv_dma_kernel", "stem_fwd_kernel", "stem_wgrad_kernel"):
         i = name.find(key)
         if i >= 0:
             return name[i:i + 60]

@@ -16,6 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def family(name):
     """kernel name -> conv family, as ops.PROF attributes the launches (a Winograd conv is its transforms + its GEMM).  The Winograd
     input transforms carry the pass in their template arguments (<AFFINE, PASS>: 0 forward, 1 data gradient, 2 weight gradient)."""
+    if "stem_fwd_kernel" in name:
+        return "conv_fwd"
+    if "stem_wgrad" in name:                                # the stem's weight-gradient kernel and the two folds of its per-block banks
+        return "conv_wgrad"
     if "conv_wgrad_kernel" in name or "wgrad_dma_kernel" in name or re.search(r"wino4?_dy_kernel", name) or re.search(r"wino4?_filter_grad_kernel", name):
         return "conv_wgrad"
     m = re.search(r"conv_fwd_kernel<\d+, \d+, \d+, (\d)", name) or re.search(r"conv_dma_kernel<\d+, \d+, (\d)", name)   # <BN, KB, MODE, ...>

@@ -135,7 +135,7 @@ def test_committed_bench_line_obeys_the_contract():
     assert "kernel_source_sha256_16" in src
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv.hip", "wgrad.hip", "winograd.hip"):
+    for f in ("conv.hip", "stem.hip", "wgrad.hip", "winograd.hip"):
         h.update(open(os.path.join(root, "uemda_amd", "csrc", f), "rb").read())
     stamp = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))
     assert stamp["kernel_source_sha256_16"] == h.hexdigest()[:16], "re-run scripts/measure_round.sh: the conv sources changed since the PMC pass"

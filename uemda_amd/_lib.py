@@ -44,6 +44,10 @@ SIGNATURES = {
     "uem_conv2d_stem_fwd": [P, P, P, I, I, I, P],
     "uem_conv2d_wgrad": [P, P, P, P, P, POINTER(ConvShape), I, P],
     "uem_conv2d_stem_wgrad": [P, P, P, I, I, I, P],
+    "uem_stem_conv_fwd": [P, P, P, I, I, I, P, P],
+    "uem_stem_conv_wgrad_workspace_floats": [],
+    "uem_stem_conv_wgrad": [P, P, P, P, I, I, I, P],
+    "uem_stem_conv_wgrad_bf16": [P, P, P, P, I, I, I, P],
     "uem_weight_transpose": [P, P, I, I, I, I, P],
     "uem_stem_pack_weight": [P, P, P],
     "uem_stem_unpack_grad": [P, P, P],
@@ -143,7 +147,7 @@ SIGNATURES = {
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P, P],
 }
 _RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64,
-            "uem_label_refine_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64,
+            "uem_label_refine_workspace_floats": c_int64, "uem_stem_conv_wgrad_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64,
             "uem_loss_workspace_floats": c_int64}
 
 # compile-time constants mirrored from the header

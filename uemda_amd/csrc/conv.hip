@@ -61,6 +61,7 @@ struct ConvP {
     unsigned long long tapmask;       // 4 bits per walked tap: tap id = ky*KW + kx (3x3 at most)
     int y_bf16;                       // stem only (MODE 2, full tiles): y is a bf16 tensor -- values rounded (RNE) at the store, the
                                       // BatchNorm tile statistics taken over the ROUNDED values (what the max-pool will read)
+    int lazy;                         // conv_bf16_kernel, persistent blocks: counted waits around the epilogue (see there); read by that kernel only
 };
 
 // Schedule-ablation hooks (diagnostic builds that skip loads / stores and give WRONG results) exist only under
@@ -1045,6 +1046,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
         return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
     };
     constexpr int LDW = BN + 4, TPR = BN / 8, RPP = NTH / TPR, NRP = 64 / RPP, NCH = BMT / 64;     // the epilogue walks NCH chunks of 64 rows
+    // LAZY (round 5, persistent blocks on full tiles without epilogue loads): the barrier in front of the epilogue does not wait for the
+    // next tile's operand pieces and the first barrier of the next tile does not wait for the epilogue's stores (EPI_STORES = the
+    // stores every thread issues per tile: a lower bound is all the counted wait needs)
+    constexpr bool LAZY = PERSIST && EPI >= 0 && !(MODE == 1 && EPI == 1);
+    constexpr int EPI_STORES = NCH * NRP;
+    static_assert(EPI_STORES >= 1 && EPI_STORES < 48, "counted wait out of the counter's range");
     float* stg = smem;                                                   // PERSIST: the stage the tile consumed last
     const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
     // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
@@ -1108,13 +1115,30 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
         if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
         if (KT > 0) {
             for (int kt = 0; kt < KT; ++kt) {
-                CONV_SYNC();
+                if (LAZY && p.lazy && kt == 0 && vc != (int)blockIdx.x) {
+                    // first k-step of a later tile of the block: its operand pieces were requested under the PREVIOUS tile's last
+                    // MFMA phase and every thread has issued at least EPI_STORES stores since (the epilogue's rows) -- the memory
+                    // counter retires in order, so "at most EPI_STORES outstanding" means the pieces have landed while the stores
+                    // are still on their way (vmcnt(0) here waited for the write acknowledgements of a whole tile, once per tile)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(EPI_STORES) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                } else {
+                    CONV_SYNC();
+                }
                 step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), issue_live, true);
                 par ^= 1;
             }
             // every wave past its last operand read, every DMA piece landed: the last step's out-of-range pieces (not persistent: the
             // staging area spans both stages) or the next tile's first operand tile (persistent: in the other stage)
-            CONV_SYNC();
+            if (LAZY && p.lazy) {
+                // the pieces in flight fill the OTHER stage: nothing the epilogue touches -- it only needs every wave past its LDS reads
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            } else {
+                CONV_SYNC();
+            }
         } else {
             __syncthreads();
         }
@@ -2176,6 +2200,12 @@ static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream
     auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT>;
     if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 2 * BMT, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
 }
+static int g_bf16_lazy = -1;     // tuning override: counted waits around the persistent blocks' epilogue on / off, -1 = environment / default
+extern "C" void uemdbg_conv_bf16_lazy(int v) { g_bf16_lazy = v; }
+static int conv_bf16_lazy() {
+    static const int env = getenv("UEM_CONV_BF16_LAZY") ? atoi(getenv("UEM_CONV_BF16_LAZY")) : 1;
+    return g_bf16_lazy >= 0 ? g_bf16_lazy : env;
+}
 static int g_bf16_big = -1;      // tuning override: 0 = never the 256-row tiles, 1 = wherever they are legal, -1 = rule
 extern "C" void uemdbg_conv_bf16_big(int v) { g_bf16_big = v; }
 template <int BN_, int MODE, int BMT = 128>
@@ -2274,7 +2304,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
     p.x = (const float*)x; p.w = (const float*)w; p.bias = nullptr; p.in_scale = p.in_shift = nullptr; p.y = (float*)y;
     p.KH = s->KH; p.KW = s->KW; p.stride = s->stride; p.pad = s->pad; p.dil = s->dil;
     p.accumulate = (flags & UEM_CONV_ACCUMULATE) ? 1 : 0; p.relu = 0;
-    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = g_conv_dbg; p.y_bf16 = 0; p.wg_rows = 0; p.wg_stride = 0;
+    p.sub = 1; p.py = p.px = 0; p.Hs = p.Ws = 0; p.ntaps = s->KH * s->KW; p.tapmask = 0; p.dbg = g_conv_dbg; p.y_bf16 = 0; p.wg_rows = 0; p.wg_stride = 0; p.lazy = conv_bf16_lazy();
     p.tile_stats = tile_stats; p.bn_z = nullptr; p.bn_vec = nullptr; p.tile_bnbwd = nullptr; p.acc_src = nullptr; p.acc_bits = nullptr; p.bn_bits = nullptr;
     if (fuse != nullptr) {
         p.bn_z = (const float*)fuse->z; p.bn_vec = fuse->vec; p.tile_bnbwd = fuse->tiles;

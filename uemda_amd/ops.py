@@ -849,9 +849,24 @@ def nchw3_to_nhwc4(x):
     return x4
 
 
+# The stem's own kernels (csrc/stem.hip, round 5): exact fp32 operands, whole 8 x 32 output tiles.  UEM_STEM_KERNEL=0: the generic
+# register-staged kernels of rounds 1-4 everywhere (they also serve the bf16-operand islands and odd sizes).
+STEM_KERNEL = os.environ.get("UEM_STEM_KERNEL", "1") != "0"
+
+
+def stem_tiles_ok(h, w):
+    return STEM_KERNEL and conv_out_size(h, 7, 2, 3, 1) % 8 == 0 and conv_out_size(w, 7, 2, 3, 1) % 32 == 0
+
+
 def stem_conv(x4, w_ohwi, w8=None):
     """w8: the packed taps when the caller holds them (stem_weight_packed(param)); else packed here from w_ohwi"""
     n, h, w, _ = x4.shape
+    if CONV_PREC == 0 and stem_tiles_ok(h, w) and w_ohwi is not None:
+        y = torch.empty((n, conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1), 64), device=x4.device, dtype=torch.float32)
+        wc = _f32c(w_ohwi, "stem filter bank")
+        PROF.run("conv_fwd", 2.0 * y.numel() * 147, lambda: call("uem_stem_conv_fwd", ptr(x4), ptr(wc), ptr(y), n, h, w, None, stream()),
+                 executed=2.0 * y.numel() * 148)
+        return y
     if w8 is None:
         w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
         call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
@@ -878,7 +893,12 @@ def stem_conv_bn(x4, w_ohwi, bn, w8=None):
         call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
     z = torch.empty((n, ho, wo, 64), device=x4.device, dtype=torch.float32)
     ts = torch.empty((M // 128, 2, 64), device=x4.device, dtype=torch.float32)
-    PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), CONV_PREC, stream()))
+    if CONV_PREC == 0 and stem_tiles_ok(h, w) and w_ohwi is not None:
+        wc = _f32c(w_ohwi, "stem filter bank")
+        PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_stem_conv_fwd", ptr(x4), ptr(wc), ptr(z), n, h, w, ptr(ts), stream()),
+                 executed=2.0 * z.numel() * 148)
+    else:
+        PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_conv2d_stem_fwd_stats", ptr(x4), ptr(w8), ptr(z), n, h, w, ptr(ts), CONV_PREC, stream()))
     st = BNState()
     st.training = True
     buf = torch.empty((4, 64), device=x4.device, dtype=torch.float32)
@@ -893,6 +913,12 @@ def stem_wgrad(x4, dy, dw_ohwi):
     if dw_ohwi is None:                      # frozen stem (freeze_at >= 1)
         return
     n, h, w, _ = x4.shape
+    if CONV_PREC_BWD == 0 and stem_tiles_ok(h, w) and dw_ohwi.is_contiguous():
+        ws = torch.empty(_lib.load().uem_stem_conv_wgrad_workspace_floats(), device=x4.device, dtype=torch.float32)
+        PROF.run("conv_wgrad", 2.0 * dy.numel() * 147,
+                 lambda: call("uem_stem_conv_wgrad", ptr(x4), ptr(dy), ptr(dw_ohwi), ptr(ws), n, h, w, stream()),
+                 executed=2.0 * dy.numel() * 160)
+        return
     dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
     PROF.run("conv_wgrad", 2.0 * dy.numel() * 147,
              lambda: call("uem_conv2d_stem_wgrad_prec", ptr(x4), ptr(dy), ptr(dw8), n, h, w, CONV_PREC_BWD, stream()))

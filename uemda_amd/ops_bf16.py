@@ -202,6 +202,13 @@ def stem_wgrad(x4, dz, dw_ohwi):
     if dw_ohwi is None:                      # frozen stem
         return
     n, h, w, _ = x4.shape
+    if ops.stem_tiles_ok(h, w) and dw_ohwi.is_contiguous():
+        # the stem's own weight-gradient kernel (csrc/stem.hip): bf16 dz widened at the load, fp32 operands, deterministic
+        ws = torch.empty(_lib.load().uem_stem_conv_wgrad_workspace_floats(), device=x4.device, dtype=torch.float32)
+        ops.PROF.run("conv_wgrad", 2.0 * dz.numel() * 147,
+                     lambda: call("uem_stem_conv_wgrad_bf16", ptr(x4), ptr(dz), ptr(dw_ohwi), ptr(ws), n, h, w, stream()),
+                     executed=2.0 * dz.numel() * 160)
+        return
     dw8 = torch.zeros((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
     ops.PROF.run("conv_wgrad", 2.0 * dz.numel() * 147, lambda: call("uem_conv2d_stem_wgrad_bf16", ptr(x4), ptr(dz), ptr(dw8), n, h, w, stream()))
     call("uem_stem_unpack_grad", ptr(dw8), ptr(dw_ohwi), stream())
