@@ -337,6 +337,33 @@ def test_maxpool_and_instnorm_vs_torch():
     torch.testing.assert_close(nchw(dxi)[:, :32], gi["gx"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 256), (4, 16, 16, 64), (1, 30, 33, 256), (8, 8, 8, 128), (2, 7, 9, 128), (2, 40, 40, 128),
+                                   (1, 32, 32, 64)])
+def test_instnorm_one_pass_kernels_vs_torch(shape):
+    """InstanceNorm2d (Encoder.py:123,147: no affine, no running statistics), forward and backward against torch in float64.  The
+    shapes cover the register-resident kernels of round 5 (planes of 64 ... 1024 pixels, whole and ragged, 4 and 16 pixels per thread),
+    the two-pass kernels they fall back to (larger planes, block counts that do not divide over the XCDs) -- and both give the same
+    numbers up to the order of the sums."""
+    from uemda_amd import ops, ops_bf16 as ob
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(n, c, h, w, generator=g) * 1.5 + 3.0).double().requires_grad_(True)     # mean >> 0 stresses the variance
+    y_ref = F.instance_norm(x, eps=1e-5)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy.double())
+    y, inv = ops.instnorm_fwd(nhwc(x.detach().float()))
+    assert float((nchw(y).double() - y_ref.detach()).abs().max()) < 2e-5
+    dx = ops.instnorm_bwd(y, nhwc(gy), inv)
+    assert float((nchw(dx).double() - x.grad).norm() / x.grad.norm()) < 2e-5
+    xb = nhwc(x.detach().float()).to(torch.bfloat16)
+    yb, invb = ob.instnorm_fwd(xb)
+    y32, inv32 = ops.instnorm_fwd(xb.float())
+    torch.testing.assert_close(yb, y32, rtol=1e-5, atol=1e-5)                  # the bf16 reader widens and does the same arithmetic
+    torch.testing.assert_close(invb, inv32, rtol=1e-5, atol=1e-7)              # (its forward keeps the two-pass kernel: other sum order)
+    dxb = ob.instnorm_bwd(y32, nhwc(gy), inv32)
+    assert torch.equal(dxb, ops.instnorm_bwd(y32, nhwc(gy), inv32).to(torch.bfloat16))
+
+
 # ---------------- layer goldens from the reference ---------------------------------------------------------
 def _load_into(module, shapes_tag):
     from oracle.weights import fill_like
