@@ -273,6 +273,16 @@ int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, co
                      const int64_t* ignore_id /* device */, float* soft_out, uint32_t* plane_max,
                      float* workspace /* uem_label_refine_workspace_floats(B,C,H,W,S) */, int B, int C, int h, int w,
                      int H, int W, int S, float temp, int mode, void* stream);
+/* uem_label_refine followed by uem_pseudo_select on the refined map (train_ssl_uem.py:209-214; alignment.py:194-293 then
+ * pseudo_generation.py:62-84), three launches: the refinement kernel also leaves each pixel's candidate (the one class above cutoff_low
+ * and its value) in cand_workspace (uem_label_refine_select_workspace_bytes(B, H, W) bytes, 16-byte aligned) and the selection pass
+ * reduces the blocks' maxima itself and reads 5 bytes per pixel instead of 4 * C.  hard: (B, H, W) int64.  Bit-identical to the two
+ * entries called in sequence.  Needs H * W % 4 == 0 (UEM_ERR_UNSUPPORTED otherwise, nothing launched).                         */
+int64_t uem_label_refine_select_workspace_bytes(int B, int H, int W);
+int uem_label_refine_select(const float* soft, const int64_t* sup, const float* sim, const float* logits1, const float* logits2,
+                            const uint32_t* seg_keys, const int64_t* ignore_id, float* soft_out, uint32_t* plane_max, float* workspace,
+                            void* cand_workspace, int64_t* hard, int B, int C, int h, int w, int H, int W, int S, float temp, int mode,
+                            float cutoff_top, float cutoff_low, int64_t ignore_label, void* stream);
 int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W, int S);
 /* per-(b,c) max over H*W of an NCHW map                                pseudo_generation.py:76     */
 int uem_plane_max(const float* mask, uint32_t* plane_max, int B, int C, int64_t HW, void* stream);

@@ -87,6 +87,45 @@ def test_label_refine_irregular_single_pred_and_explicit_ignore(aligner):
     assert torch.equal(same.cpu(), g["soft"])
 
 
+@pytest.mark.parametrize("mode", ["all", "s", "p", "l"])
+@pytest.mark.parametrize("cut", [(0.8, 0.6), (0.9, 0.5), (0.3, 0.1), (0.05, 0.01), (1.0, 0.99)])
+def test_refine_and_select_equals_the_two_calls(aligner, mode, cut):
+    """uem_label_refine_select (the step's call, train_ssl_uem.py:209-214): the refined map and the hard labels it returns are the
+    ones label_refine followed by pseudo_selection give, bit for bit -- for the reference's cutoffs (0.8, 0.6), for cutoffs under 0.5
+    where several classes pass cutoff_low and the selection pass falls back to the refined map (candidate code 255), and for cutoffs
+    nothing passes."""
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    g = load_golden("label_refine")
+    aligner.prototypes = dev(g["protos"]).contiguous()
+    args = (dev(g["sup"]), dev(g["feat"]), [dev(g["p1"]), dev(g["p2"])], dev(g["soft"]))
+    top, low = cut
+    soft_ref = aligner.label_refine(*args, True, mode, 2.0)
+    hard_ref = pseudo_selection(soft_ref, top, low, "tensor", -1)
+    soft, hard = aligner.refine_and_select(*args, mode=mode, temp=2.0, cutoff_top=top, cutoff_low=low)
+    assert torch.equal(soft, soft_ref)
+    assert hard.dtype == torch.int64 and torch.equal(hard, hard_ref)
+    pm = aligner._last_plane_max.view(torch.float32)
+    assert torch.equal(pm, soft_ref.amax(dim=(2, 3)))
+    if cut == (0.3, 0.1):
+        assert int((hard_ref >= 0).sum()) > 0 and int((hard_ref < 0).sum()) > 0       # both outcomes occur
+
+
+def test_refine_and_select_on_a_map_whose_size_is_not_a_multiple_of_four(aligner):
+    """H * W % 4 != 0: the fused entry declines and the two kernels run in sequence -- same contract."""
+    from uemda_amd.gast.pseudo_generation import pseudo_selection
+    g = torch.Generator().manual_seed(5)
+    B, H, W, h, w = 2, 17, 19, 5, 6
+    soft0 = torch.softmax(torch.randn(B, C, H, W, generator=g) * 2, 1)
+    sup = torch.randint(0, 12, (B, 1, H, W), generator=g)
+    feat = torch.randn(B, 64, h, w, generator=g)
+    p1, p2 = torch.randn(B, C, h, w, generator=g), torch.randn(B, C, h, w, generator=g)
+    aligner.prototypes = torch.randn(C, 64, generator=g).cuda()
+    args = (dev(sup), dev(feat), [dev(p1), dev(p2)], dev(soft0))
+    soft_ref = aligner.label_refine(*args, True, "all", 2.0)
+    soft, hard = aligner.refine_and_select(*args)
+    assert torch.equal(soft, soft_ref) and torch.equal(hard, pseudo_selection(soft_ref, 0.8, 0.6, "tensor", -1))
+
+
 def test_label_refine_superpixel_table_is_sized_per_call_and_reports_overflow():
     """The reference sizes the scatter from every batch (alignment.py:241-245).  A second batch whose ids exceed the
     first batch's must be refined exactly (the table used to be frozen by the first call, later ids read

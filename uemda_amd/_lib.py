@@ -90,6 +90,8 @@ SIGNATURES = {
     "uem_scatter": [P, P, P, P, I, I, I, I, I, P],
     "uem_segment_max_planar": [P, P, P, I, I, I, I, I, P, P],
     "uem_label_refine": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, P],
+    "uem_label_refine_select_workspace_bytes": [I, I, I],
+    "uem_label_refine_select": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, F, I, F, F, L, P],
     "uem_label_refine_workspace_floats": [I, I, I, I, I],
     "uem_plane_max": [P, P, I, I, L, P],
     "uem_pseudo_select": [P, P, P, P, I, I, L, F, F, L, P],
@@ -147,7 +149,7 @@ SIGNATURES = {
     "uem_sgd_clip_step": [P, P, P, L, P, F, F, F, F, I, F, P, P],
 }
 _RESTYPE = {"uem_last_error": c_char_p, "uem_bn_workspace_floats": c_int64,
-            "uem_label_refine_workspace_floats": c_int64, "uem_stem_conv_wgrad_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64,
+            "uem_label_refine_workspace_floats": c_int64, "uem_label_refine_select_workspace_bytes": c_int64, "uem_stem_conv_wgrad_workspace_floats": c_int64, "uem_pcl_workspace_floats": c_int64,
             "uem_loss_workspace_floats": c_int64}
 
 # compile-time constants mirrored from the header

@@ -487,7 +487,8 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
     const float* __restrict__ soft, const int64_t* __restrict__ sup, const float* __restrict__ sim,
     const float* __restrict__ lg1, const float* __restrict__ lg2_, const float* __restrict__ segw,
     const int64_t* __restrict__ ignore_id, float* __restrict__ out, float* __restrict__ blockmax, int C_, int h,
-    int w, int H, int W, int S, float inv_temp, int mode_, int ncell) {
+    int w, int H, int W, int S, float inv_temp, int mode_, int ncell, float* __restrict__ cand_val,
+    uint8_t* __restrict__ cand_code, float cand_low) {
     const int C = CEX > 0 ? CEX : C_;
     const int mode = MODE_T >= 0 ? MODE_T : mode_;
     const float* const lg2 = lg2_;
@@ -630,6 +631,21 @@ __global__ __launch_bounds__(256) void label_refine_kernel(
         const size_t p = (size_t)(Y0 + r) * W + X;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c) if (c < C) { o[c] = o[c] * rd; out[((size_t)b * C + c) * plane + p] = o[c]; omax[c] = fmaxf(omax[c], o[c]); }
+        if (cand_val != nullptr) {
+            // The selection pass (pseudo_generation.py:62-84) keeps a pixel when exactly ONE class is above its threshold
+            // max(top * plane maximum, low) >= low.  Which classes are above `low` is known here: none -> the pixel is ignored whatever
+            // the maxima turn out to be (code 254); one -> only that class can pass, its value decides (code = class); several -> the
+            // pass reads the pixel's classes again (code 255; impossible for low >= 0.5 up to rounding: the classes sum to 1).  The
+            // pass then reads 5 bytes per pixel instead of 4 * C.
+            int nlow = 0, code = 254;
+            float val = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C && o[c] > cand_low) { if (nlow == 0) { code = c; val = o[c]; } ++nlow; }
+            if (nlow > 1) code = 255;
+            cand_val[(size_t)b * plane + p] = val;
+            cand_code[(size_t)b * plane + p] = (uint8_t)code;
+        }
     }
     // per-(b,c) maximum for the selection pass: block maximum -> blockmax[b][block][c]; a second tiny kernel
     // reduces the blocks.  (One atomicMax per wave on the B*C result words serialised 0.8 M atomics on 192
@@ -666,10 +682,45 @@ extern "C" int64_t uem_label_refine_workspace_floats(int B, int C, int H, int W,
     const int cmax = C <= 8 ? 8 : 16;
     return (int64_t)B * uem_cdiv(W, 256) * uem_cdiv(H, LR_ROWS) * cmax + (int64_t)B * (S > 0 ? S : 0) * cmax;
 }
+struct LrSelect { int64_t* hard; float top, low; int64_t ignore; float* cand_val; uint8_t* cand_code; };
+template <int CMAX, int CEX>
+__global__ __launch_bounds__(256) void select_cand_kernel(const float* __restrict__ soft, const float* __restrict__ cand_val,
+                                                          const uint8_t* __restrict__ cand_code, const float* __restrict__ blockmax,
+                                                          int nblk, uint32_t* __restrict__ plane_max, int64_t* __restrict__ hard,
+                                                          int C_, int64_t HW, float top, float low, int64_t ignore);
+static int label_refine_impl(const float* soft, const int64_t* sup, const float* sim, const float* logits1, const float* logits2,
+                             const uint32_t* seg_keys, const int64_t* ignore_id, float* soft_out, uint32_t* plane_max, float* workspace,
+                             int B, int C, int h, int w, int H, int W, int S, float temp, int mode, const LrSelect* sel, void* stream);
 extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
                                 const float* logits2, const uint32_t* seg_keys, const int64_t* ignore_id,
                                 float* soft_out, uint32_t* plane_max, float* workspace, int B, int C, int h, int w,
                                 int H, int W, int S, float temp, int mode, void* stream) {
+    return label_refine_impl(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out, plane_max, workspace, B, C, h, w, H, W, S,
+                             temp, mode, nullptr, stream);
+}
+// label_refine followed by pseudo_selection (train_ssl_uem.py:209-214 calls them back to back on the same map) in three launches:
+// the refinement kernel leaves, beside the refined map, each pixel's candidate -- the one class above cutoff_low and its value -- and
+// the selection pass reduces the blocks' maxima itself and reads the candidates (5 bytes per pixel instead of 4 * C; pixels with
+// several classes above cutoff_low, if any, re-read their classes).  Results equal uem_label_refine + uem_pseudo_select bit for bit.
+// cand_workspace: B*H*W floats followed by B*H*W bytes (uem_label_refine_select_workspace_bytes); needs H*W % 4 == 0
+// (UEM_ERR_UNSUPPORTED otherwise: call the two entries in sequence).
+extern "C" int64_t uem_label_refine_select_workspace_bytes(int B, int H, int W) { return (int64_t)B * H * W * 5; }
+extern "C" int uem_label_refine_select(const float* soft, const int64_t* sup, const float* sim, const float* logits1,
+                                       const float* logits2, const uint32_t* seg_keys, const int64_t* ignore_id, float* soft_out,
+                                       uint32_t* plane_max, float* workspace, void* cand_workspace, int64_t* hard, int B, int C, int h,
+                                       int w, int H, int W, int S, float temp, int mode, float cutoff_top, float cutoff_low,
+                                       int64_t ignore_label, void* stream) {
+    UEM_REQUIRE(hard && cand_workspace, "label_refine_select: null pointer");
+    if (((int64_t)H * W) % 4 != 0 || (((uintptr_t)cand_workspace | (uintptr_t)hard) & 15) != 0)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "label_refine_select: needs H*W %% 4 == 0 and 16-byte aligned buffers");
+    LrSelect sel{hard, cutoff_top, cutoff_low, ignore_label, reinterpret_cast<float*>(cand_workspace),
+                 reinterpret_cast<uint8_t*>(cand_workspace) + (size_t)B * H * W * 4};
+    return label_refine_impl(soft, sup, sim, logits1, logits2, seg_keys, ignore_id, soft_out, plane_max, workspace, B, C, h, w, H, W, S,
+                             temp, mode, &sel, stream);
+}
+static int label_refine_impl(const float* soft, const int64_t* sup, const float* sim, const float* logits1, const float* logits2,
+                             const uint32_t* seg_keys, const int64_t* ignore_id, float* soft_out, uint32_t* plane_max, float* workspace,
+                             int B, int C, int h, int w, int H, int W, int S, float temp, int mode, const LrSelect* sel, void* stream) {
     UEM_REQUIRE(soft && soft_out && plane_max && workspace, "label_refine: null pointer");
     UEM_REQUIRE(mode >= 0 && mode <= 3, "label_refine: bad mode %d", mode);
     UEM_REQUIRE(B > 0 && C >= 1 && C <= UEM_MAX_CLASSES && h > 0 && w > 0 && H >= h && W >= w && H <= 65535 * LR_ROWS, "label_refine: bad shape");
@@ -695,7 +746,8 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
         if (uem_allow_lds((const void*)label_refine_kernel<CM, CE, MT, FT>, lds))                                                 \
             label_refine_kernel<CM, CE, MT, FT><<<grid, 256, lds, st>>>(soft, sup, sim, logits1, logits2, segw, ignore_id,       \
                                                                         soft_out, blockmax, C, h, w, H, W, S, 1.0f / temp, mode, \
-                                                                        ncell);                                                 \
+                                                                        ncell, sel ? sel->cand_val : nullptr,                   \
+                                                                        sel ? sel->cand_code : nullptr, sel ? sel->low : 0.f);  \
     } while (0)
     // train_ssl_uem.py:209-214: all three views, two heads, on whole 256 x LR_ROWS pixel blocks
     const bool train_call = mode == UEM_REFINE_ALL && logits2 != nullptr && W % 256 == 0 && H % LR_ROWS == 0;
@@ -706,8 +758,95 @@ extern "C" int uem_label_refine(const float* soft, const int64_t* sup, const flo
     else LAUNCH_LR3(16, 0, -1);
 #undef LAUNCH_LR3
 #undef LAUNCH_LR
-    blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(blockmax, plane_max, (int)(grid.x * grid.y), C, cmax);
-    return uem_check_launch("label_refine");
+    if (sel == nullptr) {
+        blockmax_reduce_kernel<<<dim3(C, B), 256, 0, st>>>(blockmax, plane_max, (int)(grid.x * grid.y), C, cmax);
+        return uem_check_launch("label_refine");
+    }
+    const int64_t HW = (int64_t)H * W;
+    const dim3 sgrid((unsigned)uem_cdiv(HW, 4096), (unsigned)B);
+    const int nblk = (int)(grid.x * grid.y);
+#define LAUNCH_SEL(CM, CE)                                                                                                          \
+    select_cand_kernel<CM, CE><<<sgrid, 256, 0, st>>>(soft_out, sel->cand_val, sel->cand_code, blockmax, nblk, plane_max, sel->hard, C, \
+                                                      HW, sel->top, sel->low, sel->ignore)
+    if (C == 6) LAUNCH_SEL(8, 6);
+    else if (C == 7) LAUNCH_SEL(8, 7);
+    else if (C <= 8) LAUNCH_SEL(8, 0);
+    else LAUNCH_SEL(16, 0);
+#undef LAUNCH_SEL
+    return uem_check_launch("label_refine_select");
+}
+
+// grid (chunks of 4096 pixels, B); the block first reduces its image's block maxima (label_refine_kernel left one entry per block:
+// [b][block][cmax]) to the thresholds -- the same maxima and the same products as blockmax_reduce_kernel + pseudo_select_kernel
+template <int CMAX, int CEX>
+__global__ __launch_bounds__(256) void select_cand_kernel(const float* __restrict__ soft, const float* __restrict__ cand_val,
+                                                          const uint8_t* __restrict__ cand_code, const float* __restrict__ blockmax,
+                                                          int nblk, uint32_t* __restrict__ plane_max, int64_t* __restrict__ hard,
+                                                          int C_, int64_t HW, float top, float low, int64_t ignore) {
+    const int C = CEX > 0 ? CEX : C_;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    float m[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) m[c] = 0.f;
+    for (int i = tid; i < nblk; i += 256) {
+        const float4* src = reinterpret_cast<const float4*>(blockmax + ((size_t)b * nblk + i) * CMAX);
+#pragma unroll
+        for (int q = 0; q < CMAX / 4; ++q) {
+            const float4 t = src[q];
+            m[4 * q] = fmaxf(m[4 * q], t.x); m[4 * q + 1] = fmaxf(m[4 * q + 1], t.y);
+            m[4 * q + 2] = fmaxf(m[4 * q + 2], t.z); m[4 * q + 3] = fmaxf(m[4 * q + 3], t.w);
+        }
+    }
+    __shared__ float wm[4][CMAX];
+    __shared__ float thr[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        const float v = wave_max_dpp(m[c]);
+        if ((tid & 63) == 0) wm[tid >> 6][c] = v;
+    }
+    __syncthreads();
+    if (tid < CMAX) {
+        const float pm = fmaxf(fmaxf(wm[0][tid], wm[1][tid]), fmaxf(wm[2][tid], wm[3][tid]));
+        thr[tid] = tid < C ? fmaxf(__fmul_rn(pm, top), low) : INFINITY;
+        if (blockIdx.x == 0 && tid < C) plane_max[b * C + tid] = __float_as_uint(pm);
+    }
+    __syncthreads();
+    const float* const vb = cand_val + (size_t)b * HW;
+    const uint8_t* const cb = cand_code + (size_t)b * HW;
+    int64_t* const hb = hard + (size_t)b * HW;
+    const int64_t p0 = (int64_t)blockIdx.x * 4096 + tid * 4;
+    float4 v4[4];
+    uchar4 c4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t p = p0 + j * 1024;
+        if (p < HW) { v4[j] = *reinterpret_cast<const float4*>(vb + p); c4[j] = *reinterpret_cast<const uchar4*>(cb + p); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t p = p0 + j * 1024;
+        if (p >= HW) continue;
+        const float vv[4] = {v4[j].x, v4[j].y, v4[j].z, v4[j].w};
+        const unsigned cc[4] = {c4[j].x, c4[j].y, c4[j].z, c4[j].w};
+        int64_t out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int64_t lab = ignore;
+            if (cc[e] < (unsigned)C) {
+                if (vv[e] > thr[cc[e]]) lab = (int64_t)cc[e];
+            } else if (cc[e] == 255u) {                      // several classes above cutoff_low: the selection rule in full
+                int cnt = 0, first = 0;
+                for (int c = 0; c < C; ++c) {
+                    const float x = soft[((size_t)b * C + c) * HW + p + e];
+                    if (x > thr[c]) { if (cnt == 0) first = c; ++cnt; }
+                }
+                if (cnt == 1) lab = first;
+            }
+            out[e] = lab;
+        }
+        *reinterpret_cast<longlong2*>(hb + p) = make_longlong2(out[0], out[1]);
+        *reinterpret_cast<longlong2*>(hb + p + 2) = make_longlong2(out[2], out[3]);
+    }
 }
 
 // ================================================================================================

@@ -89,7 +89,7 @@ class Aligner:
 
     # ---- label refinement ------------------------------------------------------------------------------
     def label_refine(self, label_t_sup, feat_t, preds_t, label_t_soft, refine=True, mode='all', temp=2.0,
-                     sup_ignore_id=None, return_plane_max=False):
+                     sup_ignore_id=None, return_plane_max=False, _select=None):
         """Three-view refinement of the soft pseudo label (alignment.py:194-293).
 
         `sup_ignore_id`: the ignored superpixel id; None reproduces the reference's batch-global
@@ -111,6 +111,20 @@ class Aligner:
         dev = soft.device
         sim = lg1 = lg2 = sup = seg = ign = None
         S = 1
+        if mode in ('all', 's'):
+            sup = label_t_sup.detach().contiguous().long()
+            self.check_superpixel_ids()                                # the previous call's range report, if any
+            if sup_ignore_id is None:
+                ign = index_max(sup)                                   # alignment.py:241 (device scalar, no host sync)
+            else:
+                ign = self._ignore_id_tensor(int(sup_ignore_id), dev)
+            S = self._sup_table_size(H, W, sup_ignore_id)
+            zeros = torch.zeros(B * S * C + 4, device=dev, dtype=torch.int32)      # the segment table and the range flag: one fill
+            seg, oor = zeros[:B * S * C].view(B, S, C), zeros[B * S * C]
+            # (the segment pass does not depend on the Pearson map below; run beside it on a second stream the pair took 17 us MORE
+            # than back to back -- 311 against 294 us for the whole call at B = 32: the fork and the join cost more than the overlap of
+            # two 55 us HBM-bound kernels gives)
+            call("uem_segment_max_planar", ptr(soft), ptr(sup), ptr(seg), B, C, H, W, S, ptr(oor), stream())
         if mode in ('all', 'p'):
             sim = self._pearson_sim_map(feat)
         if mode in ('all', 'l'):
@@ -119,25 +133,37 @@ class Aligner:
                 lg1, lg2 = ops.as_nhwc(preds_t[0].detach()).contiguous(), ops.as_nhwc(preds_t[1].detach()).contiguous()
             else:
                 lg1 = ops.as_nhwc(preds_t.detach()).contiguous()
-        if mode in ('all', 's'):
-            sup = label_t_sup.detach().contiguous().long()
-            self.check_superpixel_ids()                                # the previous call's range report, if any
-            if sup_ignore_id is None:
-                ign = index_max(sup)                                   # alignment.py:241 (device scalar, no host sync)
-            else:
-                ign = torch.full((), int(sup_ignore_id), device=dev, dtype=torch.int64)
-            S = self._sup_table_size(H, W, sup_ignore_id)
-            seg = torch.zeros((B, S, C), device=dev, dtype=torch.int32)
-            oor = torch.zeros((), device=dev, dtype=torch.int32)
-            call("uem_segment_max_planar", ptr(soft), ptr(sup), ptr(seg), B, C, H, W, S, ptr(oor), stream())
+        if seg is not None:
             self._report_superpixel_range(oor, S)
         out = torch.empty_like(soft)
         plane_max = torch.empty((B, C), device=dev, dtype=torch.int32)
         ws = torch.empty(_lib.load().uem_label_refine_workspace_floats(B, C, H, W, S if seg is not None else 0), device=dev, dtype=torch.float32)
+        self._last_plane_max = plane_max
+        if _select is not None and (H * W) % 4 == 0:
+            # label_refine + pseudo_selection in three launches (uem_label_refine_select): same numbers, the selection reads 5 bytes
+            # per pixel instead of the refined map
+            top, low, ignore = _select
+            cand = torch.empty(_lib.load().uem_label_refine_select_workspace_bytes(B, H, W), device=dev, dtype=torch.uint8)
+            hard = torch.empty((B, H, W), device=dev, dtype=torch.int64)
+            call("uem_label_refine_select", ptr(soft), ptr(sup), ptr(sim), ptr(lg1), ptr(lg2), ptr(seg), ptr(ign), ptr(out),
+                 ptr(plane_max), ptr(ws), ptr(cand), ptr(hard), B, C, h, w, H, W, S, float(temp), _MODES[mode], float(top), float(low),
+                 int(ignore), stream())
+            return out, hard
         call("uem_label_refine", ptr(soft), ptr(sup), ptr(sim), ptr(lg1), ptr(lg2), ptr(seg), ptr(ign), ptr(out),
              ptr(plane_max), ptr(ws), B, C, h, w, H, W, S, float(temp), _MODES[mode], stream())
-        self._last_plane_max = plane_max
+        if _select is not None:
+            top, low, ignore = _select
+            return out, pseudo_generation.pseudo_selection(out, top, low, 'tensor', ignore, _plane_max=plane_max, check_range=False)
         return (out, plane_max) if return_plane_max else out
+
+    def _ignore_id_tensor(self, value, dev):
+        """the ignored superpixel id as the device scalar the kernels read, made once per (value, device)"""
+        cache = self.__dict__.setdefault("_ign_cache", {})
+        key = (value, dev.index)
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.full((), value, device=dev, dtype=torch.int64)
+        return t
 
     # ---- superpixel table capacity ------------------------------------------------------------------------
     # The reference sizes the scatter from every batch's own maximum id (alignment.py:241-245, one host sync per
@@ -193,10 +219,8 @@ class Aligner:
                           cutoff_low=0.6, sup_ignore_id=None):
         """label_refine + pseudo_selection sharing the per-class maxima computed inside the fused kernel
         (saves one full pass over the (B,C,H,W) map); identical results to calling the two in sequence."""
-        soft, pm = self.label_refine(label_t_sup, feat_t, preds_t, label_t_soft, True, mode, temp, sup_ignore_id, True)
-        hard = pseudo_generation.pseudo_selection(soft, cutoff_top, cutoff_low, 'tensor', self.ignore_label,
-                                                  _plane_max=pm, check_range=False)
-        return soft, hard
+        return self.label_refine(label_t_sup, feat_t, preds_t, label_t_soft, True, mode, temp, sup_ignore_id,
+                                 _select=(cutoff_top, cutoff_low, self.ignore_label))
 
     # ---- prototypes --------------------------------------------------------------------------------------
     def _class_sums(self, feat, label_ds):
