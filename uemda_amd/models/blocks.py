@@ -77,7 +77,7 @@ class StemFn(Function):
         # BatchNorm statistics out of the conv epilogue; BatchNorm + ReLU applied in the max-pool's fetch: the 64-channel
         # half-resolution map (the largest activation of the network) is written once (z) and read once
         with ops.conv_precision(ctx.prec):
-            z, st = ops.stem_conv_bn(x4, ops.weight_ohwi(resnet.conv1.weight), resnet.bn1, w8=ops.stem_weight_packed(resnet.conv1.weight))
+            z, st = ops.stem_conv_bn(x4, ops.weight_ohwi(resnet.conv1.weight), resnet.bn1, w8=lambda: ops.stem_weight_packed(resnet.conv1.weight))
         need = any(ctx.needs_input_grad)
         y, idx = ops.maxpool_affine_fwd(z, st, need)
         ops.nbt_inc(resnet.bn1)

@@ -859,7 +859,8 @@ def stem_tiles_ok(h, w):
 
 
 def stem_conv(x4, w_ohwi, w8=None):
-    """w8: the packed taps when the caller holds them (stem_weight_packed(param)); else packed here from w_ohwi"""
+    """w8: the packed taps of the generic kernel when the caller holds them (stem_weight_packed(param)), or a callable that makes them
+    (asked only when that kernel runs); else packed here from w_ohwi"""
     n, h, w, _ = x4.shape
     if CONV_PREC == 0 and stem_tiles_ok(h, w) and w_ohwi is not None:
         y = torch.empty((n, conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1), 64), device=x4.device, dtype=torch.float32)
@@ -867,6 +868,8 @@ def stem_conv(x4, w_ohwi, w8=None):
         PROF.run("conv_fwd", 2.0 * y.numel() * 147, lambda: call("uem_stem_conv_fwd", ptr(x4), ptr(wc), ptr(y), n, h, w, None, stream()),
                  executed=2.0 * y.numel() * 148)
         return y
+    if callable(w8):
+        w8 = w8()
     if w8 is None:
         w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
         call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
@@ -888,12 +891,16 @@ def stem_conv_bn(x4, w_ohwi, bn, w8=None):
         z = stem_conv(x4, w_ohwi, w8)
         return z, bn_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training, bn.eps,
                            bn.momentum if bn.momentum is not None else 0.1)
-    if w8 is None:
-        w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
-        call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
+    own_kernel = CONV_PREC == 0 and stem_tiles_ok(h, w) and w_ohwi is not None
+    if not own_kernel:
+        if callable(w8):
+            w8 = w8()
+        if w8 is None:
+            w8 = torch.empty((64, 7, 8, 4), device=x4.device, dtype=torch.float32)
+            call("uem_stem_pack_weight", ptr(w_ohwi), ptr(w8), stream())
     z = torch.empty((n, ho, wo, 64), device=x4.device, dtype=torch.float32)
     ts = torch.empty((M // 128, 2, 64), device=x4.device, dtype=torch.float32)
-    if CONV_PREC == 0 and stem_tiles_ok(h, w) and w_ohwi is not None:
+    if own_kernel:
         wc = _f32c(w_ohwi, "stem filter bank")
         PROF.run("conv_fwd", 2.0 * z.numel() * 147, lambda: call("uem_stem_conv_fwd", ptr(x4), ptr(wc), ptr(z), n, h, w, ptr(ts), stream()),
                  executed=2.0 * z.numel() * 148)
