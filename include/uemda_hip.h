@@ -179,6 +179,19 @@ int uem_bn_bwd_from_tiles(const float* tile_partials, int tiles, int C, float* d
 int uem_bn_bwd_apply(const float* x, const float* dy, const void* ymask, const float* scale, const float* shift,
                      const float* save_mean, const float* save_invstd, const float* dgamma,
                      const float* dbeta, int M, int C, int relu, float* dx, float* dres, void* stream);
+/* bn3's and the downsample BatchNorm's backward apply in ONE pass (round 5): the bottleneck blocks with a downsample branch end in
+ * y = relu(bn3(z3) + bn_ds(zd)) (uemda/_resnets.py:104-112), so both read the same dy gated by the same packed ReLU bits.
+ * dx1 = bn backward of x1 under vectors 1, dx2 = of x2 under vectors 2 (dgamma / dbeta: the finished channel sums of the reduction
+ * passes); dx2 may alias dy.  Same element arithmetic as uem_bn_bwd_apply(relu = UEM_RELU_BITS).  Large power-of-two-channel maps only
+ * (what the rows kernels take): UEM_ERR_UNSUPPORTED otherwise, nothing launched -- run the two uem_bn_bwd_apply passes.            */
+int uem_bn_bwd_apply_pair(const float* x1, const float* x2, const float* dy, const uint32_t* relu_bits, const float* scale1,
+                          const float* mean1, const float* invstd1, const float* dgamma1, const float* dbeta1, const float* scale2,
+                          const float* mean2, const float* invstd2, const float* dgamma2, const float* dbeta2, int M, int C, float* dx1,
+                          float* dx2, void* stream);
+int uem_bn_bwd_apply_pair_bf16(const uint16_t* x1, const uint16_t* x2, const uint16_t* dy, const uint32_t* relu_bits, const float* scale1,
+                               const float* mean1, const float* invstd1, const float* dgamma1, const float* dbeta1, const float* scale2,
+                               const float* mean2, const float* invstd2, const float* dgamma2, const float* dbeta2, int M, int C,
+                               uint16_t* dx1, uint16_t* dx2, void* stream);
 /* BatchNorm(+ReLU, mask recomputed from x) backward of the layer in front of that max-pool (autograd of bn1 / relu / maxpool,
  * uemda/_resnets.py:150-153), reading the POOLED gradient
  * dy_pool (N, Ho, Wo, C) and the argmax taps in gather form instead of uem_maxpool3x3s2_bwd's (N, H, W, C) output: same

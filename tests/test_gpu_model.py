@@ -173,6 +173,46 @@ def test_stem_conv_and_wgrad():
     torch.testing.assert_close(dw.permute(0, 3, 1, 2).cpu(), w.grad, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,Cn", [(32768, 256), (8192, 1024), (1000, 64)])
+def test_batchnorm_backward_pair_equals_the_two_passes(M, Cn):
+    """uem_bn_bwd_apply_pair[_bf16] (a bottleneck block with a downsample branch: bn3 and the downsample BatchNorm read the same gated
+    dy): the two outputs and the four parameter-gradient vectors are the ones two bn_backward calls give, bit for bit -- with bn3's
+    reduction done here and with its per-tile partial sums handed in, with dzd written over dy, and on a map too small for the rows
+    kernels (the entry declines, the host runs the two apply passes)."""
+    from uemda_amd import ops, ops_bf16 as ob
+    g = torch.Generator().manual_seed(M + Cn)
+    z3, zd = (torch.randn(M, Cn, generator=g) * 1.3 + 0.2).cuda(), (torch.randn(M, Cn, generator=g) * 0.7 - 0.1).cuda()
+    dy = torch.randn(M, Cn, generator=g).cuda()
+    gam = [(torch.rand(Cn, generator=g) + 0.5).cuda() for _ in range(2)]
+    bet = [(torch.randn(Cn, generator=g) * 0.3).cuda() for _ in range(2)]
+    rm, rv = torch.zeros(Cn).cuda(), torch.ones(Cn).cuda()
+    st3 = ops.bn_stats(z3, gam[0], bet[0], rm.clone(), rv.clone(), True)
+    std = ops.bn_stats(zd, gam[1], bet[1], rm.clone(), rv.clone(), True)
+    _, bits = ops.affine_act(z3, st3, res=zd, res_st=std, relu=True, want_bits=True)
+    gr = [torch.zeros(Cn).cuda() for _ in range(4)]
+    d3_ref = ops.bn_backward(z3, dy, st3, gr[0], gr[1], relu=True, ymask_bits=bits)
+    dd_ref = ops.bn_backward(zd, dy, std, gr[2], gr[3], relu=True, ymask_bits=bits)
+    gp = [torch.zeros(Cn).cuda() for _ in range(4)]
+    dyc = dy.clone()
+    d3, dd = ops.bn_backward_pair(z3, zd, dyc, bits, st3, std, None, gp[0], gp[1], gp[2], gp[3], dx2=dyc)
+    assert dd.data_ptr() == dyc.data_ptr()
+    assert torch.equal(d3, d3_ref) and torch.equal(dd, dd_ref)
+    for a, b in zip(gp, gr):
+        assert torch.equal(a, b)
+    # bf16 storage
+    z3b, zdb, dyb = z3.to(torch.bfloat16), zd.to(torch.bfloat16), dy.to(torch.bfloat16)
+    st3b = ops.bn_stats(z3b.float(), gam[0], bet[0], rm.clone(), rv.clone(), True)
+    stdb = ops.bn_stats(zdb.float(), gam[1], bet[1], rm.clone(), rv.clone(), True)
+    grb = [torch.zeros(Cn).cuda() for _ in range(4)]
+    d3b_ref = ob.bn_backward(z3b, dyb, st3b, grb[0], grb[1], relu=2, bits=bits)
+    ddb_ref = ob.bn_backward(zdb, dyb, stdb, grb[2], grb[3], relu=2, bits=bits)
+    gpb = [torch.zeros(Cn).cuda() for _ in range(4)]
+    d3b, ddb = ob.bn_backward_pair(z3b, zdb, dyb, bits, st3b, stdb, None, gpb[0], gpb[1], gpb[2], gpb[3])
+    assert torch.equal(d3b, d3b_ref) and torch.equal(ddb, ddb_ref)
+    for a, b in zip(gpb, grb):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("size", [(2, 16, 64), (3, 64, 128), (1, 144, 192)])
 def test_stem_kernels_of_round5(size):
     """csrc/stem.hip (whole 8 x 32 output tiles): forward against float64 conv2d and against the generic kernel it replaces, its

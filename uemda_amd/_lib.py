@@ -65,6 +65,8 @@ SIGNATURES = {
     "uem_bn_bwd_reduce": [P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
     "uem_bn_bwd_from_tiles": [P, I, I, P, P, P, P, P],
     "uem_bn_bwd_apply": [P, P, P, P, P, P, P, P, P, I, I, I, P, P, P],
+    "uem_bn_bwd_apply_pair": [P] * 14 + [I, I, P, P, P],
+    "uem_bn_bwd_apply_pair_bf16": [P] * 14 + [I, I, P, P, P],
     "uem_affine_act_bwd": [P, P, P, P, P, L, I, I, P, P, P],
     "uem_maxpool3x3s2_fwd": [P, P, P, I, I, I, I, P],
     "uem_maxpool3x3s2_bwd": [P, P, P, I, I, I, I, P],
@@ -192,6 +194,22 @@ def load():
         fn.restype = _RESTYPE.get(name, c_int)
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -2          # UEM_ERR_UNSUPPORTED: the entry point does not take this configuration and launched nothing
+
+
+def try_call(name, *args):
+    """Like call(), for entry points that may decline a configuration: False on UEM_ERR_UNSUPPORTED (nothing was launched; the caller
+    takes its other path), True on success, UemError on anything else."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc == ERR_UNSUPPORTED:
+        return False
+    if rc != 0:
+        msg = lib.uem_last_error()
+        raise UemError(f"{name} failed (code {rc}): {msg.decode() if msg else '?'}")
+    return True
 
 
 def call(name, *args):

@@ -923,6 +923,134 @@ extern "C" int uem_bn_bwd_apply_bf16(const uint16_t* x, const uint16_t* dy, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Two BatchNorm backward apply passes that share their incoming gradient (round 5): the bottleneck blocks with a downsample branch end in
+// y = relu(bn3(z3) + bn_ds(zd)) (_resnets.py:104-112), so bn3's and the downsample BatchNorm's backward both read dy gated by the same
+// packed ReLU bits.  One pass reads dy and the bits once, z3 and zd, and writes dz3 and dzd (dzd may overwrite dy): five tensor passes
+// instead of six.  Element arithmetic identical to bn_bwd_apply_rows_kernel / bn_bwd_apply_bf16x8_rows_kernel (UEM_RELU_BITS form).
+// ---------------------------------------------------------------------------------------------------------
+struct BnPairVec { const float *scale, *mean, *invstd, *dgamma, *dbeta; };
+template <int R>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pair_rows_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                                     const float* dy, const uint32_t* __restrict__ bits, const BnPairVec v1,
+                                                                     const BnPairVec v2, int64_t nvec, int C, float invM,
+                                                                     float* __restrict__ dx1, float* dx2) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)((i0 * 4) % C);
+    auto ld = [&](const float* p) { return *reinterpret_cast<const float4*>(p + c); };
+    auto scaled = [&](float4 a) { a.x *= invM; a.y *= invM; a.z *= invM; a.w *= invM; return a; };
+    const float4 sc1 = ld(v1.scale), mu1 = ld(v1.mean), is1 = ld(v1.invstd), dg1 = scaled(ld(v1.dgamma)), db1 = scaled(ld(v1.dbeta));
+    const float4 sc2 = ld(v2.scale), mu2 = ld(v2.mean), is2 = ld(v2.invstd), dg2 = scaled(ld(v2.dgamma)), db2 = scaled(ld(v2.dbeta));
+    float4 a[R], b[R], d[R];
+    uint32_t m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i < nvec) {
+            const size_t off = (size_t)i * 4;
+            a[r] = *reinterpret_cast<const float4*>(x1 + off);
+            b[r] = *reinterpret_cast<const float4*>(x2 + off);
+            d[r] = *reinterpret_cast<const float4*>(dy + off);
+            m[r] = bits[off >> 5];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i >= nvec) continue;
+        const size_t off = (size_t)i * 4;
+        const uint32_t mm = m[r] >> (off & 31);
+        float4 g = d[r];
+        g.x = (mm & 1u) ? g.x : 0.f; g.y = (mm & 2u) ? g.y : 0.f; g.z = (mm & 4u) ? g.z : 0.f; g.w = (mm & 8u) ? g.w : 0.f;
+        float4 o;
+        o.x = sc1.x * (g.x - db1.x - ((a[r].x - mu1.x) * is1.x) * dg1.x);
+        o.y = sc1.y * (g.y - db1.y - ((a[r].y - mu1.y) * is1.y) * dg1.y);
+        o.z = sc1.z * (g.z - db1.z - ((a[r].z - mu1.z) * is1.z) * dg1.z);
+        o.w = sc1.w * (g.w - db1.w - ((a[r].w - mu1.w) * is1.w) * dg1.w);
+        *reinterpret_cast<float4*>(dx1 + off) = o;
+        o.x = sc2.x * (g.x - db2.x - ((b[r].x - mu2.x) * is2.x) * dg2.x);
+        o.y = sc2.y * (g.y - db2.y - ((b[r].y - mu2.y) * is2.y) * dg2.y);
+        o.z = sc2.z * (g.z - db2.z - ((b[r].z - mu2.z) * is2.z) * dg2.z);
+        o.w = sc2.w * (g.w - db2.w - ((b[r].w - mu2.w) * is2.w) * dg2.w);
+        *reinterpret_cast<float4*>(dx2 + off) = o;
+    }
+}
+template <int R>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pair_bf16x8_rows_kernel(const bf16_t* __restrict__ x1, const bf16_t* __restrict__ x2,
+                                                                            const bf16_t* dy, const uint32_t* __restrict__ bits,
+                                                                            const BnPairVec v1, const BnPairVec v2, int64_t nvec, int C,
+                                                                            float invM, bf16_t* __restrict__ dx1, bf16_t* dx2) {
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const int c = (int)((i0 * 8) % C);
+    float sc1[8], mu1[8], is1[8], dg1[8], db1[8], sc2[8], mu2[8], is2[8], dg2[8], db2[8];
+    ldv8(v1.scale + c, sc1); ldv8(v1.mean + c, mu1); ldv8(v1.invstd + c, is1); ldv8(v1.dgamma + c, dg1); ldv8(v1.dbeta + c, db1);
+    ldv8(v2.scale + c, sc2); ldv8(v2.mean + c, mu2); ldv8(v2.invstd + c, is2); ldv8(v2.dgamma + c, dg2); ldv8(v2.dbeta + c, db2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg1[e] = dg1[e] * invM; db1[e] = db1[e] * invM; dg2[e] = dg2[e] * invM; db2[e] = db2[e] * invM; }
+    float a[R][8], b[R][8], d[R][8];
+    uint32_t m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i < nvec) {
+            const size_t off = (size_t)i * 8;
+            ld8(x1 + off, a[r]);
+            ld8(x2 + off, b[r]);
+            ld8(dy + off, d[r]);
+            m[r] = bits[off >> 5];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = i0 + r * stride;
+        if (i >= nvec) continue;
+        const size_t off = (size_t)i * 8;
+        const uint32_t mm = m[r] >> (off & 31);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[r][e] = ((mm >> e) & 1u) ? d[r][e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sc1[e] * (d[r][e] - db1[e] - ((a[r][e] - mu1[e]) * is1[e]) * dg1[e]);
+        st8(dx1 + off, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sc2[e] * (d[r][e] - db2[e] - ((b[r][e] - mu2[e]) * is2[e]) * dg2[e]);
+        st8(dx2 + off, o);
+    }
+}
+// UEM_ERR_UNSUPPORTED (nothing launched) unless the tensors are large power-of-two-channel maps the rows kernels take (the shapes of the
+// encoder's downsample blocks at training batch sizes); the caller then runs the two uem_bn_bwd_apply passes.
+extern "C" int uem_bn_bwd_apply_pair(const float* x1, const float* x2, const float* dy, const uint32_t* relu_bits, const float* scale1,
+                                     const float* mean1, const float* invstd1, const float* dgamma1, const float* dbeta1,
+                                     const float* scale2, const float* mean2, const float* invstd2, const float* dgamma2,
+                                     const float* dbeta2, int M, int C, float* dx1, float* dx2, void* stream) {
+    UEM_REQUIRE(x1 && x2 && dy && relu_bits && dx1 && dx2 && scale1 && mean1 && invstd1 && dgamma1 && dbeta1 && scale2 && mean2 && invstd2 &&
+                dgamma2 && dbeta2, "bn_bwd_apply_pair: null pointer");
+    UEM_REQUIRE(M > 0 && C > 0 && C % 32 == 0, "bn_bwd_apply_pair: bad shape");
+    const int64_t nvec = (int64_t)M * C / 4;
+    if (bn_rows(nvec, C, 4) < 2) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pair: shape not taken by the rows kernels");
+    const BnPairVec v1{scale1, mean1, invstd1, dgamma1, dbeta1}, v2{scale2, mean2, invstd2, dgamma2, dbeta2};
+    bn_bwd_apply_pair_rows_kernel<2><<<(unsigned)uem_cdiv(nvec, 512), 256, 0, (hipStream_t)stream>>>(x1, x2, dy, relu_bits, v1, v2, nvec, C,
+                                                                                                  1.0f / (float)M, dx1, dx2);
+    return uem_check_launch("bn_bwd_apply_pair");
+}
+extern "C" int uem_bn_bwd_apply_pair_bf16(const uint16_t* x1, const uint16_t* x2, const uint16_t* dy, const uint32_t* relu_bits,
+                                          const float* scale1, const float* mean1, const float* invstd1, const float* dgamma1,
+                                          const float* dbeta1, const float* scale2, const float* mean2, const float* invstd2,
+                                          const float* dgamma2, const float* dbeta2, int M, int C, uint16_t* dx1, uint16_t* dx2,
+                                          void* stream) {
+    UEM_REQUIRE(x1 && x2 && dy && relu_bits && dx1 && dx2 && scale1 && mean1 && invstd1 && dgamma1 && dbeta1 && scale2 && mean2 && invstd2 &&
+                dgamma2 && dbeta2, "bn_bwd_apply_pair_bf16: null pointer");
+    UEM_REQUIRE(M > 0 && C > 0 && C % 32 == 0, "bn_bwd_apply_pair_bf16: bad shape");
+    const int64_t nvec8 = (int64_t)M * C / 8;
+    if ((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dx1 | (uintptr_t)dx2) & 15) != 0 || bn_rows(nvec8, C, 8) < 2)
+        return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pair_bf16: shape not taken by the rows kernels");
+    const BnPairVec v1{scale1, mean1, invstd1, dgamma1, dbeta1}, v2{scale2, mean2, invstd2, dgamma2, dbeta2};
+    bn_bwd_apply_pair_bf16x8_rows_kernel<2><<<(unsigned)uem_cdiv(nvec8, 512), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const bf16_t*>(x1), reinterpret_cast<const bf16_t*>(x2), reinterpret_cast<const bf16_t*>(dy), relu_bits, v1, v2, nvec8,
+        C, 1.0f / (float)M, reinterpret_cast<bf16_t*>(dx1), reinterpret_cast<bf16_t*>(dx2));
+    return uem_check_launch("bn_bwd_apply_pair_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // BatchNorm(+ReLU) backward of the layer in front of a 3x3 / stride 2 / pad 1 max-pool (the stem), reading the POOLED gradient
 // (N, Ho, Wo, C) and the pool's argmax taps instead of a materialised (N, H, W, C) gradient.  Work item = one 2x2 block of
 // input pixels (2k..2k+1, 2j..2j+1): it lies in exactly the four windows (k..k+1, j..j+1), so four (tap, gradient) loads serve

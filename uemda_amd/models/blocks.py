@@ -201,7 +201,20 @@ class BottleneckFn(Function):
         # dy may be overwritten in place only when it is the buffer the next block's backward allocated for us (a gradient
         # handed in by the caller, or one autograd summed from several consumers, is left alone)
         own = lo is not None and lo.owns(dy)
-        if own and lo.tiles is not None:
+        dz3 = dzd = None
+        if ctx.has_ds and packed:
+            # bn3 and the downsample BatchNorm read the same gated dy: their apply passes run as one (dzd takes dy's place when it is ours)
+            tiles = lo.tiles if own and lo.tiles is not None else None
+            ds_bn = blk.downsample[1]
+            pair = ops.bn_backward_pair(z3, sv[8], dy, ybits, st3, _st_from(sv[9], ctx.training), tiles, gb(blk.bn3.weight),
+                                        gb(blk.bn3.bias), gb(ds_bn.weight), gb(ds_bn.bias), dx2=dy if own else None)
+            if pair is not None:
+                dz3, dzd = pair
+                if tiles is not None:
+                    lo.tiles = None
+        if dz3 is not None:
+            pass
+        elif own and lo.tiles is not None:
             dz3 = ops.bn_backward_from_partials(z3, dy, st3, lo.tiles, gb(blk.bn3.weight), gb(blk.bn3.bias), ybits, dres=dp)
             lo.tiles = None
         else:
@@ -243,8 +256,9 @@ class BottleneckFn(Function):
         if ctx.has_ds:
             zd, std = sv[8], _st_from(sv[9], ctx.training)
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
-            kw = dict(ymask_bits=ybits) if packed else dict(ymask=ybits)
-            dzd = ops.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=True, dx=dy if own else None, **kw)
+            if dzd is None:
+                kw = dict(ymask_bits=ybits) if packed else dict(ymask=ybits)
+                dzd = ops.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=True, dx=dy if own else None, **kw)
             ops.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s, side=True)
             wtd = ops.weight_transpose_cached(ds_conv.weight)
             if s == 1 and tail_ok:

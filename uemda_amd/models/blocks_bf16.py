@@ -120,7 +120,20 @@ class BottleneckBf16Fn(Function):
         # dy may be overwritten in place only when it is the buffer the next block's backward allocated for us
         own = lo is not None and lo.owns(dy)
         dp = None
-        if own and lo.tiles is not None:
+        dz3 = dzd = None
+        if ctx.has_ds:
+            # bn3 and the downsample BatchNorm read the same gated dy: their apply passes run as one (dzd takes dy's place when it is ours)
+            tiles = lo.tiles if own and lo.tiles is not None else None
+            ds_bn = blk.downsample[1]
+            pair = ob.bn_backward_pair(z3, sv[10], dy, bits, st3, _st_from(sv[11], ctx.training), tiles, gb(blk.bn3.weight),
+                                       gb(blk.bn3.bias), gb(ds_bn.weight), gb(ds_bn.bias), dx2=dy if own else None)
+            if pair is not None:
+                dz3, dzd = pair
+                if tiles is not None:
+                    lo.tiles = None
+        if dz3 is not None:
+            pass
+        elif own and lo.tiles is not None:
             dz3 = ob.bn_backward_from_partials(z3, dy, st3, lo.tiles, gb(blk.bn3.weight), gb(blk.bn3.bias), relu=2, bits=bits)
             lo.tiles = None
         elif need_dp:
@@ -143,7 +156,8 @@ class BottleneckBf16Fn(Function):
         if ctx.has_ds:
             zd, std = sv[10], _st_from(sv[11], ctx.training)
             ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
-            dzd = ob.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=2, bits=bits, dx=dy if own else None)
+            if dzd is None:
+                dzd = ob.bn_backward(zd, dy, std, gb(ds_bn.weight), gb(ds_bn.bias), relu=2, bits=bits, dx=dy if own else None)
             ob.conv2d_wgrad(x, dzd, G(ds_conv.weight), stride=s, side=True)
             wtd = ob.weight_t(ds_conv.weight)
             if s == 1 and tail_ok:

@@ -1006,6 +1006,43 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None
     return dx
 
 
+BN_PAIR = os.environ.get("UEM_BN_PAIR", "1") != "0"
+
+
+def bn_backward_pair(x1, x2, dy, bits, st1, st2, tiles1, gg1, gb1, gg2, gb2, dx2=None):
+    """bn3's and the downsample BatchNorm's backward of a bottleneck block with a downsample branch: both read dy gated by the same
+    packed ReLU bits, so their apply passes run as one (uem_bn_bwd_apply_pair).  tiles1: bn3's per-tile partial sums when its reduction
+    rode in the next block's data-gradient epilogue (blocks._Link), else None (reduced here).  Returns (dx1, dx2); dx2 may be dy.
+    Training-mode statistics; None when the pair kernel does not take the shape or a BatchNorm is frozen (the caller runs the two)."""
+    if not (BN_PAIR and st1.training and st2.training):
+        return None
+    C = x1.shape[-1]
+    M = x1.numel() // C
+    lib = _lib.load()
+    if C % 32 != 0 or x2.shape != x1.shape or bits is None:
+        return None
+    tmp = torch.empty((4, C), device=x1.device, dtype=torch.float32)
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if dx2 is None else dx2
+    # the reductions first (they are needed either way), then the one apply; a refusal of the pair entry is decided by shape alone
+    ws = torch.empty(lib.uem_bn_workspace_floats(M, C), device=x1.device, dtype=torch.float32)
+    if tiles1 is not None:
+        call("uem_bn_bwd_from_tiles", ptr(tiles1), tiles1.shape[0], C, ptr(tmp[0]), ptr(tmp[1]), ptr(gg1), ptr(gb1), stream())
+    else:
+        call("uem_bn_bwd_reduce", ptr(x1), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.shift), ptr(st1.mean), ptr(st1.invstd), M, C, 2,
+             ptr(tmp[0]), ptr(tmp[1]), ptr(gg1), ptr(gb1), ptr(ws), stream())
+    call("uem_bn_bwd_reduce", ptr(x2), ptr(dy), ptr(bits), ptr(st2.scale), ptr(st2.shift), ptr(st2.mean), ptr(st2.invstd), M, C, 2,
+         ptr(tmp[2]), ptr(tmp[3]), ptr(gg2), ptr(gb2), ptr(ws), stream())
+    if not _lib.try_call("uem_bn_bwd_apply_pair", ptr(x1), ptr(x2), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.mean), ptr(st1.invstd),
+                         ptr(tmp[0]), ptr(tmp[1]), ptr(st2.scale), ptr(st2.mean), ptr(st2.invstd), ptr(tmp[2]), ptr(tmp[3]), M, C,
+                         ptr(dx1), ptr(dx2), stream()):
+        call("uem_bn_bwd_apply", ptr(x1), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.shift), ptr(st1.mean), ptr(st1.invstd),
+             ptr(tmp[0]), ptr(tmp[1]), M, C, 2, ptr(dx1), None, stream())
+        call("uem_bn_bwd_apply", ptr(x2), ptr(dy), ptr(bits), ptr(st2.scale), ptr(st2.shift), ptr(st2.mean), ptr(st2.invstd),
+             ptr(tmp[2]), ptr(tmp[3]), M, C, 2, ptr(dx2), None, stream())
+    return dx1, dx2
+
+
 def maxpool_fwd(x, want_idx):
     n, h, w, c = x.shape
     ho, wo = conv_out_size(h, 3, 2, 1, 1), conv_out_size(w, 3, 2, 1, 1)

@@ -343,6 +343,36 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, relu, bits=None, want_dres=Fal
     return (dx, dres) if want_dres else dx
 
 
+def bn_backward_pair(x1, x2, dy, bits, st1, st2, tiles1, gg1, gb1, gg2, gb2, dx2=None):
+    """bf16 twin of ops.bn_backward_pair: bn3's and the downsample BatchNorm's backward of a block with a downsample branch, one apply
+    pass for both (uem_bn_bwd_apply_pair_bf16).  None when a BatchNorm is frozen or the switch is off (the caller runs the two)."""
+    if not (ops.BN_PAIR and st1.training and st2.training) or bits is None or x1.shape != x2.shape:
+        return None
+    C = x1.shape[-1]
+    M = x1.numel() // C
+    if C % 32 != 0:
+        return None
+    tmp = torch.empty((4, C), device=x1.device, dtype=torch.float32)
+    ws = torch.empty(_lib.load().uem_bn_workspace_floats(M, C), device=x1.device, dtype=torch.float32)
+    if tiles1 is not None:
+        call("uem_bn_bwd_from_tiles", ptr(tiles1), tiles1.shape[0], C, ptr(tmp[0]), ptr(tmp[1]), ptr(gg1), ptr(gb1), stream())
+    else:
+        call("uem_bn_bwd_reduce_bf16", ptr(x1), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.shift), ptr(st1.mean), ptr(st1.invstd), M, C, 2,
+             ptr(tmp[0]), ptr(tmp[1]), ptr(gg1), ptr(gb1), ptr(ws), stream())
+    call("uem_bn_bwd_reduce_bf16", ptr(x2), ptr(dy), ptr(bits), ptr(st2.scale), ptr(st2.shift), ptr(st2.mean), ptr(st2.invstd), M, C, 2,
+         ptr(tmp[2]), ptr(tmp[3]), ptr(gg2), ptr(gb2), ptr(ws), stream())
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if dx2 is None else dx2
+    if not _lib.try_call("uem_bn_bwd_apply_pair_bf16", ptr(x1), ptr(x2), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.mean), ptr(st1.invstd),
+                         ptr(tmp[0]), ptr(tmp[1]), ptr(st2.scale), ptr(st2.mean), ptr(st2.invstd), ptr(tmp[2]), ptr(tmp[3]), M, C,
+                         ptr(dx1), ptr(dx2), stream()):
+        call("uem_bn_bwd_apply_bf16", ptr(x1), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.shift), ptr(st1.mean), ptr(st1.invstd),
+             ptr(tmp[0]), ptr(tmp[1]), M, C, 2, ptr(dx1), None, stream())
+        call("uem_bn_bwd_apply_bf16", ptr(x2), ptr(dy), ptr(bits), ptr(st2.scale), ptr(st2.shift), ptr(st2.mean), ptr(st2.invstd),
+             ptr(tmp[2]), ptr(tmp[3]), M, C, 2, ptr(dx2), None, stream())
+    return dx1, dx2
+
+
 def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, relu, bits=None, dx=None):
     """BatchNorm backward whose reduction pass already ran in a data-gradient epilogue (tp = its per-tile partial sums)."""
     C = x.shape[-1]
