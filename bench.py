@@ -340,9 +340,10 @@ def short_leg(cfg, steps=6, warmup=2):
     bf16 = cfg.storage == "bf16"
     out = dict(value=round(s.tiles_per_step / dt, 2), unit=f"tiles({cfg.size}x{cfg.size})/s", ms_per_step=round(1e3 * dt, 2), steps=steps,
                warmup=warmup, dtype="bf16 storage (fp32 accumulate / statistics / master weights)" if cfg.storage == "bf16" else "f32",
-               workload=f"{cfg.model}-{cfg.head} {cfg.workload} step, {cfg.batch} source + {cfg.batch} target {cfg.size}x{cfg.size} tiles",
+               workload=f"{cfg.model}-{cfg.head} {cfg.workload} step, {cfg.batch} source + {cfg.batch if cfg.workload == 'ssl' else 0} target {cfg.size}x{cfg.size} tiles",
                roofline=roofline_of(ops.PROF.summary(), BF16_MATRIX_PEAK_TFLOPS if bf16 else F32_MATRIX_PEAK_TFLOPS),
-               peak_allocated_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
+               peak_allocated_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1),
+               peak_reserved_GB=round(torch.cuda.max_memory_reserved() / 1e9, 1))
     ops.PROF.records = []
     if cfg.storage == "bf16" and cfg.size <= 512 and not getattr(cfg, "no_hipgraph", False):
         out["hipgraph"] = replay_leg(s, cfg.workload, warmup + steps, s.tiles_per_step)     # where the host's share was largest (16 of 45 ms)
@@ -350,6 +351,53 @@ def short_leg(cfg, steps=6, warmup=2):
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start the N rank processes -- fresh children of a parent that has made no GPU
+    call -- through `torch.distributed.run` (one rank per GPU, rendezvous on 127.0.0.1), forward their output (rank 0 prints the
+    JSON line) and return the launcher's exit code, which is non-zero when any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver supports dmabuf IPC only (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"--gpus {n} without a torchrun environment: launching {n} ranks ({' '.join(cmd[1:8])} ...)")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args):
+    """`--launch-check`: the rank plumbing of this file WITHOUT the model -- process group, barrier, K timed no-op steps, MAX of the
+    elapsed time over the ranks, rank 0's one JSON line -- so that `--gpus N` meaning N ranks can be tested where there is no GPU
+    (tests/test_dp_gloo.py, gloo).  It measures nothing: `value` is null."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("UEM_LAUNCH_CHECK_FAIL_RANK") == str(rank):          # the test of "a failed rank fails the launcher"
+        raise SystemExit(f"launch check: rank {rank} was told to fail")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ranks = torch.zeros(world, dtype=torch.float64)
+    ranks[rank] = 1.0
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no model, no GPU)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * float(t) / max(1, args.steps), 3),
+                          "ranks_seen": int(ranks.sum()), "launch_check": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -381,7 +429,20 @@ def main():
                     "(nccl backend: the all-reduces are captured; the ranks agree on the capture's success before anyone replays)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configurations (bf16 storage, PPM head, R101 1024^2; N=1 only)")
+    ap.add_argument("--launch-check", action="store_true", help="rank plumbing only (process group, barrier, max-over-ranks timing, one "
+                    "JSON line from rank 0) without the model or a GPU: the CPU test of `--gpus N`")
     args = ap.parse_args()
+
+    # `--gpus N` means N ranks.  Under torchrun (the driver's launch line) WORLD_SIZE says so already; a bare `python bench.py --gpus N`
+    # starts the ranks itself, as fresh children, BEFORE this process makes any GPU call -- and never prints an n_gpus: 1 line for it.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(launch_ranks(args.gpus))
+    if int(env_world or "1") != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world or 1}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself when no torchrun environment is set)")
+    if args.launch_check:
+        return launch_check(args)
 
     from uemda_amd import dp as udp, ops
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
@@ -392,8 +453,8 @@ def main():
     if args.device is not None:
         torch.cuda.set_device(args.device)
     rank, world, local = udp.init(args.backend, device=args.device)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")
     torch.cuda.set_device(local if args.device is None else args.device)
 
     make_wrapper = (lambda m: udp.DataParallel(m, overlap=not args.no_overlap)) if (world > 1 or udp.FORCE) else None
@@ -571,6 +632,8 @@ def main():
                                             measured="HIP events on the compute stream around the phase in the last timed step; bytes = "
                                                      "SURVEY 8(d)'s 25.2 MB per target tile (soft 6.29 + superpixels 2.10 + features 8.39 read, "
                                                      "refined soft 6.29 + hard labels 2.10 written) x tiles")
+                if roof is not None:           # mirrored inside `roofline`, the object the driver's parsed record keeps
+                    roof["hbm_phase"] = {k: line["roofline_hbm"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms", "tiles")}
         ms = mem_f
         line["device_memory"] = {"peak_allocated_GB": round(ms.get("allocated_bytes.all.peak", 0) / 1e9, 1),
                                  "peak_reserved_GB": round(ms.get("reserved_bytes.all.peak", 0) / 1e9, 1),
@@ -594,6 +657,7 @@ def main():
         torch.cuda.empty_cache()
         oc = {}
         legs = {"bf16 storage r50-aspp 512": dict(storage="bf16"), "fp32 r50-ppm 512": dict(head="ppm"),
+                "fp32 r50-aspp 512 src (BASELINE config 2: fwd+bwd only)": dict(workload="src"),
                 "bf16 storage r101-aspp 1024 (BASELINE config 5, one GPU's share)": dict(storage="bf16", model="resnet101", size=1024)}
         for name, over in legs.items():
             cfg = types.SimpleNamespace(**{**vars(args), "data_rank": None, **over})

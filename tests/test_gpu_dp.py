@@ -65,6 +65,20 @@ def _two_ranks(path, *args, env=None):
     return line, [torch.load(f"{path}.rank{r}.pt") for r in range(2)]
 
 
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun environment starts its two ranks itself (fresh children of a parent that made no GPU
+    call) and rank 0's line says n_gpus: 2 -- here both ranks share device 0 over gloo, the only two-rank form one MI355X allows."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", *COMMON],
+                         env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, _report(out.returncode, out.stdout, out.stderr)
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["replicas_identical"] and line["value"] > 0
+    assert line["config"]["global_batch"] == 2 * 2 * 4            # (source + target) x per-rank batch x ranks
+
+
 def test_single_rank_rccl_step_matches_plain_step():
     plain = _bench({})
     forced = _bench({"UEM_DP_FORCE": "1", "MASTER_PORT": str(_free_port())})
