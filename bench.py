@@ -278,8 +278,11 @@ def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
         kw = dict(sup_ignore_id=s.sup_ignore) if workload == "ssl" else {}
         if s.wrapper is not None:
             kw["dp"] = s.wrapper                   # the data-parallel step: RCCL's all-reduces are captured with it
+        # data parallel: NO eager warm-up step inside the constructor (a rank that failed there would leave its peers inside a
+        # real gradient all-reduce; the timed steps above were the warm-up -- same shapes, the optimizer has stepped); the capture itself
+        # executes no collective, and the ranks agree on its success right after
         gs = GraphedStep(_ssl if workload == "ssl" else _src, s.model, s.aligner if workload == "ssl" else None, s.opt, s.state,
-                         s.batch, warmup=1, lr=s.lr_at(step0), **kw)
+                         s.batch, warmup=0 if s.wrapper is not None else 1, lr=s.lr_at(step0), **kw)
     except Exception as e:                    # noqa: BLE001
         err = repr(e)[:300]
     # data parallel: replay only a graph that EVERY rank holds (a rank replaying alone would launch collectives nobody joins); the

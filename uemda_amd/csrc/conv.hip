@@ -538,6 +538,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
 // =========================================================================================================
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 extern "C" __device__ void uem_raw_buffer_load_lds(i32x4 rsrc, lds_u32p lds, int size, int voffset, int soffset, int offset,
                                                    int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 #define CONV_OOB 0xFFFFFFF0u
@@ -858,13 +859,22 @@ __global__ __launch_bounds__(256, (ConvDmaCfg<BN, KB, PERSIST>::BPC)) void conv_
 // = k-steps x 1.3 us + epilogue): a 256-row tile does twice (BN = 128) or four times (BN = 256) the MFMA work per round trip and
 // moves half the operand bytes per flop from L2 into LDS; its wave tile 64 x 128 (BN = 256) reads 0.75 KB of LDS per MFMA where
 // 64 x 64 reads 1 KB.
-template <int BN, bool PERSIST = false, int BMT = 128>
+// NST (round 6): stages of the operand ring.  2 = rounds 2-5 (the next k-step requested under the current one's MFMAs and waited for at
+// the next barrier).  3 (256-row persistent blocks only): TWO k-steps in flight -- the per-shape table of the step said every k-step
+// exposed one round trip (tile time = k-steps x 1.3 us + epilogue: 0.2-0.4 us of MFMAs per k-step and CU against 1.3 us of latency),
+// and with one 256-row block per CU nobody else covers it.  The barrier in front of k-step g waits with a COUNTED vmcnt for the
+// pieces of step g only (the pieces of step g + 1, requested during step g - 1, stay in flight: loads, stores and LDS-DMA retire in
+// issue order), the ring keeps running across the block's tiles -- the next tile's first two k-steps fly under this tile's last MFMA
+// phases and its whole epilogue -- and the epilogue's barriers are LDS-only (a __syncthreads() there drains the DMA queue).
+template <int BN, bool PERSIST = false, int BMT = 128, int NST = 2>
 struct ConvBf16Cfg {
     static constexpr int A_ELEMS = BMT * KBH, B_ELEMS = BN * KBH;         // bf16 elements per stage
     static constexpr int RAW_STAGE_BYTES = (A_ELEMS + B_ELEMS) * 2;
     static constexpr int EPI_BYTES = 64 * (BN + 4) * 4;
     static constexpr int STAGE_BYTES = PERSIST && RAW_STAGE_BYTES < EPI_BYTES ? EPI_BYTES : RAW_STAGE_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+    static constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
+    static_assert(NST == 2 || (PERSIST && BMT == 256), "the deeper ring is built for the persistent 256-row blocks");
+    static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the CU's LDS");
 };
 __device__ __forceinline__ unsigned short f2bf(float f) {                  // RNE, NaN stays NaN (hipcc: v_cvt_pk_bf16_f32)
     const __bf16 b = (__bf16)f;
@@ -876,9 +886,10 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // epilogue that tests its options per row keeps the compiler from batching the LDS reads, conversions and stores:
 //   0  full dense tiles, plain store;  1  full dense tiles + BatchNorm tile statistics (forward) / the residual tail and
 //   BatchNorm-backward options (data gradient);  -1  anything (ragged last tile, strided output rows, accumulate in forward)
-template <int BN, int MODE, int EPI, bool PERSIST, int BMT = 128>
+template <int BN, int MODE, int EPI, bool PERSIST, int BMT = 128, int NST = 2>
 __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes, const int ntiles) {
-    using C = ConvBf16Cfg<BN, PERSIST, BMT>;
+    using C = ConvBf16Cfg<BN, PERSIST, BMT, NST>;
+    constexpr bool RING = NST > 2;
     constexpr int NTH = 2 * BMT, NW = NTH / 64, RPS = NTH / 8;            // threads, waves, rows per DMA pass (8 lanes per 128-B row)
     constexpr int WM = BMT / 64, WN = 2, MT = BMT / WM / 32, NT = BN / WN / 32, BR = BN / RPS;
     static_assert(MT == 2 && BMT / RPS == 4, "a wave owns 64 rows; four A pieces per thread and k-step");
@@ -1051,6 +1062,18 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     // stores every thread issues per tile: a lower bound is all the counted wait needs)
     constexpr bool LAZY = PERSIST && EPI >= 0 && !(MODE == 1 && EPI == 1);
     constexpr int EPI_STORES = NCH * NRP;
+    static_assert(!RING || EPI >= 0, "the ring serves full dense tiles");
+    // LDS-only barrier (ring): a __syncthreads() with LDS-DMA pieces outstanding makes the compiler drain them (vmcnt(0))
+#define EPI_SYNC()                                                              \
+    do {                                                                        \
+        if constexpr (RING) {                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
+            __builtin_amdgcn_s_barrier();                                       \
+            asm volatile("" ::: "memory");                                      \
+        } else {                                                                \
+            __syncthreads();                                                    \
+        }                                                                       \
+    } while (0)
     static_assert(EPI_STORES >= 1 && EPI_STORES < 48, "counted wait out of the counter's range");
     float* stg = smem;                                                   // PERSIST: the stage the tile consumed last
     const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
@@ -1059,7 +1082,8 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     const bool fuse_bn = MODE == 1 && EPI != 0 && p.tile_bnbwd != nullptr;
     const bool acc_on = (EPI == 0 || (EPI == 1 && MODE == 0)) ? false : p.accumulate != 0;
     const bool stats_on = MODE == 0 && (EPI == 1 || (EPI < 0 && p.tile_stats != nullptr));
-    const bool ablate_store = EPI < 0 && (UEM_DBG(p.dbg) & 1), ablate_stage = EPI < 0 && (UEM_DBG(p.dbg) & 2);
+    const bool ablate_store = (EPI < 0 || RING) && (UEM_DBG(p.dbg) & 1), ablate_stage = (EPI < 0 || RING) && (UEM_DBG(p.dbg) & 2);
+    const bool ablate_epi = RING && (UEM_DBG(p.dbg) & 8);                 // DEBUG_HOOKS builds only: the tile's epilogue skipped altogether
     const unsigned short* const zh = reinterpret_cast<const unsigned short*>(p.bn_z);
     const unsigned short* const ah = p.acc_src != nullptr ? reinterpret_cast<const unsigned short*>(p.acc_src) : yh;
     float pb[8], pg[8], bsc[8], bsh[8], bmu[8], bis[8];
@@ -1092,7 +1116,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     __builtin_amdgcn_s_barrier();                                   \
     asm volatile("" ::: "memory")
     unsigned short* const st0 = lds16;
-    if (KT > 0) step(st0, st0 + C::STAGE_BYTES / 2, issue_live, false);  // first operand tile of the block's first tile
+    constexpr int SE = C::STAGE_BYTES / 2;                               // bf16 elements per stage
+    if (RING && (UEM_DBG(p.dbg) >> 8) && (blockIdx.x & 1)) {             // DEBUG_HOOKS: odd blocks start (dbg >> 8) x 3.4 us late (chip-wide phase lock?)
+        for (int i = 0; i < (UEM_DBG(p.dbg) >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    if (KT > 0) step(st0, st0 + SE, issue_live, false);                  // first operand tile of the block's first tile
+    if (RING && KT > 0) step(st0 + SE, st0, issue_live, false);          // ... and the second k-step of the issue stream (maybe the next tile's)
     int par = 0;                                                         // stage the next k-step consumes
     for (int vc = blockIdx.x; vc < ntiles; vc += gridDim.x) {
         {
@@ -1112,9 +1141,31 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) { bsc[e] = v4[e]; bsh[e] = v4[p.Cout + e]; bmu[e] = v4[2 * p.Cout + e]; bis[e] = v4[3 * p.Cout + e]; }
         }
-        if (EPI < 0 || (MODE == 1 && EPI == 1)) epi_fetch(0);
+        if (!RING && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(0);
         if (KT > 0) {
             for (int kt = 0; kt < KT; ++kt) {
+                if constexpr (RING) {
+                    // the epilogue's own operands (fused data gradients) are requested in front of the tile's LAST k-step: younger than
+                    // every operand piece the tile still waits for, so no k-step barrier waits for an HBM stream (rounds 4-5: requested
+                    // before the main loop they made persistence a loss for these epilogues)
+                    // step g needs the pieces requested during step g - 2; younger than those are the NPC pieces of step g - 1 and, on
+                    // the first k-step of a later tile, the epilogue's stores in between (a lower bound is all a counted wait needs)
+                    // ... which holds for the SECOND k-step of a later tile as well (its pieces were requested during the previous tile's
+                    // last k-step, before that tile's epilogue): only from the third k-step on does a wait for operand pieces imply a
+                    // wait for the previous tile's stores to be acknowledged (one counter, retired in order)
+                    if (kt <= 1 && vc != (int)blockIdx.x && !(UEM_DBG(p.dbg) & 16)) {
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC + EPI_STORES) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC) : "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if ((MODE == 1 && EPI == 1) && kt == KT - 1) epi_fetch(0);
+                    const int fs = par == 0 ? NST - 1 : par - 1;
+                    step(st0 + fs * SE, st0 + par * SE, issue_live, true);
+                    par = par + 1 == NST ? 0 : par + 1;
+                    continue;
+                }
                 if (LAZY && p.lazy && kt == 0 && vc != (int)blockIdx.x) {
                     // first k-step of a later tile of the block: its operand pieces were requested under the PREVIOUS tile's last
                     // MFMA phase and every thread has issued at least EPI_STORES stores since (the epilogue's rows) -- the memory
@@ -1126,13 +1177,13 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                 } else {
                     CONV_SYNC();
                 }
-                step(st0 + (par ^ 1) * (C::STAGE_BYTES / 2), st0 + par * (C::STAGE_BYTES / 2), issue_live, true);
+                step(st0 + (par ^ 1) * SE, st0 + par * SE, issue_live, true);
                 par ^= 1;
             }
             // every wave past its last operand read, every DMA piece landed: the last step's out-of-range pieces (not persistent: the
             // staging area spans both stages) or the next tile's first operand tile (persistent: in the other stage)
-            if (LAZY && p.lazy) {
-                // the pieces in flight fill the OTHER stage: nothing the epilogue touches -- it only needs every wave past its LDS reads
+            if (RING || (LAZY && p.lazy)) {
+                // the pieces in flight fill the OTHER stage(s): nothing the epilogue touches -- it only needs every wave past its LDS reads
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -1142,9 +1193,13 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
         } else {
             __syncthreads();
         }
-        if (PERSIST) stg = reinterpret_cast<float*>(st0 + (par ^ 1) * (C::STAGE_BYTES / 2));
+        if (PERSIST) stg = reinterpret_cast<float*>(st0 + (RING ? (par == 0 ? NST - 1 : par - 1) : (par ^ 1)) * SE);   // the stage consumed last
 
         // ---- epilogue (operands prefetched above) ---------------------------------------------------------------
+        if (ablate_epi) {
+            if (acc[0][0][0] == 123456.f) yh[0] = 1;                         // keep the accumulators alive
+            continue;
+        }
 #pragma unroll
         for (int hm = 0; hm < NCH; ++hm) {
             if (wm / 64 == hm && !ablate_stage) {
@@ -1157,7 +1212,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                         for (int r = 0; r < 16; ++r)
                             stg[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LDW + wn + j * 32 + fr] = acc[i][j][r];
             }
-            __syncthreads();
+            EPI_SYNC();
             if (hm + 1 < NCH && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(hm + 1);
             bool rok[NRP];
 #pragma unroll
@@ -1171,13 +1226,32 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                 abyte[u] = has_ab ? (eab[hm & 1][u] >> bshift) & 0xffu : 0xffu;
                 bbyte[u] = has_zb ? (ebb[hm & 1][u] >> bshift) & 0xffu : 0u;
             }
+            // ring: the staged accumulators are read by hand-written ds_read_b128 -- the compiler orders every LDS read it can see behind
+            // every outstanding LDS-DMA piece AND, with them, behind the previous chunk's global stores (an `s_waitcnt vmcnt(0)` in front
+            // of each chunk's first read, found in the ISA: the next tile's operand prefetch and the write acknowledgements of the rows
+            // just stored were waited for four times per tile); the reads are ordered by the barrier above and waited for right here
+            f32x4v svlo[NRP], svhi[NRP];
+            if constexpr (RING) {
+#pragma unroll
+                for (int u = 0; u < NRP; ++u) {
+                    const unsigned la = (unsigned)(unsigned long long)(lds_u32p)(&stg[(srow + u * RPP) * LDW + sc8]);
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(svlo[u]), "=&v"(svhi[u]) : "v"(la));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int u = 0; u < NRP; ++u) {
                 const int row = srow + u * RPP;
                 if (!rok[u]) continue;
                 float v[8];
-                *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8]);
-                *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8 + 4]);
+                if constexpr (RING) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = svlo[u][e]; v[4 + e] = svhi[u][e]; }
+                } else {
+                    *reinterpret_cast<float4*>(&v[0]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8]);
+                    *reinterpret_cast<float4*>(&v[4]) = *reinterpret_cast<const float4*>(&stg[row * LDW + sc8 + 4]);
+                }
                 if (acc_on) {
                     const unsigned w4[4] = {o[u].x, o[u].y, o[u].z, o[u].w};
 #pragma unroll
@@ -1211,7 +1285,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                     }
                 }
             }
-            __syncthreads();
+            EPI_SYNC();
             // column sums over 128 rows = two chunks: the partial-sum tensors keep one entry per 128 rows whatever the block's tile
             // (the finalize kernels merge 128-row groups)
             float* const tile_out = fuse_bn ? p.tile_bnbwd : (stats_on ? p.tile_stats : nullptr);
@@ -1220,7 +1294,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                 float* const red = stg;                                      // [2][RPP][BN]
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; pb[e] = pg[e] = 0.f; }
-                __syncthreads();
+                EPI_SYNC();
                 for (int i = tid; i < 2 * BN; i += NTH) {
                     const int which = i / BN, col = i % BN;
                     float a = 0.f;
@@ -1229,12 +1303,13 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                     const size_t tiles_m = (size_t)(p.M / 128);
                     tile_out[((size_t)which * p.Cout + n0 + col) * tiles_m + (size_t)(m0 / 128 + (hm >> 1))] = a;
                 }
-                if (hm + 1 < NCH) __syncthreads();                           // red is the next chunk's staging area
+                if (hm + 1 < NCH) EPI_SYNC();                           // red is the next chunk's staging area
             }
         }
         if (!PERSIST) break;
     }                                                                    // tiles of a persistent block
 #undef CONV_SYNC
+#undef EPI_SYNC
 }
 
 static int conv_check(const uem_conv_shape* s) {
@@ -2188,17 +2263,41 @@ extern "C" int uem_aspp_unpack_grad(const float* dwall, const float* db, void* c
 // =========================================================================================================
 static int g_bf16_persist = -1;  // tuning override: 1 / 0 = persistent blocks on / off, -1 = rule
 extern "C" void uemdbg_conv_bf16_persist(int v) { g_bf16_persist = v; }
-template <int BN_, int MODE, int EPI, bool PERSIST, int BMT = 128>
+template <int BN_, int MODE, int EPI, bool PERSIST, int BMT = 128, int NST = 2>
 static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
-    using C = ConvBf16Cfg<BN_, PERSIST, BMT>;
+    using C = ConvBf16Cfg<BN_, PERSIST, BMT, NST>;
     const int ntiles = (int)uem_cdiv(p.M, BMT) * (p.Cout / BN_);
     // persistent: one block per resident-block slot (LDS: one 256-row, two 128-wide or three 64-wide blocks per CU; a multiple of 8,
     // so a block's tiles stay on its XCD's share)
     const int per_cu = BMT == 256 ? 1 : (160 * 1024 / C::LDS_BYTES > 3 ? 3 : 160 * 1024 / C::LDS_BYTES);
     const int slots = 256 * per_cu;
     const int grid = PERSIST && ntiles > slots ? slots : ntiles;
-    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT>;
+    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT, NST>;
     if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 2 * BMT, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
+}
+// Ring of three operand stages on persistent 256-row blocks (conv_bf16_kernel<..., NST = 3>): full dense tiles, forward (plain / with the
+// BatchNorm tile statistics) and data gradient (plain / residual tail / BatchNorm-backward partial sums).  -1 = rule, 0 = never,
+// 1 = wherever legal (tests, sweeps).
+static int g_bf16_ring = -1;
+extern "C" void uemdbg_conv_bf16_ring(int v) { g_bf16_ring = v; }
+template <int MODE>
+static int conv_bf16_ring_bn(const ConvP& p) {
+    static const int env = getenv("UEM_CONV_BF16_RING") ? atoi(getenv("UEM_CONV_BF16_RING")) : -1;
+    const int set = g_bf16_ring >= 0 ? g_bf16_ring : env;
+    if (set == 0 || p.M % 256 != 0 || (MODE == 1 && p.sub != 1) || p.ntaps <= 0) return 0;
+    if (MODE == 0 && p.accumulate) return 0;
+    const int bn = p.Cout % 128 == 0 ? 128 : 64;
+    if (set == 1) return bn;
+    // rule (scripts/sweep_conv_bf16_ring.py, profiles/r06_*_conv_bf16_ring_sweep.txt): at least one tile per CU
+    const int ntiles = (p.M / 256) * (p.Cout / bn);
+    static const int min_tiles = getenv("UEM_CONV_BF16_RING_MIN_TILES") ? atoi(getenv("UEM_CONV_BF16_RING_MIN_TILES")) : 256;
+    return ntiles >= min_tiles ? bn : 0;
+}
+template <int BN_, int MODE>
+static void conv_bf16_ring_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+    const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
+    if (extras) conv_bf16_launch<BN_, MODE, 1, true, 256, 3>(p, xb, wb, st);
+    else conv_bf16_launch<BN_, MODE, 0, true, 256, 3>(p, xb, wb, st);
 }
 static int g_bf16_lazy = -1;     // tuning override: counted waits around the persistent blocks' epilogue on / off, -1 = environment / default
 extern "C" void uemdbg_conv_bf16_lazy(int v) { g_bf16_lazy = v; }
@@ -2317,8 +2416,11 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
         p.x_ld = s->x_ld; p.y_ld = s->y_ld; p.M = s->N * s->Ho * s->Wo;
         const double xb = (double)p.N * p.H * p.W * p.x_ld * 2.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 2.0;
         if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
-        const int big = conv_bf16_big_bn<0>(p);
-        if (big == 256) conv_bf16_go<256, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
+        const int ring = conv_bf16_ring_bn<0>(p);
+        const int big = ring ? 0 : conv_bf16_big_bn<0>(p);
+        if (ring == 128) conv_bf16_ring_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        else if (ring == 64) conv_bf16_ring_go<64, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        else if (big == 256) conv_bf16_go<256, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
         else if (big == 128) conv_bf16_go<128, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
         else if (p.Cout % 128 == 0) conv_bf16_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
         else conv_bf16_go<64, 0>(p, (unsigned)xb, (unsigned)wb, st);
@@ -2356,8 +2458,11 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
             static const int wt_env = getenv("UEM_BF16_WIDE_TAIL") ? atoi(getenv("UEM_BF16_WIDE_TAIL")) : 0;
             const bool wide_tail = wt_env != 0 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout &&
                                    (wt_env != 2 || p.Cin <= 256);
-            const int big = wide_tail ? 0 : conv_bf16_big_bn<1>(p);
-            if (big == 256) conv_bf16_go<256, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
+            const int ring = wide_tail ? 0 : conv_bf16_ring_bn<1>(p);
+            const int big = (wide_tail || ring) ? 0 : conv_bf16_big_bn<1>(p);
+            if (ring == 128) conv_bf16_ring_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            else if (ring == 64) conv_bf16_ring_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            else if (big == 256) conv_bf16_go<256, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
             else if (big == 128) conv_bf16_go<128, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
             else if (p.Cout % 128 == 0 && !wide_tail) conv_bf16_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
             else conv_bf16_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);

@@ -133,6 +133,7 @@ class DataParallel:
     def reduce_gradients(self):
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
+        ops.side_join()            # side-stream weight gradients land before the arena goes out (also after a backward that raised)
         if self._split is not None and self._fwd_calls != self._bwd_calls:
             # a train-mode forward whose graph never ran backward (a validation pass left in .train(), a dropped
             # output): the early bucket was (rightly) not sent, nothing is wrong with THIS step's gradients, but

@@ -166,6 +166,7 @@ class Deeplabv2(nn.Module):
         """Zero the flat gradient arena (one memset) and keep every .grad attached to it."""
         if self._grad_arena is None:
             return super().zero_grad(set_to_none)
+        ops.side_join()             # weight gradients a failed backward left on the side stream must not land after the memset
         self._grad_arena.zero_()
         for p in self.parameters():
             if p.grad is None and p.requires_grad:           # a frozen parameter keeps .grad = None, as under torch autograd

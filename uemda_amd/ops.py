@@ -4,6 +4,7 @@ device allocations and the stream; every arithmetic step is a `uem_*` HIP kernel
 Internal activation layout is NHWC: tensors of shape (N, H, W, C), contiguous, fp32.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -186,8 +187,9 @@ class _Side:
 
     def __init__(self):
         self.stream = torch.cuda.Stream()
-        self.queued = False              # an end-of-backward join is pending
+        self.task = None                 # id of the backward graph task whose end-of-backward callback will join (None: no join queued)
         self.dirty = False               # work was queued since the last join
+        self.reads = []                  # (first byte, past-the-end byte, label) of what the queued launches read, since the last join
 
     @classmethod
     def get(cls):
@@ -198,21 +200,52 @@ class _Side:
         return st
 
     def join(self):
-        self.queued = False
+        self.task = None
+        self.reads.clear()
         if self.dirty:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.dirty = False
 
 
 def side_join():
-    """main stream waits for the side stream's weight gradients (no-op when none are pending): the data-parallel bucket trigger calls
-    this before a slice of the gradient arena goes out; the end-of-backward callback is the same call"""
+    """main stream waits for the side stream's weight gradients (no-op when none are pending).  Called by the end-of-backward callback,
+    by the data-parallel bucket trigger before a slice of the gradient arena goes out, and -- ADVICE r5 -- unconditionally at the top of
+    FusedSGD.step / clip_grad_norm_ / DataParallel.reduce_gradients: a backward pass that RAISED after a launch was queued never runs
+    its final callbacks, and whoever reads the gradient arena next must still wait for the side stream."""
+    if not _Side.by_device:           # no side stream was ever used in this process (also: CPU-only hosts)
+        return
     st = _Side.by_device.get(torch.cuda.current_device())
     if st is not None:
         st.join()
 
 
-def on_side(launch, tensors):
+def _byte_range(t):
+    lo = t.data_ptr()
+    return lo, lo + t.numel() * t.element_size()
+
+
+def guard_write(t, what):
+    """GUARD: a main-stream kernel is about to write into the EXISTING buffer `t` (an `out=` / `dx=` handed in by
+    the caller, i.e. an in-place update the allocator knows nothing about).  If a side-stream launch queued since the last join reads
+    any byte of it, that is a race between the two streams -- the first side-stream build lost one exactly so (DESIGN 8, round 5:
+    PPM step goldens red) -- and it fails HERE, loudly, instead of racing.  Kernels write through raw pointers and never move a
+    tensor's `_version`, so the guard works on byte ranges, not on versions.  Costs nothing when no side launch is pending."""
+    if t is None:
+        return
+    st = _Side.by_device.get(t.device.index)
+    if st is None or not st.reads:
+        return
+    lo, hi = _byte_range(t)
+    for a, b, label, alive in st.reads:
+        # a range whose tensor is gone no longer guards anything: its memory was recorded on the side stream (record_stream), so the
+        # caching allocator hands it out again only after the side launch has run -- a fresh tensor at that address is no race
+        if lo < b and a < hi and alive() is not None:
+            raise UemError(f"{what}: writes in place into a buffer ({tuple(t.shape)} at 0x{lo:x}) that a weight gradient queued on the "
+                           f"side stream still reads ({label}); the main stream may overwrite only what no pending side launch reads "
+                           f"(ops.on_side / ops.side_join)")
+
+
+def on_side(launch, tensors, label="weight gradient"):
     st = _Side.get()
     main = torch.cuda.current_stream()
     if main == st.stream:
@@ -222,17 +255,27 @@ def on_side(launch, tensors):
         launch()
     for t in tensors:
         t.record_stream(st.stream)
+        st.reads.append(_byte_range(t) + (f"{label} reading {tuple(t.shape)}", weakref.ref(t if t._base is None else t._base)))
     st.dirty = True
-    if not st.queued:
+    # one join per backward pass, queued in THAT pass: the flag is the graph task's id, not a boolean -- a pass that raised after
+    # queueing never ran its callbacks, and a boolean left True would keep every later pass from queueing its own
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:
+        st.join()                        # not inside a backward pass (a direct call from a test or a script): join right away
+    elif st.task != tid:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(st.join)
-            st.queued = True
-        except RuntimeError:             # not inside a backward pass (a direct call from a test or a script): join right away
+            st.task = tid
+        except RuntimeError:
             st.join()
 
 
 
-SIDE_OFF = 0            # > 0: no side stream (GraphedStep raises it around its warm-up steps and its capture)
+SIDE_OFF = 0            # > 0: no side stream (GraphedStep raises it around its capture when UEM_GRAPH_SIDE=0)
+# Round 6: the side stream is captured WITH the step (a fork at the first weight gradient of a backward pass, a join at its end): the
+# Winograd weight gradient no longer allocates inside its side-stream launch (_WinoSideWs), which is what had invalidated the capture in
+# round 5.  UEM_GRAPH_SIDE=0: the capture keeps the side stream out again (the replay is then the serial step).
+GRAPH_SIDE = os.environ.get("UEM_GRAPH_SIDE", "1") != "0"
 
 
 def in_backward():
@@ -242,7 +285,7 @@ def in_backward():
     # allocation on a second stream during a capture invalidates it -- hipErrorStreamCaptureInvalidated, which took the whole bench line
     # down in a rehearsal of this round; a replayed graph serialises the side stream's nodes anyway: bf16 39.4 ms without, 40.0 with)
     return ((not torch.is_grad_enabled()) and torch._C._current_graph_task_id() >= 0 and not PROF.enabled and SIDE_OFF == 0
-            and not torch.cuda.is_current_stream_capturing())
+            and (GRAPH_SIDE or not torch.cuda.is_current_stream_capturing()))
 
 
 def need_gpu(*tensors):
@@ -347,6 +390,8 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     s.x_ld, s.y_ld = cin, cout
     if out is None:
         out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
+    else:
+        guard_write(out, "conv2d_dgrad(out=)")
     flags = CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0) | CONV_PREC_BWD
     flops = 2.0 * n * dy.shape[1] * dy.shape[2] * (algo_cout or cout) * kh * kw * cin
     PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_fwd", ptr(dy), ptr(w_t), None, None, None, ptr(out),
@@ -404,6 +449,8 @@ def conv2d_dgrad_tail(dy, w_t, x_shape, acc_src=None, acc_bits=None, out=None, a
     s.x_ld, s.y_ld = cin, cout
     if out is None:
         out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.float32)
+    else:
+        guard_write(out, "conv2d_dgrad_tail(out=)")
     M = n * h * w
     tp = torch.empty((M // 128, 2, cin), device=dy.device, dtype=torch.float32) if bn_z is not None else None
     flags = CONV_PREC_BWD | (CONV_ACCUMULATE if accumulate else 0)
@@ -423,6 +470,7 @@ def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, ymask_bits, 
     partial sums): finalize + apply only."""
     C = x.shape[-1]
     M = x.numel() // C
+    guard_write(dx, "bn_backward_from_partials(dx=)"), guard_write(dres, "bn_backward_from_partials(dres=)")
     dx = torch.empty_like(x) if dx is None else dx
     tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
     call("uem_bn_bwd_from_tiles", ptr(tp), tp.shape[0], C, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
@@ -807,6 +855,28 @@ def conv3x3_wino_dgrad_bn_backward(dy, param, z, st, gamma_grad, beta_grad, dil,
     return da
 
 
+class _WinoSideWs:
+    """Temporaries of the Winograd weight gradient when it runs on the SIDE stream, owned per shape and pre-sized:
+    the transformed dY (npos, T, Cout), the transformed-domain accumulator dU (npos, Cout, Cin) and, where V is recomputed, V
+    (npos, T, Cin).  They used to be allocated inside the launch, i.e. on the side stream -- which kept the side stream out of a hipGraph
+    capture (round 5: hipErrorStreamCaptureInvalidated) and grew the side stream's own allocator pool (peak reserved 63 -> 82 GB).
+    Launches of one shape run one after the other on the side stream, so one set per shape is enough; it is allocated on the MAIN stream
+    at first use (the side stream waits for the main stream before every launch) and lives as long as the process (1.2 GB for R50 at
+    B = 32: 36 x T x C floats per distinct 3x3 layer shape).  Main-stream launches keep their per-call allocations."""
+    sets = {}
+
+    @classmethod
+    def get(cls, device, npos, t, cout, cin, need_v):
+        key = (device.index, npos, t, cout, cin)
+        ws = cls.sets.get(key)
+        if ws is None:
+            ws = cls.sets[key] = dict(dm=torch.empty((npos, t, cout), device=device, dtype=torch.float32),
+                                      du=torch.empty((npos, cout, cin), device=device, dtype=torch.float32), v=None)
+        if need_v and ws["v"] is None:
+            ws["v"] = torch.empty((npos, t, cin), device=device, dtype=torch.float32)
+        return ws
+
+
 def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None, in_relu=False, m=None, side=False):
     """dw (Cout,3,3,Cin) += weight gradient from dy (N,H,W,Cout) and the transformed input V (npos, T, Cin) the forward saved; with
     v None, V is recomputed from the conv input x (through the producer's BatchNorm affine + ReLU) at tile edge m."""
@@ -820,20 +890,31 @@ def conv3x3_wino_wgrad(v, dy, dw_ohwi, dil, x=None, in_scale=None, in_shift=None
         cin = v.shape[2]
     else:
         cin = x.shape[-1]
+    npos, t = (m + 2) ** 2, n * h * w // (m * m)
+    on_the_side = side and SIDE_WGRAD_F32 and in_backward()
+    ws = _WinoSideWs.get(dy.device, npos, t, cout, cin, v is None) if on_the_side else None
 
     def run():
-        vv = v if v is not None else wino_input(x, dil, in_scale, in_shift, in_relu, m, which=2)
-        npos, t, _ = vv.shape
-        dm = torch.empty((npos, t, cout), device=dy.device, dtype=torch.float32)
-        du = torch.empty((npos, cout, cin), device=dy.device, dtype=torch.float32)       # cleared by the dY transform's launch
+        if v is not None:
+            vv = v
+        elif ws is not None:
+            vv = ws["v"]
+            call("uem_wino_input", ptr(x), ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, ptr(vv), n, h, w, cin, dil, m, 2, stream())
+        else:
+            vv = wino_input(x, dil, in_scale, in_shift, in_relu, m, which=2)
+        if ws is not None:
+            dm, du = ws["dm"], ws["du"]
+        else:
+            dm = torch.empty((npos, t, cout), device=dy.device, dtype=torch.float32)
+            du = torch.empty((npos, cout, cin), device=dy.device, dtype=torch.float32)   # cleared by the dY transform's launch
         call("uem_wino_dy", ptr(dy), ptr(dm), n, h, w, cout, dil, m, ptr(du), du.numel(), stream())
         call("uem_wino_wgrad_gemm", ptr(vv), ptr(dm), ptr(du), t, cin, cout, npos, stream())
         call("uem_wino_filter_grad", ptr(du), ptr(dw_ohwi), cout, cin, m, stream())
 
     alg, exe = _wino_flops(n * h * w, cout, cin, m)
-    if side and SIDE_WGRAD_F32 and in_backward():             # side: as in conv2d_wgrad
+    if on_the_side:             # side: as in conv2d_wgrad
         on_side(lambda: PROF.run("conv_wgrad", alg, run, executed=exe, who="conv3x3_wino_wgrad"),
-                [t for t in (v, dy, x, in_scale, in_shift) if t is not None])
+                [t_ for t_ in (v, dy, x, in_scale, in_shift) if t_ is not None], "Winograd weight gradient")
     else:
         PROF.run("conv_wgrad", alg, run, executed=exe)
 
@@ -968,6 +1049,7 @@ def affine_act(x, st, res=None, res_st=None, relu=True, out=None, want_bits=Fals
     """y = relu?(x*scale + shift (+ res [*res_scale + res_shift])).  want_bits: also return the packed sign bits of y
     (int32 words, 1/32 of y) that bn_backward(ymask_bits=...) reads instead of y."""
     C = x.shape[-1]
+    guard_write(out, "affine_act(out=)")
     out = torch.empty_like(x) if out is None else out
     bits = torch.empty(x.numel() // 32, device=x.device, dtype=torch.int32) if want_bits else None
     call("uem_affine_act", ptr(x), ptr(st.scale), ptr(st.shift), ptr(res),
@@ -980,6 +1062,7 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, ymask=None, relu=True, dx=None
     """BatchNorm(+ReLU) backward.  Accumulates into gamma_grad/beta_grad; returns dx (may alias dy)."""
     C = x.shape[-1]
     M = x.numel() // C
+    guard_write(dx, "bn_backward(dx=)"), guard_write(dres, "bn_backward(dres=)")
     dx = torch.empty_like(x) if dx is None else dx
     if ymask_bits is not None:
         ymask, relu = ymask_bits, 2          # UEM_RELU_BITS
@@ -1023,6 +1106,7 @@ def bn_backward_pair(x1, x2, dy, bits, st1, st2, tiles1, gg1, gb1, gg2, gb2, dx2
         return None
     tmp = torch.empty((4, C), device=x1.device, dtype=torch.float32)
     dx1 = torch.empty_like(x1)
+    guard_write(dx2, "bn_backward_pair(dx2=)")
     dx2 = torch.empty_like(x2) if dx2 is None else dx2
     # the reductions first (they are needed either way), then the one apply; a refusal of the pair entry is decided by shape alone
     ws = torch.empty(lib.uem_bn_workspace_floats(M, C), device=x1.device, dtype=torch.float32)

@@ -67,6 +67,8 @@ def conv2d_dgrad(dy, w_t, x_shape, stride=1, pad=0, dil=1, out=None, accumulate=
     s.x_ld, s.y_ld = cin, cout
     if out is None:
         out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.bfloat16)
+    else:
+        ops.guard_write(out, "conv2d_dgrad_bf16(out=)")
     flops = 2.0 * n * dy.shape[1] * dy.shape[2] * cout * kh * kw * cin
     ops.PROF.run("conv_dgrad", flops, lambda: call("uem_conv2d_bf16", ptr(dy), ptr(w_t), ptr(out), ctypes.byref(s),
                                                    CONV_TRANSPOSED | (CONV_ACCUMULATE if accumulate else 0), None, stream()))
@@ -93,6 +95,8 @@ def conv2d_dgrad_tail(dy, w_t, x_shape, acc_src=None, acc_bits=None, out=None, a
     s.x_ld, s.y_ld = cin, cout
     if out is None:
         out = torch.empty((n, h, w, cin), device=dy.device, dtype=torch.bfloat16)
+    else:
+        ops.guard_write(out, "conv2d_dgrad_tail_bf16(out=)")
     M = n * h * w
     tp = torch.empty((M // 128, 2, cin), device=dy.device, dtype=torch.float32) if bn_z is not None else None
     flops = 2.0 * n * dy.shape[1] * dy.shape[2] * cout * kh * kw * cin
@@ -137,7 +141,7 @@ def conv2d_wgrad(x, dy, dw_ohwi, stride=1, pad=0, dil=1, side=False):
             ops.PROF.run("conv_wgrad", flops, lambda: call("uem_conv2d_wgrad_bf16", ptr(x), ptr(dy), ptr(dw_ohwi), ctypes.byref(s), stream()),
                          who="conv2d_wgrad")
         if side and SIDE_WGRAD and ops.in_backward():            # side: only for gradient-arena views (ops.conv2d_wgrad)
-            _on_side(launch, (x, dy))
+            _on_side(launch, (x, dy), "bf16 weight gradient")
         else:
             launch()
     except UemError as e:
@@ -336,6 +340,7 @@ def bn_backward(x, dy, st, gamma_grad, beta_grad, relu, bits=None, want_dres=Fal
         # dx = dp*scale -- the apply pass with both batch sums zero; gamma / beta, when still trainable, took sum dp*xhat / sum dp
         # (xhat from the running statistics) in the reduce above
         tmp.zero_()
+    ops.guard_write(dx, "bn_backward_bf16(dx=)")
     dx = torch.empty_like(x) if dx is None else dx
     dres = torch.empty_like(x) if want_dres else None
     call("uem_bn_bwd_apply_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
@@ -362,6 +367,7 @@ def bn_backward_pair(x1, x2, dy, bits, st1, st2, tiles1, gg1, gb1, gg2, gb2, dx2
     call("uem_bn_bwd_reduce_bf16", ptr(x2), ptr(dy), ptr(bits), ptr(st2.scale), ptr(st2.shift), ptr(st2.mean), ptr(st2.invstd), M, C, 2,
          ptr(tmp[2]), ptr(tmp[3]), ptr(gg2), ptr(gb2), ptr(ws), stream())
     dx1 = torch.empty_like(x1)
+    ops.guard_write(dx2, "bn_backward_pair_bf16(dx2=)")
     dx2 = torch.empty_like(x2) if dx2 is None else dx2
     if not _lib.try_call("uem_bn_bwd_apply_pair_bf16", ptr(x1), ptr(x2), ptr(dy), ptr(bits), ptr(st1.scale), ptr(st1.mean), ptr(st1.invstd),
                          ptr(tmp[0]), ptr(tmp[1]), ptr(st2.scale), ptr(st2.mean), ptr(st2.invstd), ptr(tmp[2]), ptr(tmp[3]), M, C,
@@ -379,6 +385,7 @@ def bn_backward_from_partials(x, dy, st, tp, gamma_grad, beta_grad, relu, bits=N
     M = x.numel() // C
     tmp = torch.empty((2, C), device=x.device, dtype=torch.float32)
     call("uem_bn_bwd_from_tiles", ptr(tp), tp.shape[0], C, ptr(tmp[0]), ptr(tmp[1]), ptr(gamma_grad), ptr(beta_grad), stream())
+    ops.guard_write(dx, "bn_backward_from_partials_bf16(dx=)")
     dx = torch.empty_like(x) if dx is None else dx
     call("uem_bn_bwd_apply_bf16", ptr(x), ptr(dy), ptr(bits), ptr(st.scale), ptr(st.shift), ptr(st.mean), ptr(st.invstd),
          ptr(tmp[0]), ptr(tmp[1]), M, C, int(relu), ptr(dx), None, stream())

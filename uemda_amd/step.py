@@ -161,39 +161,46 @@ class GraphedStep:
             if aligner is None:
                 return step_fn(model, optimizer, state, batch, float(lr), **kw)
             return step_fn(model, aligner, optimizer, state, batch, float(lr), **kw)
-        # the weight gradients' side stream (ops.on_side) stays out of the warm-up steps and of the capture: what the capture records is
-        # one stream's work, and nothing of the eager steps before may still be in flight on another stream when it starts
+        # The weight gradients' side stream (ops.on_side) is captured with the step (round 6): the warm-up steps run it too, so that the
+        # side stream exists and the Winograd weight gradients' per-shape workspaces (ops._WinoSideWs) are allocated BEFORE the capture --
+        # an allocation on a second stream during a capture is what invalidated it in round 5.  Nothing of the eager steps may still be
+        # in flight on another stream when the capture starts.  UEM_GRAPH_SIDE=0 keeps the side stream out of the capture as before.
         torch.cuda.synchronize()
-        ops.SIDE_OFF += 1
+        graph_side = ops.GRAPH_SIDE
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm-up off the default stream, as torch.cuda.graph asks
+            for _ in range(max(int(warmup), 1 if optimizer._steps == 0 else 0)):
+                run()
+            ops.side_join()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if aligner is not None:
+            # the warm-up steps' superpixel-range report is collected NOW: inside the step the check no longer waits (round 5), and a
+            # report still pending at the capture would be queried there -- hipEventQuery under a capture invalidates it (this took
+            # bench.py's replay leg down in a rehearsal: hipErrorStreamCaptureInvalidated)
+            aligner.check_superpixel_ids()
+        # the weight-preparation job table is fixed before the capture (a single warm-up step leaves it half built) and stays alive as
+        # long as the graph whose refresh launch reads it -- and so does every parameter / derived bank the table points at, including
+        # those of OTHER models alive on the device now (the captured launch covers the whole table)
+        self._prep_tables = ops.PREP.settle()
+        self._prep_hold = ops.PREP.hold()
+        self._side_ws = dict(ops._WinoSideWs.sets)       # the captured side-stream launches write into these: keep them alive
+        self.graph = torch.cuda.CUDAGraph()
+        steps_before = optimizer._steps
+        # With a process group alive, its watchdog thread polls its work events (hipEventQuery) whenever it likes: under the default
+        # "global" capture mode such a call from ANOTHER thread while this one captures is an error, raised in that thread -- the
+        # process aborts, now and then (seen once in four runs of the captured data-parallel step).  "thread_local" checks this
+        # thread's calls only; what is recorded is the same (capture is per stream).
+        mode = "thread_local" if (dp is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else "global"
+        if not graph_side:
+            ops.SIDE_OFF += 1
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                    # warm-up off the default stream, as torch.cuda.graph asks
-                for _ in range(max(int(warmup), 1 if optimizer._steps == 0 else 0)):
-                    run()
-            torch.cuda.current_stream().wait_stream(side)
-            if aligner is not None:
-                # the warm-up steps' superpixel-range report is collected NOW: inside the step the check no longer waits (round 5), and a
-                # report still pending at the capture would be queried there -- hipEventQuery under a capture invalidates it (this took
-                # bench.py's replay leg down in a rehearsal: hipErrorStreamCaptureInvalidated)
-                torch.cuda.current_stream().synchronize()
-                aligner.check_superpixel_ids()
-            # the weight-preparation job table is fixed before the capture (a single warm-up step leaves it half built) and stays alive as
-            # long as the graph whose refresh launch reads it -- and so does every parameter / derived bank the table points at, including
-            # those of OTHER models alive on the device now (the captured launch covers the whole table)
-            self._prep_tables = ops.PREP.settle()
-            self._prep_hold = ops.PREP.hold()
-            self.graph = torch.cuda.CUDAGraph()
-            steps_before = optimizer._steps
-            # With a process group alive, its watchdog thread polls its work events (hipEventQuery) whenever it likes: under the default
-            # "global" capture mode such a call from ANOTHER thread while this one captures is an error, raised in that thread -- the
-            # process aborts, now and then (seen once in four runs of the captured data-parallel step).  "thread_local" checks this
-            # thread's calls only; what is recorded is the same (capture is per stream).
-            mode = "thread_local" if (dp is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else "global"
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.out = run()
         finally:
-            ops.SIDE_OFF -= 1
+            if not graph_side:
+                ops.SIDE_OFF -= 1
         optimizer._steps = steps_before                  # the capture pass ran the host side of step() without taking a step
 
     @staticmethod
