@@ -30,10 +30,14 @@ def timeit(fn, reps=8):
 
 
 def same(a, b):
+    """bf16 tensors bit for bit; fp32 tensors (the per-128-row partial sums, whose summation order depends on the tile shape) to 1e-5 of
+    the column's magnitude"""
     if isinstance(a, (tuple, list)):
         return all(same(x, y) for x, y in zip(a, b))
     if a is None:
         return b is None
+    if a.dtype == torch.float32:
+        return bool(((a - b).abs() <= 1e-5 * (a.abs() + b.abs()) + 1e-3).all())
     return bool(torch.equal(a, b))
 
 
@@ -42,9 +46,13 @@ def main():
     scale = int(os.environ.get("SCALE", "1"))
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     lib = _lib.load()
+    what = os.environ.get("SWEEP", "split")                  # ring: the three-stage ring with the classic epilogue; split: + loader / storer waves
     lib.uemdbg_conv_bf16_ring.argtypes = [ctypes.c_int]
     lib.uemdbg_conv_bf16_ring.restype = None
-    print(f"B={B} scale={scale}   times in ms: round-5 dispatch / ring, change; '!' = outputs differ")
+
+    def switch(on):
+        lib.uemdbg_conv_bf16_ring({"ring": 1, "split": 2}[what] if on else 0)
+    print(f"B={B} scale={scale}   times in ms: round-5 dispatch / {what}, change; '!' = outputs differ beyond the statistics' summation order")
     print(f"{'shape':22s} {'M':>8s} {'tiles':>6s} | {'fwd':>21s} | {'dgrad':>21s} | {'bnbwd':>21s} | {'tail':>21s}")
     tot = {}
     for name, cin, cout, k, s, d, hin, cnt in SHAPES:
@@ -75,15 +83,15 @@ def main():
             if fn is None:
                 cells.append(f"{'-':>21s}")
                 continue
-            lib.uemdbg_conv_bf16_ring(0)
+            switch(False)
             ref = fn()
             t0 = timeit(fn)
-            lib.uemdbg_conv_bf16_ring(1)
+            switch(True)
             out = fn()
             t1 = timeit(fn)
-            lib.uemdbg_conv_bf16_ring(0)
+            switch(False)
             t0 = min(t0, timeit(fn))
-            lib.uemdbg_conv_bf16_ring(1)
+            switch(True)
             t1 = min(t1, timeit(fn))
             ok = same(ref, out)
             cells.append(f"{t0:6.3f} {t1:6.3f} {100 * (t1 / t0 - 1):+6.1f}%{' ' if ok else '!'}")

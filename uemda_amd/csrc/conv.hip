@@ -886,19 +886,30 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // epilogue that tests its options per row keeps the compiler from batching the LDS reads, conversions and stores:
 //   0  full dense tiles, plain store;  1  full dense tiles + BatchNorm tile statistics (forward) / the residual tail and
 //   BatchNorm-backward options (data gradient);  -1  anything (ragged last tile, strided output rows, accumulate in forward)
-template <int BN, int MODE, int EPI, bool PERSIST, int BMT = 128, int NST = 2>
+// SPLIT (round 6): the vector-memory counter of a wave retires loads, stores and LDS-DMA pieces in issue order, so a wave that stores its
+// share of a tile and then waits for operand pieces waits for the stores' ACKNOWLEDGEMENTS first -- microseconds under load, once per tile,
+// with the matrix pipe idle (ablation, profiles/r06_b_conv_bf16_ring_ablation.txt: 256 -> 1024 on 64 x 64 maps, 144 us with the stores, 100
+// without; streaming the stores between the next tile's MFMAs made it WORSE, 196 us: every k-step then waited for store
+// acknowledgements, profiles/r06_c_*).  The waves therefore split the roles: the first half of the block (LOADERS) issues every operand piece
+// and never stores -- its counted wait sees pieces only; the second half (STORERS) writes the tile out and never waits on the
+// vector-memory counter at all -- its stores drain behind the next tile's MFMAs.  All waves run the MFMAs.
+template <int BN, int MODE, int EPI, bool PERSIST, int BMT = 128, int NST = 2, bool SPLIT = false>
 __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(const ConvP p, const unsigned x_bytes, const unsigned w_bytes, const int ntiles) {
     using C = ConvBf16Cfg<BN, PERSIST, BMT, NST>;
     constexpr bool RING = NST > 2;
-    constexpr int NTH = 2 * BMT, NW = NTH / 64, RPS = NTH / 8;            // threads, waves, rows per DMA pass (8 lanes per 128-B row)
+    constexpr int NTH = 2 * BMT, NW = NTH / 64;                           // threads, waves
+    constexpr int NWL = SPLIT ? NW / 2 : NW, RPS = NWL * 8, NA = BMT / RPS;   // loader waves, rows per DMA pass (8 lanes per 128-B row), A pieces per loader thread
     constexpr int WM = BMT / 64, WN = 2, MT = BMT / WM / 32, NT = BN / WN / 32, BR = BN / RPS;
-    static_assert(MT == 2 && BMT / RPS == 4, "a wave owns 64 rows; four A pieces per thread and k-step");
+    static_assert(MT == 2 && (NA == 4 || NA == 8), "a wave owns 64 rows; four (eight: split roles) A pieces per loader thread and k-step");
+    static_assert(!SPLIT || (PERSIST && EPI >= 0 && !(MODE == 1 && EPI == 1)), "split roles: persistent blocks on full tiles without epilogue loads");
+    constexpr bool RAWB = RING || SPLIT;                                  // epilogue with LDS-only barriers and hand-written staging reads
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
     const unsigned short* const xh = reinterpret_cast<const unsigned short*>(p.x);
     unsigned short* const yh = reinterpret_cast<unsigned short*>(p.y);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = !SPLIT || wave < NWL, is_storer = !SPLIT || wave >= NWL;      // wave-uniform
     const int tiles_n = p.Cout / BN;
     int m0 = 0, n0 = 0;                                                  // compute side: the tile whose accumulators the block holds
     const int lrow = tid >> 3;                                           // DMA: 8 lanes per 128-B row, rows lrow + RPS*j
@@ -913,19 +924,19 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     // block's next tile while the current one still computes)
     int vi = blockIdx.x, in0 = 0;
     bool issue_live = vi < ntiles;
-    int gy[4], gx[4], gpix[4];
+    int gy[NA], gx[NA], gpix[NA];
     auto issue_tile_setup = [&]() {
         const int tile = xcd_remap(vi, ntiles);
         const int im0 = (tile / tiles_n) * BMT;
         in0 = (tile % tiles_n) * BN;
         if (pointwise) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { gy[j] = gx[j] = 0; gpix[j] = (im0 + lrow + RPS * j < p.M) ? im0 + lrow + RPS * j : -1; }
+            for (int j = 0; j < NA; ++j) { gy[j] = gx[j] = 0; gpix[j] = (im0 + lrow + RPS * j < p.M) ? im0 + lrow + RPS * j : -1; }
         } else {
             const int HoWo = (MODE == 1) ? p.Hs * p.Ws : p.Ho * p.Wo;
             const int Wrow = (MODE == 1) ? p.Ws : p.Wo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NA; ++j) {
                 const int m = im0 + lrow + RPS * j;
                 if (m < p.M) {
                     const int n = m / HoWo, rem = m - n * HoWo;
@@ -940,12 +951,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     issue_tile_setup();
     const int cpb = p.Cin / KBH, KT = p.ntaps * cpb, Ktot = p.KH * p.KW * p.Cin;
     int lt = 0, lci0 = 0;
-    unsigned tapok = 0, aoff[4], boff[BR];
+    unsigned tapok = 0, aoff[NA], boff[BR];
     auto setup_tap = [&](int t) {
         if (pointwise) {
             tapok = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NA; ++j) {
                 aoff[j] = ((unsigned)gpix[j] * (unsigned)p.x_ld + (unsigned)lc8) * 2u;
                 tapok |= (gpix[j] >= 0 ? 1u : 0u) << j;
             }
@@ -958,7 +969,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
         const int kx = tap - ky * p.KW;
         tapok = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NA; ++j) {
             bool ok = gpix[j] >= 0;
             int iy, ix;
             if (MODE == 1) {
@@ -987,20 +998,21 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     // one -- 4 + BR pieces per 16 MFMAs here, where a burst of them in front of the MFMA phase cost more issue time than the MFMAs
     // themselves take -- and the step has ONE call site (stages chosen by address).  A step with nothing left to request sends its
     // pieces with an out-of-range offset (no memory access).
-    constexpr int NPC = 4 + BR, NKS = KBH / 16;
+    constexpr int NPC = NA + BR, NKS = KBH / 16;
     auto step = [&](unsigned short* __restrict__ fill, const unsigned short* __restrict__ use, const bool live_, const bool do_phase) {
         const bool live = live_ && !(UEM_DBG(p.dbg) & 4);
         unsigned short* const fAs = fill;
         unsigned short* const fBs = fill + C::A_ELEMS;
         if (live && lci0 == 0) setup_tap(lt);
         auto piece = [&](const int j) {
-            if (j < 4) {
+            if (SPLIT && !is_loader) return;                             // split roles: the storer waves issue no operand pieces
+            if (j < NA) {
                 const bool ok = live && ((tapok >> j) & 1u);
-                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(fAs + (j * NW + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
+                uem_raw_buffer_load_lds(rs_x, (lds_u32p)(fAs + (j * NWL + wave) * 512), 16, (int)(ok ? aoff[j] : CONV_OOB), 0, 0, 0);
                 aoff[j] += KBH * 2;
             } else if (j < NPC) {
-                const int jb = j - 4;
-                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(fBs + (jb * NW + wave) * 512), 16, (int)(live ? boff[jb] : CONV_OOB), 0, 0, 0);
+                const int jb = j - NA;
+                uem_raw_buffer_load_lds(rs_w, (lds_u32p)(fBs + (jb * NWL + wave) * 512), 16, (int)(live ? boff[jb] : CONV_OOB), 0, 0, 0);
                 boff[jb] += KBH * 2;
             }
         };
@@ -1056,7 +1068,8 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
         const int yy = rem / p.Ws, xx = rem - yy * p.Ws;
         return (((size_t)ni * p.Ho + (size_t)(yy * p.sub + p.py)) * p.Wo + (size_t)(xx * p.sub + p.px)) * p.y_ld;
     };
-    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = NTH / TPR, NRP = 64 / RPP, NCH = BMT / 64;     // the epilogue walks NCH chunks of 64 rows
+    constexpr int NTS = SPLIT ? NTH / 2 : NTH;                            // threads that write the tile out (split roles: the storer waves)
+    constexpr int LDW = BN + 4, TPR = BN / 8, RPP = NTS / TPR, NRP = 64 / RPP, NCH = BMT / 64;     // the epilogue walks NCH chunks of 64 rows
     // LAZY (round 5, persistent blocks on full tiles without epilogue loads): the barrier in front of the epilogue does not wait for the
     // next tile's operand pieces and the first barrier of the next tile does not wait for the epilogue's stores (EPI_STORES = the
     // stores every thread issues per tile: a lower bound is all the counted wait needs)
@@ -1066,7 +1079,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     // LDS-only barrier (ring): a __syncthreads() with LDS-DMA pieces outstanding makes the compiler drain them (vmcnt(0))
 #define EPI_SYNC()                                                              \
     do {                                                                        \
-        if constexpr (RING) {                                                   \
+        if constexpr (RAWB) {                                                   \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  \
             __builtin_amdgcn_s_barrier();                                       \
             asm volatile("" ::: "memory");                                      \
@@ -1076,7 +1089,8 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
     } while (0)
     static_assert(EPI_STORES >= 1 && EPI_STORES < 48, "counted wait out of the counter's range");
     float* stg = smem;                                                   // PERSIST: the stage the tile consumed last
-    const int srow = tid / TPR, sc8 = (tid % TPR) * 8;
+    const int etid = SPLIT ? (tid - NTH / 2) & (NTS - 1) : tid;          // storer-relative thread index (loader waves never use theirs)
+    const int srow = etid / TPR, sc8 = (etid % TPR) * 8;
     // data gradient only: the residual tail (identity gradient acc_src*[acc_bits]) and the first pass of a BatchNorm(+ReLU)
     // backward over the rounded dx (same contract as the fp32 kernel's epilogue, bf16 tensors)
     const bool fuse_bn = MODE == 1 && EPI != 0 && p.tile_bnbwd != nullptr;
@@ -1153,7 +1167,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                     // ... which holds for the SECOND k-step of a later tile as well (its pieces were requested during the previous tile's
                     // last k-step, before that tile's epilogue): only from the third k-step on does a wait for operand pieces imply a
                     // wait for the previous tile's stores to be acknowledged (one counter, retired in order)
-                    if (kt <= 1 && vc != (int)blockIdx.x && !(UEM_DBG(p.dbg) & 16)) {
+                    if constexpr (SPLIT) {
+                        // loader waves: nothing but operand pieces in their queue, NPC per k-step; storer waves: no wait on the
+                        // vector-memory counter at all (their stores drain behind the MFMAs)
+                        if (is_loader) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC) : "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    } else if (kt <= 1 && vc != (int)blockIdx.x && !(UEM_DBG(p.dbg) & 16)) {
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC + EPI_STORES) : "memory");
                     } else {
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC) : "memory");
@@ -1166,7 +1185,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                     par = par + 1 == NST ? 0 : par + 1;
                     continue;
                 }
-                if (LAZY && p.lazy && kt == 0 && vc != (int)blockIdx.x) {
+                if constexpr (SPLIT) {                                   // two stages, split roles: the loaders' queue holds operand pieces only
+                    if (is_loader) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                } else if (LAZY && p.lazy && kt == 0 && vc != (int)blockIdx.x) {
                     // first k-step of a later tile of the block: its operand pieces were requested under the PREVIOUS tile's last
                     // MFMA phase and every thread has issued at least EPI_STORES stores since (the epilogue's rows) -- the memory
                     // counter retires in order, so "at most EPI_STORES outstanding" means the pieces have landed while the stores
@@ -1182,7 +1206,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
             }
             // every wave past its last operand read, every DMA piece landed: the last step's out-of-range pieces (not persistent: the
             // staging area spans both stages) or the next tile's first operand tile (persistent: in the other stage)
-            if (RING || (LAZY && p.lazy)) {
+            if (RAWB || (LAZY && p.lazy)) {
                 // the pieces in flight fill the OTHER stage(s): nothing the epilogue touches -- it only needs every wave past its LDS reads
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -1214,6 +1238,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
             }
             EPI_SYNC();
             if (hm + 1 < NCH && (EPI < 0 || (MODE == 1 && EPI == 1))) epi_fetch(hm + 1);
+            if (is_storer) {
             bool rok[NRP];
 #pragma unroll
             for (int u = 0; u < NRP; ++u) rok[u] = FULL || m0 + hm * 64 + srow + u * RPP < p.M;
@@ -1231,7 +1256,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
             // of each chunk's first read, found in the ISA: the next tile's operand prefetch and the write acknowledgements of the rows
             // just stored were waited for four times per tile); the reads are ordered by the barrier above and waited for right here
             f32x4v svlo[NRP], svhi[NRP];
-            if constexpr (RING) {
+            if constexpr (RAWB) {
 #pragma unroll
                 for (int u = 0; u < NRP; ++u) {
                     const unsigned la = (unsigned)(unsigned long long)(lds_u32p)(&stg[(srow + u * RPP) * LDW + sc8]);
@@ -1245,7 +1270,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                 const int row = srow + u * RPP;
                 if (!rok[u]) continue;
                 float v[8];
-                if constexpr (RING) {
+                if constexpr (RAWB) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = svlo[u][e]; v[4 + e] = svhi[u][e]; }
                 } else {
@@ -1285,6 +1310,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
                     }
                 }
             }
+            }
             EPI_SYNC();
             // column sums over 128 rows = two chunks: the partial-sum tensors keep one entry per 128 rows whatever the block's tile
             // (the finalize kernels merge 128-row groups)
@@ -1292,10 +1318,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_bf16_kernel(
             if ((hm & 1) && tile_out != nullptr) {
                 // every thread summed its 8 columns over its rows in registers; the RPP thread rows combine through LDS
                 float* const red = stg;                                      // [2][RPP][BN]
+                if (is_storer) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; pb[e] = pg[e] = 0.f; }
+                    for (int e = 0; e < 8; ++e) { red[srow * BN + sc8 + e] = pb[e]; red[(RPP + srow) * BN + sc8 + e] = pg[e]; pb[e] = pg[e] = 0.f; }
+                }
                 EPI_SYNC();
-                for (int i = tid; i < 2 * BN; i += NTH) {
+                for (int i = is_storer ? etid : 2 * BN; i < 2 * BN; i += NTS) {
                     const int which = i / BN, col = i % BN;
                     float a = 0.f;
 #pragma unroll 8
@@ -2263,7 +2291,7 @@ extern "C" int uem_aspp_unpack_grad(const float* dwall, const float* db, void* c
 // =========================================================================================================
 static int g_bf16_persist = -1;  // tuning override: 1 / 0 = persistent blocks on / off, -1 = rule
 extern "C" void uemdbg_conv_bf16_persist(int v) { g_bf16_persist = v; }
-template <int BN_, int MODE, int EPI, bool PERSIST, int BMT = 128, int NST = 2>
+template <int BN_, int MODE, int EPI, bool PERSIST, int BMT = 128, int NST = 2, bool SPLIT = false>
 static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
     using C = ConvBf16Cfg<BN_, PERSIST, BMT, NST>;
     const int ntiles = (int)uem_cdiv(p.M, BMT) * (p.Cout / BN_);
@@ -2272,7 +2300,7 @@ static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream
     const int per_cu = BMT == 256 ? 1 : (160 * 1024 / C::LDS_BYTES > 3 ? 3 : 160 * 1024 / C::LDS_BYTES);
     const int slots = 256 * per_cu;
     const int grid = PERSIST && ntiles > slots ? slots : ntiles;
-    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT, NST>;
+    auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT, NST, SPLIT>;
     if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 2 * BMT, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
 }
 // Ring of three operand stages on persistent 256-row blocks (conv_bf16_kernel<..., NST = 3>): full dense tiles, forward (plain / with the
@@ -2288,16 +2316,32 @@ static int conv_bf16_ring_bn(const ConvP& p) {
     if (MODE == 0 && p.accumulate) return 0;
     const int bn = p.Cout % 128 == 0 ? 128 : 64;
     if (set == 1) return bn;
-    // rule (scripts/sweep_conv_bf16_ring.py, profiles/r06_*_conv_bf16_ring_sweep.txt): at least one tile per CU
-    const int ntiles = (p.M / 256) * (p.Cout / bn);
-    static const int min_tiles = getenv("UEM_CONV_BF16_RING_MIN_TILES") ? atoi(getenv("UEM_CONV_BF16_RING_MIN_TILES")) : 256;
-    return ntiles >= min_tiles ? bn : 0;
+    if (set == 2) return (bn != 128 || (MODE == 1 && (p.accumulate || p.acc_src || p.tile_bnbwd))) ? 0 : 1128;   // split roles (128 columns, no epilogue loads)
+    // Rule, from the per-shape sweeps against the round-5 dispatch (scripts/sweep_conv_bf16_ring.py; profiles/r06_a ... r06_f):
+    //  * the ring with the classic epilogue ties or loses (forward +3 ... +30 %, fused data gradients +15 ... +25 %): never by rule;
+    //  * with the roles split (loader / storer waves) it wins -5 ... -18 % where a block walks many short tiles -- at least 16 tiles of
+    //    256 x 128 per CU and 2 ... 18 k-steps per tile (the pointwise layers of the 1024 x 1024 configuration) -- and loses on the long
+    //    reductions (3x3 at 256 / 512 channels: +7 ... +15 %), on single-k-step tiles (64 -> 256: +14 %) and wherever a CU gets fewer
+    //    than 16 tiles (every shape of the 512 x 512 configuration: +4 ... +25 %).  No epilogue loads (forward, plain data gradient).
+    //    On 128-row two-stage blocks (two per CU) the split loses everywhere (+4 ... +30 %): not instantiated.
+    if (bn != 128 || (MODE == 1 && (p.accumulate || p.acc_src || p.tile_bnbwd))) return 0;
+    const int KT = p.ntaps * (p.Cin / KBH);
+    const int ntiles = (p.M / 256) * (p.Cout / 128);
+    static const int min_tiles = getenv("UEM_CONV_BF16_SPLIT_MIN_TILES") ? atoi(getenv("UEM_CONV_BF16_SPLIT_MIN_TILES")) : 4096;
+    return (ntiles >= min_tiles && KT >= 2 && KT <= 18) ? 1128 : 0;
 }
 template <int BN_, int MODE>
 static void conv_bf16_ring_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
     const bool extras = MODE == 0 ? p.tile_stats != nullptr : (p.accumulate || p.acc_src || p.tile_bnbwd);
     if (extras) conv_bf16_launch<BN_, MODE, 1, true, 256, 3>(p, xb, wb, st);
     else conv_bf16_launch<BN_, MODE, 0, true, 256, 3>(p, xb, wb, st);
+}
+template <int BN_, int MODE, int BMT = 256, int NST = 3>
+static void conv_bf16_split_go(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+    if constexpr (MODE == 0) {
+        if (p.tile_stats != nullptr) { conv_bf16_launch<BN_, 0, 1, true, BMT, NST, true>(p, xb, wb, st); return; }
+    }
+    conv_bf16_launch<BN_, MODE, 0, true, BMT, NST, true>(p, xb, wb, st);
 }
 static int g_bf16_lazy = -1;     // tuning override: counted waits around the persistent blocks' epilogue on / off, -1 = environment / default
 extern "C" void uemdbg_conv_bf16_lazy(int v) { g_bf16_lazy = v; }
@@ -2418,7 +2462,8 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
         if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
         const int ring = conv_bf16_ring_bn<0>(p);
         const int big = ring ? 0 : conv_bf16_big_bn<0>(p);
-        if (ring == 128) conv_bf16_ring_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        if (ring == 1128) conv_bf16_split_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
+        else if (ring == 128) conv_bf16_ring_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
         else if (ring == 64) conv_bf16_ring_go<64, 0>(p, (unsigned)xb, (unsigned)wb, st);
         else if (big == 256) conv_bf16_go<256, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
         else if (big == 128) conv_bf16_go<128, 0, 256>(p, (unsigned)xb, (unsigned)wb, st);
@@ -2460,7 +2505,8 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
                                    (wt_env != 2 || p.Cin <= 256);
             const int ring = wide_tail ? 0 : conv_bf16_ring_bn<1>(p);
             const int big = (wide_tail || ring) ? 0 : conv_bf16_big_bn<1>(p);
-            if (ring == 128) conv_bf16_ring_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            if (ring == 1128) conv_bf16_split_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
+            else if (ring == 128) conv_bf16_ring_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
             else if (ring == 64) conv_bf16_ring_go<64, 1>(p, (unsigned)xb, (unsigned)wb, st);
             else if (big == 256) conv_bf16_go<256, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
             else if (big == 128) conv_bf16_go<128, 1, 256>(p, (unsigned)xb, (unsigned)wb, st);
