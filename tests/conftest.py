@@ -26,7 +26,17 @@ def pytest_collection_modifyitems(config, items):
 
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}      # name lists stay numpy
+    g = {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}         # name lists stay numpy
+    # step fixtures: the per-tensor noise floor of the first update as the MAX over many self-draws of the reference
+    # (tests/golden/make_noise_floors.py -> update_noise_floors.npz), in the fixture's own tensor order
+    fl = os.path.join(GOLDEN, "update_noise_floors.npz")
+    if "upd_names" in g and os.path.exists(fl):
+        f = np.load(fl)
+        if name + ":floor_max" in f.files:
+            assert [str(n) for n in f[name + ":names"]] == [str(n) for n in g["upd_names"]], "noise-floor table out of step with the fixture"
+            g["upd_noise_floor_max"] = torch.from_numpy(f[name + ":floor_max"])
+            g["upd_noise_floor_draws"] = int(f[name + ":draws"].shape[0])
+    return g
 
 
 def golden_initial_state(g, sd):

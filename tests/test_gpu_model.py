@@ -1,5 +1,7 @@
 """GPU parity of the convolution / normalisation kernels, the residual blocks and the full network
 against torch-CPU fp32 references, the oracle and the reference goldens (through the C ABI)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -336,25 +338,38 @@ def test_batchnorm_stats_apply_backward(Cn, M):
     torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-4, atol=1e-6)
     gg, gb = torch.zeros(Cn, device="cuda"), torch.zeros(Cn, device="cuda")
-    pre = F.batch_norm(x.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5)
-    away = pre.abs() > 1e-4            # a pre-activation within rounding of the ReLU kink may flip its mask
-    # ... and a flipped mask moves its whole CHANNEL's two sums by one gradient value, i.e. every dx of the channel by O(|gy| / M):
-    # above the 1e-4 bar for the large tensors (26 M elements hold a handful of pre-activations within 5e-6 of the kink)
-    calm = ~(pre.abs() < 5e-6).any(0)
-    assert calm.float().mean() > 0.7
     y2, bits = ops.affine_act(xd, st, relu=True, want_bits=True)          # packed sign bits (C % 32 == 0 here)
     assert torch.equal(y2, y)
     expect = (y.reshape(-1, 32) > 0).to(torch.int64) << torch.arange(32, device="cuda")
     assert torch.equal(bits.to(torch.int64) & 0xFFFFFFFF, expect.sum(1))
+    # The expected gradient is built in float64 from the kernel's OWN ReLU mask: a pre-activation within rounding
+    # of the kink may come out on either side of it in two implementations, and a flipped mask moves its whole channel's two sums by
+    # one gradient value -- so instead of leaving such channels out (round 5: "calm" channels only), every channel and every element
+    # is compared against the backward pass of the function the forward actually computed.  That the mask itself is right is the
+    # forward comparison above (y against torch) plus: it differs from torch's only where the pre-activation is at rounding level.
+    mask = (y > 0).cpu()
+    pre = F.batch_norm(x.detach(), None, None, gamma.detach(), beta.detach(), True, 0.1, 1e-5)
+    flipped = mask != (pre > 0)
+    assert float(pre[flipped].abs().max()) < 1e-5 if flipped.any() else True
+    x64, gy64, g64 = x.detach().double(), gy.double(), gamma.detach().double()
+    mu, var = x64.mean(0), x64.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    xhat = (x64 - mu) * invstd
+    dp = gy64 * mask
+    gb_ref, gg_ref = dp.sum(0), (dp * xhat).sum(0)
+    dx_ref = g64 * invstd * (dp - gb_ref / M - xhat * (gg_ref / M))
+    dx_scale = float(dx_ref.abs().max())
     for ymask in (None, y, bits):                         # recomputed, materialised and bit-packed masks agree
         gg.zero_(), gb.zero_()
         kw = dict(ymask_bits=bits) if ymask is bits else dict(ymask=ymask)
         dx = ops.bn_backward(xd, gy.cuda(), st, gg, gb, relu=True, **kw)
-        torch.testing.assert_close(dx.cpu()[:, calm][away[:, calm]], x.grad[:, calm][away[:, calm]], rtol=1e-3, atol=1e-4)
-        assert away.float().mean() > 0.999
-        # (a channel with a pre-activation on the kink may flip one mask: its two sums move by that element's gradient)
-        torch.testing.assert_close(gg.cpu()[calm], gamma.grad[calm], rtol=5e-3, atol=1e-3)
-        torch.testing.assert_close(gb.cpu()[calm], beta.grad[calm], rtol=5e-3, atol=1e-3)
+        if ymask is None:                                 # the mask recomputed from x, scale, shift is the forward's, bit for bit
+            remask = (xd * st.scale + st.shift > 0).cpu()
+            assert torch.equal(remask, mask)
+        # every element of every channel: fp32 sums over up to 26 M elements against float64
+        assert float((dx.cpu().double() - dx_ref).abs().max()) <= 1e-4 * max(1.0, dx_scale)
+        torch.testing.assert_close(gg.cpu().double(), gg_ref, rtol=2e-4, atol=2e-3 * float(gg_ref.abs().max()) / max(1.0, M ** 0.5))
+        torch.testing.assert_close(gb.cpu().double(), gb_ref, rtol=2e-4, atol=2e-3 * float(gb_ref.abs().max()) / max(1.0, M ** 0.5))
 
 
 def test_maxpool_and_instnorm_vs_torch():
@@ -657,13 +672,29 @@ def _check_updates(model, g, use_ppm, num_classes=C, resnet_type="resnet50"):
         assert ((w_post - (w_pre + upd)).abs() <= 1.5 * ulp + 2e-6 * upd.abs()).all(), n
     if not ratios:                                       # every trainable tensor sits at rounding level (frozen BatchNorm statistics)
         return
-    worst = sorted(((e / f, n) for e, f, n in report if f >= 2.5e-4), reverse=True)[:4]
     ratios.sort()
     median = ratios[len(ratios) // 2]
-    # a wrong update of ONE tensor is 10-100x its floor.  The floor is one draw of the reference against itself, the error another of
-    # ours against it: among ~160 tensors the largest ratio of two such draws reaches 3-4 with nothing wrong (it moves between 2.4
-    # and 3.7 when a kernel's summation order changes); 5 is still an order of magnitude under a real defect, and at most one tensor
-    # may pass 3
+    if "upd_noise_floor_max" in g:
+        # Derived bar: the floor of a tensor is the MAXIMUM distance of its update over N perturbed runs of the
+        # reference itself (other conv backend x one-ulp input nudges x thread counts; N = 24, 6 for the 512 x 512 fixture).  An
+        # implementation as close to the reference as the reference is to itself exceeds the maximum of N exchangeable draws with
+        # probability 1 / (N + 1) per tensor; every tensor -- none excluded, no tuned constants -- must stay within 1.5 x that maximum
+        fmax = g["upd_noise_floor_max"]
+        by_name = {n: float(fmax[i]) for i, n in enumerate(names)}
+        derived = sorted(((e / max(by_name[n], 1e-30), e, by_name[n], n) for e, f, n in report if by_name[n] >= 2.5e-4), reverse=True)
+        print(f"update error / max over {g['upd_noise_floor_draws']} reference self-draws, {len(derived)} tensors: median "
+              f"{derived[len(derived) // 2][0]:.2f}, worst {[(round(r, 2), n) for r, e, f, n in derived[:3]]}; against the fixture's two-draw "
+              f"floor: median {median:.2f}, max {ratios[-1]:.2f}")
+        if os.environ.get("UEM_TEST_REPORT_ONLY"):
+            return
+        for r, e, f, n in derived:
+            assert r <= 1.5, (n, e, f, r)
+        for e, f, n in report:                           # tensors whose reference floor is at rounding level (head side): 1e-3 as before
+            if by_name[n] < 2.5e-4:
+                assert e < 1e-3, (n, e, by_name[n])
+        return
+    worst = sorted(((e / f, n) for e, f, n in report if f >= 2.5e-4), reverse=True)[:4]
+    # fixtures without a derived table (none today): the round-5 bar
     assert worst[0][0] < 5.0 and (len(worst) < 2 or worst[1][0] < 3.0), worst
     print(f"update error / reference noise floor over {len(ratios)} encoder tensors: median {median:.2f}, max {ratios[-1]:.2f}; "
           f"worst absolute {max(report)[:2]} {max(report)[2]}")
