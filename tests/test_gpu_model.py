@@ -755,9 +755,11 @@ def test_reference_optimizer_lines_torch_sgd_and_clip_grad_norm_on_the_arena_mod
     assert (p1.cpu() - out["pred_s1"].cpu()).abs().max() > 1e-4          # and they did move
 
 
-@pytest.mark.parametrize("storage", ["fp32", "bf16"])
-def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage):
-    """the whole train_ssl_uem step captured in one hipGraph (uemda_amd.step.GraphedStep) must BE the eager step.
+@pytest.mark.parametrize("storage,graph_side", [("fp32", False), ("bf16", False), ("fp32", True), ("bf16", True)])
+def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage, graph_side, monkeypatch):
+    """graph_side: the weight gradients' side stream captured WITH the step (forks and a join inside the graph; round 6, off by default
+    because the forked graph replays slower -- ops.GRAPH_SIDE) or kept out of the capture.
+    VERDICT r2 item 7: the whole train_ssl_uem step captured in one hipGraph (uemda_amd.step.GraphedStep) must BE the eager step.
     Before each of three replays -- with a learning rate that changes 10x from step to step, so that a rate baked into the capture
     would show -- the complete training state (weights, BatchNorm buffers, momentum, prototypes) is copied into a second model that
     takes the same step eagerly: same losses, same hard labels, same updated weights to fp32-atomic order.  (Whole trajectories
@@ -766,6 +768,8 @@ def test_graphed_step_replays_the_eager_step_with_a_moving_learning_rate(storage
     from uemda_amd.gast.alignment import Aligner
     from uemda_amd.optim import FusedSGD
     from uemda_amd.step import HYPER, GraphedStep, StepState, ssl_step
+    from uemda_amd import ops as _ops
+    monkeypatch.setattr(_ops, "GRAPH_SIDE", graph_side)
     batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=2333).items()}
 
     def fresh():

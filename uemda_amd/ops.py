@@ -272,10 +272,13 @@ def on_side(launch, tensors, label="weight gradient"):
 
 
 SIDE_OFF = 0            # > 0: no side stream (GraphedStep raises it around its capture when UEM_GRAPH_SIDE=0)
-# Round 6: the side stream is captured WITH the step (a fork at the first weight gradient of a backward pass, a join at its end): the
-# Winograd weight gradient no longer allocates inside its side-stream launch (_WinoSideWs), which is what had invalidated the capture in
-# round 5.  UEM_GRAPH_SIDE=0: the capture keeps the side stream out again (the replay is then the serial step).
-GRAPH_SIDE = os.environ.get("UEM_GRAPH_SIDE", "1") != "0"
+# Round 6: the side stream CAN be captured with the step (a fork at every side launch, a join at the end of backward): the Winograd
+# weight gradient no longer allocates inside its side-stream launch (_WinoSideWs), which is what had invalidated the capture in round 5;
+# tests/test_gpu_model.py replays such a graph against the eager step.  Measured (profiles/r06_g_hipgraph_side_stream.txt, A/B on one
+# box): the replay of the forked graph is SLOWER than the replay of the serial one -- fp32 104.0 against 100.2 ms (eager 98.9), bf16
+# storage 39.7 against 39.1 (eager 38.7), 2.4 ms of host time per replay against 0.25: ~70 fork edges per backward pass cost the graph
+# launch more than the overlap returns.  Default therefore: the capture keeps the side stream out (UEM_GRAPH_SIDE=1 captures it).
+GRAPH_SIDE = os.environ.get("UEM_GRAPH_SIDE", "0") != "0"
 
 
 def in_backward():
