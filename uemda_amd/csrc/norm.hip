@@ -788,6 +788,14 @@ static inline int bn_rows(int64_t nvec, int C, int per_vec) {
     if ((uem_cdiv(nvec, (int64_t)256 * R) * 256 * per_vec) % C != 0) return 1;
     return R;
 }
+// the paired apply kernels are instantiated for two rows per lane ONLY, whatever UEM_BN_ROWS says for the single passes: their
+// admission test is the row-stride condition of THEIR grid (under UEM_BN_ROWS=4 the stride was checked for a grid of
+// cdiv(nvec, 1024) blocks while cdiv(nvec, 512) were launched)
+static inline bool bn_pair_rows_ok(int64_t nvec, int C, int per_vec) {
+    static const int rows = getenv("UEM_BN_ROWS") ? atoi(getenv("UEM_BN_ROWS")) : 2;
+    if (rows < 2 || nvec < ((int64_t)1 << 20) || C < 64 || C > 2048 || (C & (C - 1)) != 0) return false;
+    return (uem_cdiv(nvec, (int64_t)512) * 256 * per_vec) % C == 0;
+}
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16x8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                   const uint32_t* __restrict__ rbits, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ smean,
@@ -1026,7 +1034,7 @@ extern "C" int uem_bn_bwd_apply_pair(const float* x1, const float* x2, const flo
                 dgamma2 && dbeta2, "bn_bwd_apply_pair: null pointer");
     UEM_REQUIRE(M > 0 && C > 0 && C % 32 == 0, "bn_bwd_apply_pair: bad shape");
     const int64_t nvec = (int64_t)M * C / 4;
-    if (bn_rows(nvec, C, 4) < 2) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pair: shape not taken by the rows kernels");
+    if (!bn_pair_rows_ok(nvec, C, 4)) return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pair: shape not taken by the rows kernels");
     const BnPairVec v1{scale1, mean1, invstd1, dgamma1, dbeta1}, v2{scale2, mean2, invstd2, dgamma2, dbeta2};
     bn_bwd_apply_pair_rows_kernel<2><<<(unsigned)uem_cdiv(nvec, 512), 256, 0, (hipStream_t)stream>>>(x1, x2, dy, relu_bits, v1, v2, nvec, C,
                                                                                                   1.0f / (float)M, dx1, dx2);
@@ -1041,7 +1049,7 @@ extern "C" int uem_bn_bwd_apply_pair_bf16(const uint16_t* x1, const uint16_t* x2
                 dgamma2 && dbeta2, "bn_bwd_apply_pair_bf16: null pointer");
     UEM_REQUIRE(M > 0 && C > 0 && C % 32 == 0, "bn_bwd_apply_pair_bf16: bad shape");
     const int64_t nvec8 = (int64_t)M * C / 8;
-    if ((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dx1 | (uintptr_t)dx2) & 15) != 0 || bn_rows(nvec8, C, 8) < 2)
+    if ((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)dy | (uintptr_t)dx1 | (uintptr_t)dx2) & 15) != 0 || !bn_pair_rows_ok(nvec8, C, 8))
         return uem_fail(UEM_ERR_UNSUPPORTED, "bn_bwd_apply_pair_bf16: shape not taken by the rows kernels");
     const BnPairVec v1{scale1, mean1, invstd1, dgamma1, dbeta1}, v2{scale2, mean2, invstd2, dgamma2, dbeta2};
     bn_bwd_apply_pair_bf16x8_rows_kernel<2><<<(unsigned)uem_cdiv(nvec8, 512), 256, 0, (hipStream_t)stream>>>(

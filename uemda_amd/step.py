@@ -121,6 +121,14 @@ def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_
                 grad_norm=optimizer.last_grad_norm)
 
 
+def finish(aligner):
+    """After the LAST step of a training loop, and before a checkpoint is written: wait for the last step's superpixel-range report.
+    Inside ssl_step / align_step the check never waits (`check_superpixel_ids(wait=False)`: an id outside the segment table raises one
+    step late), so the final step's report is only seen by this call."""
+    if aligner is not None:
+        aligner.check_superpixel_ids(wait=True)
+
+
 class GraphedStep:
     """One whole training iteration captured in ONE hipGraph and replayed: ~1100 kernel launches per step become one graph launch
     (host time per step 0.2 ms instead of 16-30).  The device time is unchanged -- the step is device-bound at the benchmark batch --
@@ -140,8 +148,11 @@ class GraphedStep:
     (`aligner.last_superpixel_range_flag`); `check()` reads it (a host sync: call it now and then, not every step).  The PPM heads'
     Dropout2d draws its masks from torch's graph-safe generator while capturing (models/ppm.py), a fresh mask per replay."""
 
-    def __init__(self, step_fn, model, aligner, optimizer, state, batch, warmup=2, lr=1e-3, **kw):
+    def __init__(self, step_fn, model, aligner, optimizer, state, batch, warmup=2, lr=1e-3, check_every=0, **kw):
+        """check_every = N > 0: every N-th replay ends with `check()` (one host sync: the superpixel-table overflow flag of a replayed
+        step never leaves the device otherwise -- ADVICE r5); 0: the caller calls `check()` itself."""
         import torch
+        self.check_every, self._replays = int(check_every), 0
         from .optim import FusedSGD
         from .ops import UemError
         if not isinstance(optimizer, FusedSGD):
@@ -229,6 +240,9 @@ class GraphedStep:
         self.lr.fill_(float(lr))
         self.graph.replay()
         self._after_replay()
+        self._replays += 1
+        if self.check_every > 0 and self._replays % self.check_every == 0:
+            self.check()
         return self.out
 
     def check(self):
