@@ -322,6 +322,10 @@ def _aspp_pack(heads, feat):
     return wall.view(R, 1, 1, cin), bias, C, nd, R, used
 
 
+import os as _os
+BF16_HEADS_DMA = _os.environ.get("UEM_BF16_HEADS_DMA", "1") != "0"      # bf16 storage: heads on the LDS-DMA bf16 kernels (0: rounds 2-5)
+
+
 class ASPPHeadsFn(Function):
     """Both Classifier_Module heads (Encoder.py:68-84): the 2 heads x 4 dilations x 9 taps are the columns of
     ONE 1x1 GEMM G = feat x Wall on the MFMA kernel (feat is read once), then a 36-term gather rebuilds the
@@ -340,14 +344,25 @@ class ASPPHeadsFn(Function):
         n, h, w, cin = feat.shape
         dil = (ctypes.c_int * nd)(*head5.dilations)
         ctx.prec = ASPPHeadsFn.prec
-        with ops.conv_precision(ctx.prec):
-            G = ops.conv2d(feat, wall, algo_cout=used)
+        # bf16 storage (round 6): the heads' GEMM and its two gradients on the LDS-DMA bf16 kernels the encoder runs
+        # (operands rounded to bf16 either way; rounds 2-5 ran them on the register-staged fp32-tensor kernel with bf16 operands: 1.4 ms
+        # of the 38 ms R50 step, 5.6 of R101-1024's 204).  feat / dG are cast once (the mining still reads the fp32 features), G and
+        # dfeat come back through one cast each
+        ctx.dma = ctx.prec == "bf16" and BF16_HEADS_DMA and cin % 64 == 0 and R % 64 == 0
+        if ctx.dma:
+            from .. import ops_bf16 as ob
+            feat_b, wall_b = ob.to_bf16(feat), ob.to_bf16(wall)
+            G = ob.to_f32(ob.conv2d(feat_b, wall_b))
+        else:
+            with ops.conv_precision(ctx.prec):
+                G = ops.conv2d(feat, wall, algo_cout=used)
         x1 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32)
         x2 = torch.empty((n, h, w, C), device=feat.device, dtype=torch.float32) if nh == 2 else None
         ops.call("uem_aspp_gather_fwd", ops.ptr(G), ops.ptr(bias), ops.ptr(x1), ops.ptr(x2), n, h, w, nh * C, R, nd, dil, ops.stream())
         if any(ctx.needs_input_grad):
             ctx.heads = heads
-            ctx.save_for_backward(feat, wall)
+            ctx.feat_shape = feat.shape
+            ctx.save_for_backward(feat_b if ctx.dma else feat, wall)
         return (x1, x2) if nh == 2 else x1
 
     @staticmethod
@@ -359,7 +374,7 @@ class ASPPHeadsFn(Function):
         head5 = heads[0]
         C = head5.conv2d_list[0].weight.shape[0]
         nd = len(head5.dilations)
-        n, h, w, cin = feat.shape
+        n, h, w, cin = ctx.feat_shape
         R = wall.shape[0]
         used = nd * 9 * nh * C
         d1 = d1.contiguous()
@@ -372,9 +387,17 @@ class ASPPHeadsFn(Function):
         dil = (ctypes.c_int * nd)(*head5.dilations)
         ops.call("uem_aspp_gather_bwd", ops.ptr(d1), ops.ptr(d2), ops.ptr(dG), n, h, w, nh * C, R, nd, dil, ops.stream())
         dwall = torch.zeros((R, 1, 1, cin), device=feat.device, dtype=torch.float32)
-        with ops.conv_precision(ctx.prec):
-            ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
-            dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
+        if ctx.dma:
+            from .. import ops_bf16 as ob
+            dG_b = ob.to_bf16(dG)
+            ob.conv2d_wgrad(feat, dG_b, dwall)                              # `feat` is the bf16 copy here
+            wall_t = torch.empty((cin, 1, 1, R), device=feat.device, dtype=torch.bfloat16)
+            ops.call("uem_weight_transpose_bf16", ops.ptr(wall), ops.ptr(wall_t), R, 1, 1, cin, ops.stream())
+            dfeat = ob.to_f32(ob.conv2d_dgrad(dG_b, wall_t, ctx.feat_shape))
+        else:
+            with ops.conv_precision(ctx.prec):
+                ops.conv2d_wgrad(feat, dG, dwall, algo_cout=used)
+                dfeat = ops.conv2d_dgrad(dG, ops.weight_transpose(wall), feat.shape, algo_cout=used)
         convs = [head.conv2d_list[i] for head in heads for i in range(nd)]
         gws, gbs = [grad_ohwi(c.weight) for c in convs], [grad_buffer(c.bias) for c in convs]
         if all(g is not None for g in gws + gbs):
