@@ -790,3 +790,37 @@ def test_bf16_stem_and_instnorm_ends_of_the_bf16_region():
     dxi = ob.instnorm_bwd(yi, dyi, inv)
     assert dxi.dtype == torch.bfloat16
     torch.testing.assert_close(dxi.float(), ops.instnorm_bwd(yi_ref, dyi, inv_ref), rtol=2 ** -8, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,hw,stats", [(256, 1024, 32, True), (64, 256, 64, True), (512, 128, 32, False), (1024, 256, 16, True)])
+def test_pointwise_stream_kernel_equals_the_dispatched_kernel(cin, cout, hw, stats):
+    """Round 6: pw_bf16_stream_kernel (four-stage operand ring of 32-channel k-steps, loader / storer waves, the tile's output parked in
+    LDS and stored under the next tile's MFMAs) is off by rule -- it ties the round-5 dispatch -- but stays in the library as the record of
+    that structure: forced on, it must equal the dispatched kernel bit for bit (same accumulation order), forward with and without the
+    BatchNorm tile statistics and as a plain data gradient; the statistics to their summation order."""
+    import ctypes
+    from uemda_amd import _lib, ops_bf16
+    lib = _lib.load()
+    lib.uemdbg_conv_bf16_pw.argtypes = [ctypes.c_int]
+    lib.uemdbg_conv_bf16_pw.restype = None
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(8, hw, hw, cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) * 0.05).cuda().bfloat16()
+    dy = torch.randn(8, hw, hw, cout, generator=g).cuda().bfloat16()
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    try:
+        lib.uemdbg_conv_bf16_pw(0)
+        ref = ops_bf16.conv2d(x, w, want_stats=stats)
+        ref_d = ops_bf16.conv2d_dgrad(dy, wt, x.shape)
+        lib.uemdbg_conv_bf16_pw(1)
+        out = ops_bf16.conv2d(x, w, want_stats=stats)
+        out_d = ops_bf16.conv2d_dgrad(dy, wt, x.shape)
+    finally:
+        lib.uemdbg_conv_bf16_pw(-1)
+    torch.cuda.synchronize()
+    if stats:
+        assert torch.equal(out[0], ref[0])
+        torch.testing.assert_close(out[1], ref[1], rtol=2e-5, atol=2e-3)
+    else:
+        assert torch.equal(out, ref)
+    assert torch.equal(out_d, ref_d)

@@ -2303,6 +2303,255 @@ static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream
     auto k = conv_bf16_kernel<BN_, MODE, EPI, PERSIST, BMT, NST, SPLIT>;
     if (uem_allow_lds((const void*)k, C::LDS_BYTES)) k<<<grid, 2 * BMT, C::LDS_BYTES, st>>>(p, xb, wb, ntiles);
 }
+// =========================================================================================================
+// Pointwise bf16 GEMM with a four-stage operand ring, loader / storer waves and streamed stores (round 6).
+//   C[M x N] (bf16) = A[M x K] (bf16, row stride lda) x B[N x K]^T (bf16, dense rows), fp32 accumulation -- the 1x1 / stride-1
+//   convolutions of the bf16-storage path, forward (optionally with the BatchNorm tile statistics of the rounded output) and plain
+//   data gradient (A = dy, B = the transposed bank).
+// Why: on these layers a tile is a handful of k-steps around an epilogue that costs more than they do; the ablation
+// and four variants of conv_bf16_kernel said what a block needs AT ONCE -- operand pieces several k-steps ahead (one block of eight waves
+// per CU has nobody else to cover a round trip), no wave that waits for operand pieces behind its own stores (one in-order vector-memory
+// counter per wave), and stores that leave under the next tile's MFMAs instead of as a burst the whole chip drains while the matrix pipe
+// idles -- and that 160 KB of LDS hold a ring AND a parked tile only at 32-channel k-steps:
+//   * tile 256 x 128, k-step 32 channels: a stage is A 256 x 64 B + B 128 x 64 B = 24 KB, four stages (three k-steps in flight) = 96 KB;
+//     the tile's output, rounded to bf16, is parked in a 64 KB out-buffer: 160 KB, one block per CU;
+//   * rows of 64 bytes, their four 16-byte chunks XOR-swizzled by (row >> 2) & 3 on the DMA source address and on the read: the 16 lanes of
+//     a ds_read_b128 group cover 16 distinct slots of the 256-byte bank row;
+//   * waves 0-3 (LOADERS) issue all 24 pieces of a k-step, six each, and wait with vmcnt(12): the pieces of the step about to be consumed
+//     have landed, the next two steps' stay in flight, and nothing else is ever in their queue; waves 4-7 (STORERS) read the parked tile
+//     back 16 bytes per lane (hand-written ds_read: the compiler would order an LDS read behind every DMA piece in flight) and store it,
+//     a few rows per k-step of the NEXT tile, and never wait on the vector-memory counter; all eight run the MFMAs (wave tile 64 x 64);
+//   * the ring runs across the block's tiles (persistent blocks, XCD-aware tile order, column tiles of one row tile adjacent).
+// Same accumulation order over k as conv_bf16_kernel (16-channel MFMA steps in ascending order): outputs are bit-equal to it.
+// =========================================================================================================
+struct PwP {
+    const unsigned short* A; const unsigned short* B; unsigned short* C;
+    float* tile_stats;                    // [2][N][M / 128] or null
+    int M, N, K, lda, ldc;
+    unsigned a_bytes, b_bytes;
+};
+template <bool STATS>
+__global__ __launch_bounds__(512, 1) void pw_bf16_stream_kernel(const PwP p, const int ntiles) {
+    constexpr int PBM = 256, PBN = 128, PBK = 32, PNS = 4;
+    constexpr int A_ELEMS = PBM * PBK, B_ELEMS = PBN * PBK, SE = A_ELEMS + B_ELEMS;          // bf16 elements per stage (24 KB)
+    constexpr int NPC = 6;                                                                // pieces per loader wave and k-step: 4 A + 2 B
+    constexpr int NSL = (PBM * PBN / 8) / 256;                                             // 16-byte slices per storer thread and tile: 16
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const ob = lds16 + PNS * SE;                                          // [256][128] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave < 4;
+    const int tiles_n = p.N / PBN;
+    const int KT = p.K / PBK;
+    const i32x4 rs_a = conv_rsrc(p.A, p.a_bytes), rs_b = conv_rsrc(p.B, p.b_bytes);
+    // ---- issue side (loader waves): three k-steps ahead of the MFMAs, moving on to the block's next tile on its own
+    const int lrow = lane >> 2;                                                           // row inside a 16-row piece
+    int vi = blockIdx.x, ikt = 0;
+    bool issue_live = vi < ntiles;
+    unsigned aoff[4], boff[2];
+    auto issue_setup = [&]() {
+        const int tile = xcd_remap(vi, ntiles);
+        const int im0 = (tile / tiles_n) * PBM, in0 = (tile % tiles_n) * PBN;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (j * 4 + wave) * 16 + lrow;                                     // row of the tile's A block = LDS row
+            aoff[j] = ((unsigned)(im0 + r) * (unsigned)p.lda + (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 8)) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (j * 4 + wave) * 16 + lrow;
+            boff[j] = ((unsigned)(in0 + r) * (unsigned)p.K + (unsigned)(((lane & 3) ^ ((r >> 2) & 3)) * 8)) * 2u;
+        }
+    };
+    if (is_loader && issue_live) issue_setup();
+    auto issue_step = [&](unsigned short* __restrict__ fill) {                            // six pieces, always (out of range when nothing is left)
+        unsigned short* const fA = fill;
+        unsigned short* const fB = fill + A_ELEMS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uem_raw_buffer_load_lds(rs_a, (lds_u32p)(fA + (j * 4 + wave) * 512), 16, (int)(issue_live ? aoff[j] : CONV_OOB), 0, 0, 0);
+            aoff[j] += PBK * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uem_raw_buffer_load_lds(rs_b, (lds_u32p)(fB + (j * 4 + wave) * 512), 16, (int)(issue_live ? boff[j] : CONV_OOB), 0, 0, 0);
+            boff[j] += PBK * 2;
+        }
+        if (issue_live && ++ikt == KT) {
+            ikt = 0;
+            vi += gridDim.x;
+            issue_live = vi < ntiles;
+            if (issue_live) issue_setup();
+        }
+    };
+    // ---- compute side
+    f32x16 acc[2][2];
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int fr = lane & 31, fh = lane >> 5;
+    // ---- storer side: the parked tile leaves `per_step` slices per k-step
+    const int stid = (tid - 256) & 255;
+    int pm0 = 0, pn0 = 0, tr_left = 0;
+    const int per_step = (NSL + KT - 1) / KT;
+    auto trickle = [&](int nsend) {
+        while (nsend > 0 && tr_left > 0) {
+            f32x4v v[4];
+            unsigned go[4];
+            int nb = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < nsend && tr_left > 0) {
+                    const int c = (NSL - tr_left) * 256 + stid, row = c >> 4, ch = c & 15;
+                    const unsigned la = (unsigned)(unsigned long long)(lds_u32p)(ob + row * PBN + ch * 8);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(la));
+                    go[u] = (unsigned)(pm0 + row) * (unsigned)p.ldc + (unsigned)(pn0 + ch * 8);
+                    --tr_left;
+                    nb = u + 1;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < nb) *reinterpret_cast<f32x4v*>(p.C + (size_t)go[u]) = v[u];
+            nsend -= 4;
+        }
+    };
+    // ---- prologue: three k-steps in flight
+    if (is_loader) {
+        issue_step(lds16 + 0 * SE);
+        issue_step(lds16 + 1 * SE);
+        issue_step(lds16 + 2 * SE);
+    }
+    int cs = 0;                                                                           // stage the next k-step consumes
+    for (int vc = blockIdx.x; vc < ntiles; vc += gridDim.x) {
+        const int tile = xcd_remap(vc, ntiles);
+        const int m0 = (tile / tiles_n) * PBM, n0 = (tile % tiles_n) * PBN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (is_loader) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPC) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned short* __restrict__ const As = lds16 + cs * SE;
+            const unsigned short* __restrict__ const Bs = As + A_ELEMS;
+            if (is_loader) issue_step(lds16 + ((cs + PNS - 1) & (PNS - 1)) * SE);          // the stage consumed last: every wave is past it
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = wm + i * 32 + fr;
+                    a[i] = *reinterpret_cast<const bf16x8*>(&As[r * PBK + (((ks * 2 + fh) ^ ((r >> 2) & 3)) * 8)]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = wn + j * 32 + fr;
+                    b[j] = *reinterpret_cast<const bf16x8*>(&Bs[r * PBK + (((ks * 2 + fh) ^ ((r >> 2) & 3)) * 8)]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (!is_loader && tr_left > 0) trickle(ks == 0 ? (per_step + 1) / 2 : per_step / 2);
+            }
+            cs = (cs + 1) & (PNS - 1);
+        }
+        // ---- tile end: no epilogue phase.  Whatever of the previous tile is still parked leaves now (nothing, when KT x per_step >= 16)
+        if (!is_loader) trickle(NSL);
+        float s1[2], s2[2];
+        if constexpr (STATS) {
+            // BatchNorm tile statistics of the ROUNDED values: the lane's two columns over its 32 rows, then the lane halves
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s1[j] = s2[j] = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float vr = bf2f(f2bf(acc[i][j][r])); s1[j] += vr; s2[j] = fmaf(vr, vr, s2[j]); }
+                s1[j] += __shfl_xor(s1[j], 32);
+                s2[j] += __shfl_xor(s2[j], 32);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                                     // the out-buffer is free: every storer past its reads
+        asm volatile("" ::: "memory");
+        if constexpr (STATS) {
+            float* const sc = reinterpret_cast<float*>(ob);                               // [8 waves][2][64], in the still empty out-buffer
+            if (fh == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { sc[(wave * 2 + 0) * 64 + j * 32 + fr] = s1[j]; sc[(wave * 2 + 1) * 64 + j * 32 + fr] = s2[j]; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!is_loader) {                                                             // entry e (128 rows) x 128 columns, both sums, by the storers
+                const int e = stid >> 7, col = stid & 127, wni = col >> 6, cc = col & 63;
+                const unsigned l0 = (unsigned)(unsigned long long)(lds_u32p)(sc + (((2 * e) * 2 + wni) * 2) * 64 + cc);
+                float a0, a1, b0, b1;                     // row groups 2e and 2e + 1 are two waves = 256 floats apart; sum / sum of squares 64 floats apart
+                asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:1024\n\tds_read_b32 %3, %4 offset:1280\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1) : "v"(l0) : "memory");
+                const size_t tiles_m = (size_t)(p.M / 128);
+                p.tile_stats[((size_t)0 * p.N + n0 + col) * tiles_m + (size_t)(m0 / 128 + e)] = a0 + a1;
+                p.tile_stats[((size_t)1 * p.N + n0 + col) * tiles_m + (size_t)(m0 / 128 + e)] = b0 + b1;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ob[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * PBN + wn + j * 32 + fr] = f2bf(acc[i][j][r]);
+        pm0 = m0; pn0 = n0; tr_left = NSL;                // the next k-step's barrier orders the dump before the storers' reads
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (!is_loader) trickle(NSL);                          // the block's last tile
+}
+// -1 = rule, 0 = never, 1 = wherever legal
+static int g_bf16_pw = -1;
+extern "C" void uemdbg_conv_bf16_pw(int v) { g_bf16_pw = v; }
+template <int MODE>
+static bool conv_bf16_pw_try(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+    static const int env = getenv("UEM_CONV_BF16_PW") ? atoi(getenv("UEM_CONV_BF16_PW")) : -1;
+    const int set = g_bf16_pw >= 0 ? g_bf16_pw : env;
+    const bool pointwise = p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
+    if (set == 0 || !pointwise || p.M % 256 != 0 || p.Cout % 128 != 0 || p.Cin % 32 != 0 || p.accumulate) return false;
+    if (MODE == 1 && (p.acc_src || p.tile_bnbwd)) return false;
+    if ((double)p.M * p.y_ld * 2.0 >= 4294967280.0) return false;
+    const int ntiles = (p.M / 256) * (p.Cout / 128);
+    // Rule: OFF (UEM_CONV_BF16_PW=1 / uemdbg_conv_bf16_pw(1): wherever legal).  Bit-equal to conv_bf16_kernel and within +-5 % of the round-5
+    // dispatch on the 1024 x 1024 pointwise layers, +10 ... +20 % on the 512 x 512 ones (scripts/sweep_conv_bf16_ring.py SWEEP=pw,
+    // profiles/r06_i_*): the sixth block structure to land on the same time -- what bounds these layers is the operand bytes a CU pulls
+    // from L2 per flop, which no pipeline inside the block changes; the tile shape does (conv_bf16_big_bn).
+    if (set != 1) return false;
+    PwP q;
+    q.A = reinterpret_cast<const unsigned short*>(p.x); q.B = reinterpret_cast<const unsigned short*>(p.w);
+    q.C = reinterpret_cast<unsigned short*>(p.y); q.tile_stats = MODE == 0 ? p.tile_stats : nullptr;
+    q.M = p.M; q.N = p.Cout; q.K = p.Cin; q.lda = p.x_ld; q.ldc = p.y_ld; q.a_bytes = xb; q.b_bytes = wb;
+    constexpr int LDS = 4 * (256 * 32 + 128 * 32) * 2 + 256 * 128 * 2;                    // 160 KB
+    const int grid = ntiles > 256 ? 256 : ntiles;
+    if (q.tile_stats != nullptr) {
+        auto k = pw_bf16_stream_kernel<true>;
+        if (!uem_allow_lds((const void*)k, LDS)) return false;
+        k<<<grid, 512, LDS, st>>>(q, ntiles);
+    } else {
+        auto k = pw_bf16_stream_kernel<false>;
+        if (!uem_allow_lds((const void*)k, LDS)) return false;
+        k<<<grid, 512, LDS, st>>>(q, ntiles);
+    }
+    return true;
+}
 // Ring of three operand stages on persistent 256-row blocks (conv_bf16_kernel<..., NST = 3>): full dense tiles, forward (plain / with the
 // BatchNorm tile statistics) and data gradient (plain / residual tail / BatchNorm-backward partial sums).  -1 = rule, 0 = never,
 // 1 = wherever legal (tests, sweeps).
@@ -2406,6 +2655,16 @@ static int conv_bf16_big_bn(const ConvP& p) {
     if (set == 1) return (!extras && p.Cout % 256 == 0) ? 256 : 128;
     // the fused data-gradient epilogues (residual tail, BatchNorm-backward partial sums) LOSE on 256-row tiles: with one block per CU
     // nothing covers their three extra streams (R101 1024^2 step: forward family 46.9 -> 44.9 ms, data gradient 54.4 -> 56.4)
+    // Round 6: 256 x 256 tiles ALSO on short reductions when the output is wide and the grid is deep (the 1024 x 1024 configuration: never
+    // swept in round 5).  What bounds the short-k pointwise layers is not HBM and not the block's pipeline -- five structures of the block
+    // land on the same time -- but the operand bytes a CU pulls from L2 per flop (~70 GB/s per CU from L2,
+    // MI355X_MICROARCH.md "Indexed rows"): a 256 x 256 tile fetches 2/3 of what 256 x 128 fetches.  Measured at 1024 x 1024
+    // (profiles/r06_j_conv_bf16_big_sweep_1024.txt): 128 -> 512 -13 %, 256 -> 1024 -10 %, 512 -> 2048 -18 % forward; the plain data gradients
+    // with 512 ... 2048 output columns -11 ... -17 %; 512 output columns behind a reduction of 1024 and more: +2 ... +4 % (not taken).
+    static const int wide_min_tiles = getenv("UEM_CONV_BF16_BIG_WIDE_MIN_TILES") ? atoi(getenv("UEM_CONV_BF16_BIG_WIDE_MIN_TILES")) : 1024;
+    if (!extras && KT < min_kt && p.Cout % 256 == 0 && (p.Cout >= 1024 || KT <= 4) && p.Cout >= 512 && KT >= 2 &&
+        rows * (p.Cout / 256) >= wide_min_tiles)
+        return 256;
     if (KT < min_kt || extras) return 0;
     if (!extras && p.Cout % 256 == 0 && rows * (p.Cout / 256) >= min_tiles) return 256;
     return rows * (p.Cout / 128) >= min_tiles ? 128 : 0;
@@ -2460,6 +2719,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
         p.x_ld = s->x_ld; p.y_ld = s->y_ld; p.M = s->N * s->Ho * s->Wo;
         const double xb = (double)p.N * p.H * p.W * p.x_ld * 2.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 2.0;
         if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
+        if (conv_bf16_pw_try<0>(p, (unsigned)xb, (unsigned)wb, st)) return uem_check_launch("conv2d_bf16 (pointwise stream)");
         const int ring = conv_bf16_ring_bn<0>(p);
         const int big = ring ? 0 : conv_bf16_big_bn<0>(p);
         if (ring == 1128) conv_bf16_split_go<128, 0>(p, (unsigned)xb, (unsigned)wb, st);
@@ -2503,6 +2763,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
             static const int wt_env = getenv("UEM_BF16_WIDE_TAIL") ? atoi(getenv("UEM_BF16_WIDE_TAIL")) : 0;
             const bool wide_tail = wt_env != 0 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout &&
                                    (wt_env != 2 || p.Cin <= 256);
+            if (!wide_tail && conv_bf16_pw_try<1>(p, (unsigned)xb, (unsigned)wb, st)) continue;
             const int ring = wide_tail ? 0 : conv_bf16_ring_bn<1>(p);
             const int big = (wide_tail || ring) ? 0 : conv_bf16_big_bn<1>(p);
             if (ring == 1128) conv_bf16_split_go<128, 1>(p, (unsigned)xb, (unsigned)wb, st);
