@@ -334,3 +334,59 @@ def test_config5_r101_1024_b32_bf16_storage_batch_replication():
     # (both runs carry bf16 backward noise, so the gain of a noisy tensor sits below 1: 1 / (1 + noise^2 / signal^2))
     assert 0.75 < lo and hi < 1.1, (lo, klo, hi)
     torch.testing.assert_close(pbig, psmall, rtol=2e-3, atol=2e-4)
+
+
+def test_config2_src_step_b32_matches_the_oracle_through_batch_replication():
+    """BASELINE config 2 (ResNet50-ASPP, 32 tiles of 512 x 512, forward + backward only: tools/train_src.py:112-141) at its full size.
+    The oracle takes the same step on 2 tiles in seconds; a batch that repeats those 2 tiles 16x has the 2-tile batch's statistics,
+    mean loss and mean gradient, so: (1) the HIP src_step at B = 2 against the oracle's (logits 1e-3 of the largest, loss 1e-3, gradient
+    norm 1 %); (2) the B = 32 step against the B = 2 one -- replicas of a tile bit-identical inside the batch, logits within 2e-4
+    (the batch statistics agree to fp32 rounding), loss 1e-4, gradient norm 2e-3, every conv weight's first update at a least-squares
+    gain of 0.9-1.1 of the small batch's."""
+    from oracle import synth
+    from oracle.model import OracleDeeplabv2
+    from oracle.step import HYPER as OH, SGDState, src_step as oracle_src
+    from oracle.weights import det_state_dict
+    from uemda_amd.models.Encoder import Deeplabv2
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import StepState, src_step
+    sd = det_state_dict("resnet50", C, False, seed=2333)
+    pool = synth.make_batch(B=2, H=S, W=S, C=C, k=2048, seed=47)
+    cfg = dict(backbone=dict(resnet_type="resnet50", output_stride=16, pretrained=False), multi_layer=True, cascade=False,
+               use_ppm=False, ppm=dict(num_classes=C, use_aux=False, fc_dim=2048), inchannels=2048, num_classes=C, is_ins_norm=True)
+
+    def run(rep):
+        model = Deeplabv2(cfg)
+        model.load_state_dict(sd)
+        model = model.cuda()
+        b = {k: (v.cuda().repeat((rep,) + (1,) * (v.dim() - 1)).contiguous() if k != "prototypes" else v.cuda()) for k, v in pool.items()}
+        w0 = {k: v.detach().clone() for k, v in model.state_dict().items() if v.dim() == 4}
+        out = src_step(model, FusedSGD(model, 1e-2, 0.9, 5e-4), StepState(C), b, 2e-3)
+        torch.cuda.synchronize()
+        upd = {k: (v.detach() - w0[k]).double() for k, v in model.state_dict().items() if k in w0}
+        keep = {k: out[k].detach().clone() for k in ("pred_s1", "pred_s2", "loss_source", "grad_norm")}
+        del model, b, out
+        torch.cuda.empty_cache()
+        return keep, upd
+
+    small, usmall = run(1)
+    om = OracleDeeplabv2(sd, "resnet50", C, False)
+    ref = oracle_src(om, SGDState(om.parameters(), 0.9, 5e-4), pool, 2e-3, OH)
+    for k in ("pred_s1", "pred_s2"):
+        err = float((small[k].cpu() - ref[k]).abs().max() / ref[k].abs().max())
+        assert err < 1e-3, (k, err)
+    assert abs(float(small["loss_source"]) / float(ref["loss_source"]) - 1.0) < 1e-3
+    assert abs(float(small["grad_norm"]) / float(ref["grad_norm"]) - 1.0) < 1e-2
+    big, ubig = run(B // 2)
+    assert big["pred_s1"].shape[0] == B
+    for k in ("pred_s1", "pred_s2"):
+        for i in range(2, B):
+            assert torch.equal(big[k][i], big[k][i % 2]), (k, i)
+    rel = max(float((big[k][:2] - small[k]).abs().max() / small[k].abs().max()) for k in ("pred_s1", "pred_s2"))
+    ls = abs(float(big["loss_source"]) / float(small["loss_source"]) - 1.0)
+    gn = abs(float(big["grad_norm"]) / float(small["grad_norm"]) - 1.0)
+    gains = {k: float((ubig[k] * usmall[k]).sum() / (usmall[k] * usmall[k]).sum()) for k in usmall if float(usmall[k].norm()) > 0}
+    lo, hi = min(gains.values()), max(gains.values())
+    print(f"config 2 at B=32 vs the same 2 tiles at B=2: logits {rel:.2e}, loss {ls:.2e}, grad norm {gn:.2e}, conv-update gain {lo:.3f} .. {hi:.3f}")
+    assert rel < 2e-4 and ls < 1e-4 and gn < 2e-3, (rel, ls, gn)
+    assert 0.9 < lo and hi < 1.1, (lo, hi)
