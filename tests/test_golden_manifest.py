@@ -92,3 +92,29 @@ def test_committed_fixture_has_every_key_its_generator_writes(gen, names, keys, 
         have = set(np.load(path, allow_pickle=False).files)
         missing = [k for k in keys if k not in have]
         assert not missing, f"{name}.npz lacks {missing}: re-run `python tests/golden/{gen}` (generator line {line})"
+
+
+def test_update_noise_floors_cover_every_step_fixture():
+    """tests/golden/update_noise_floors.npz (make_noise_floors.py: the reference's own first-step update under N rounding-level
+    perturbations) has an entry for EVERY step fixture, in the fixture's tensor order, with at least 6 draws; its first two draws are
+    the two the fixture's own `upd_noise_floor` was taken from, and reproduce it."""
+    import glob
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fl = np.load(os.path.join(here, "update_noise_floors.npz"))
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(here, "model_*.npz"))):
+        fx = np.load(path)
+        if "upd_names" not in fx.files:
+            continue
+        name = os.path.splitext(os.path.basename(path))[0]
+        assert name + ":floor_max" in fl.files, f"{name}: no derived noise floor (run tests/golden/make_noise_floors.py {name})"
+        assert [str(n) for n in fl[name + ":names"]] == [str(n) for n in fx["upd_names"]]
+        draws = fl[name + ":draws"]
+        assert draws.shape[0] >= 6 and draws.shape[1] == len(fx["upd_names"]) and len(fl[name + ":perturbations"]) == draws.shape[0]
+        np.testing.assert_allclose(draws[:2].max(axis=0), fx["upd_noise_floor"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_array_equal(draws.max(axis=0), fl[name + ":floor_max"])
+        assert (fl[name + ":floor_max"] >= fx["upd_noise_floor"] * (1 - 1e-5) - 1e-8).all()
+        seen += 1
+    assert seen >= 7
