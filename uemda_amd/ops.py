@@ -180,6 +180,7 @@ if TRACE_NONFINITE:
 # are recorded on it (the caching allocator will not hand their memory out again before the launch has run), and the main stream waits
 # for the side stream once per backward pass -- an autograd end-of-backward callback -- and before a data-parallel bucket goes out.
 SIDE_WGRAD_F32 = os.environ.get("UEM_SIDE_WGRAD", "1") != "0"
+SIDE_HOLD = os.environ.get("UEM_SIDE_HOLD", "1") != "0"       # 0: record_stream instead of holding references until the join (rounds 5 / early 6)
 
 
 class _Side:
@@ -190,6 +191,7 @@ class _Side:
         self.task = None                 # id of the backward graph task whose end-of-backward callback will join (None: no join queued)
         self.dirty = False               # work was queued since the last join
         self.reads = []                  # (first byte, past-the-end byte, label) of what the queued launches read, since the last join
+        self.held = []                   # the tensors those launches read, kept alive until the join (see on_side)
 
     @classmethod
     def get(cls):
@@ -205,6 +207,7 @@ class _Side:
         if self.dirty:
             torch.cuda.current_stream().wait_stream(self.stream)
             self.dirty = False
+        self.held.clear()                # freed in main-stream order BEHIND the wait: reusable at once, no cross-stream bookkeeping
 
 
 def side_join():
@@ -237,8 +240,8 @@ def guard_write(t, what):
         return
     lo, hi = _byte_range(t)
     for a, b, label, alive in st.reads:
-        # a range whose tensor is gone no longer guards anything: its memory was recorded on the side stream (record_stream), so the
-        # caching allocator hands it out again only after the side launch has run -- a fresh tensor at that address is no race
+        # a range whose tensor is gone no longer guards anything (on_side holds the tensors a launch reads until the join, so this is
+        # the exception: a caller that passed a temporary VIEW whose base lives on elsewhere)
         if lo < b and a < hi and alive() is not None:
             raise UemError(f"{what}: writes in place into a buffer ({tuple(t.shape)} at 0x{lo:x}) that a weight gradient queued on the "
                            f"side stream still reads ({label}); the main stream may overwrite only what no pending side launch reads "
@@ -253,8 +256,17 @@ def on_side(launch, tensors, label="weight gradient"):
     st.stream.wait_stream(main)
     with torch.cuda.stream(st.stream):
         launch()
+    # The tensors the launch reads stay referenced until the join instead of being recorded on the side stream (measured in
+    # round 6): a block freed while recorded on another stream is reusable only once the DEVICE has passed that stream's event, and the
+    # host enqueues a whole backward pass in a tenth of the time the device takes -- so within a pass none of those blocks ever came back
+    # and the allocator kept asking the driver for more (peak reserved 87.7 GB against 33.9 without the side stream at 33 GB allocated;
+    # R101-1024 bf16: 167-255 GB against 106).  Held until the main stream has waited for the side stream, they are freed in main-stream
+    # order and reusable immediately.
     for t in tensors:
-        t.record_stream(st.stream)
+        if SIDE_HOLD:
+            st.held.append(t)
+        else:
+            t.record_stream(st.stream)
         st.reads.append(_byte_range(t) + (f"{label} reading {tuple(t.shape)}", weakref.ref(t if t._base is None else t._base)))
     st.dirty = True
     # one join per backward pass, queued in THAT pass: the flag is the graph task's id, not a boolean -- a pass that raised after
