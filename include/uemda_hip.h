@@ -250,6 +250,10 @@ int uem_bilinear_up_bwd(const float* dy, float* dx /* = */, int N, int h, int w,
 int uem_dropout2d(const float* x, float* y, float* mask /*[N][C]*/, int N, int HW, int C, float p,
                   uint64_t seed, void* stream);
 int uem_add_inplace(float* a, const float* b, int64_t n, void* stream);
+/* a += b; b = 0 in one pass: the fold of the shadow gradient arena (the step's second graph, backward on its own stream, accumulates
+ * its parameter gradients there -- the host-side ordering this package adds around torch autograd's per-stream backward; the
+ * reference accumulates both graphs into one .grad on one stream, tools/train_ssl_uem.py:224-227). */
+int uem_add_clear(float* a, float* b, int64_t n, void* stream);
 int uem_nhwc_to_nchw(const float* x, float* y, int N, int HW, int C, void* stream);
 int uem_nchw_to_nhwc(const float* x, float* y, int N, int HW, int C, void* stream);
 

@@ -84,6 +84,7 @@ SIGNATURES = {
     "uem_bilinear_up_bwd": [P, P, I, I, I, I, I, I, I, I, P],
     "uem_dropout2d": [P, P, P, I, I, I, F, c_uint64, P],
     "uem_add_inplace": [P, P, L, P],
+    "uem_add_clear": [P, P, L, P],
     "uem_nhwc_to_nchw": [P, P, I, I, I, P],
     "uem_nchw_to_nhwc": [P, P, I, I, I, P],
     "uem_pearson_sim": [P, P, P, P, I, I, I, P],

@@ -1896,6 +1896,32 @@ extern "C" int uem_add_inplace(float* a, const float* b, int64_t n, void* stream
     return uem_check_launch("add_inplace");
 }
 
+// a += b; b = 0 in one pass (the fold of the shadow gradient arena the step's second graph accumulates into: 4 n bytes read + written
+// per operand instead of the add's 12 n + the memset's 4 n).  16-byte accesses where both are aligned and n allows.
+__global__ __launch_bounds__(256) void add_clear_kernel(float* __restrict__ a, float* __restrict__ b, int64_t n4, int64_t n) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float4* a4 = reinterpret_cast<float4*>(a);
+    float4* b4 = reinterpret_cast<float4*>(b);
+    for (int64_t i = i0; i < n4; i += step) {
+        float4 x = a4[i];
+        const float4 y = b4[i];
+        x.x += y.x, x.y += y.y, x.z += y.z, x.w += y.w;
+        a4[i] = x;
+        b4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t i = n4 * 4 + i0; i < n; i += step) {
+        a[i] += b[i];
+        b[i] = 0.f;
+    }
+}
+extern "C" int uem_add_clear(float* a, float* b, int64_t n, void* stream) {
+    UEM_REQUIRE(a && b && n > 0, "add_clear: bad arguments");
+    const bool al = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+    const int64_t n4 = al ? n / 4 : 0;
+    add_clear_kernel<<<uem_flat_grid(al ? (n + 3) / 4 : n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n4, n);
+    return uem_check_launch("add_clear");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // layout transforms at the API edge (LDS-tiled transposes)
 // ---------------------------------------------------------------------------------------------------------

@@ -85,6 +85,7 @@ class DataParallel:
         self._pending = None
         self._fwd_calls = 0
         self._bwd_calls = 0
+        self._trigger_events = []           # (stream, event) at the trigger of every backward pass but the last (two backward streams)
         self.unpaired_forwards = 0          # train-mode forwards that never saw a backward (diagnostic)
         self._active = self.world > 1 or (FORCE and dist.is_initialized())
         if overlap:
@@ -126,14 +127,31 @@ class DataParallel:
         if self._bwd_calls > self._fwd_calls:
             raise ops.UemError(f"DataParallel: {self._bwd_calls} backward passes through the model since the last "
                                f"reduce_gradients() but only {self._fwd_calls} train-mode forwards were counted")
-        if self._active and self._split is not None and self._pending is None and self._bwd_calls == self._fwd_calls:
+        last = self._bwd_calls == self._fwd_calls
+        two = bool(ops._FWD2) and torch.cuda.is_available()
+        if two and not last:
+            # the step's graphs may run their backward chains on two streams (ops, "two streams"): remember where this one stood
+            ev = torch.cuda.Event()
+            ev.record()
+            self._trigger_events.append((torch.cuda.current_stream(), ev))
+        if self._active and self._split is not None and self._pending is None and last:
+            if two:
+                cur = torch.cuda.current_stream()
+                for s, ev in self._trigger_events:
+                    if s != cur:
+                        cur.wait_event(ev)          # the other graph's chain is past its trigger too ...
+                fold = getattr(self.model, "fold_shadow_grads", None)
+                if fold is not None:
+                    fold(lo=self._split, synced=True)   # ... and its share of the bucket joins the arena before the bucket goes out
             _, garena, n = self.model.flat_parameters()
             self._pending = dist.all_reduce(garena[self._split:], op=dist.ReduceOp.SUM, async_op=True)
+        if last:
+            self._trigger_events.clear()
 
     def reduce_gradients(self):
         """all-reduce(sum) of the gradient arena; returns the prescale (1/world) for FusedSGD.step."""
         _, garena, _ = self.model.flat_parameters()
-        ops.side_join()            # side-stream weight gradients land before the arena goes out (also after a backward that raised)
+        ops.grad_join()            # side-stream / second-stream gradients land before the arena goes out (also after a backward that raised)
         if self._split is not None and self._fwd_calls != self._bwd_calls:
             # a train-mode forward whose graph never ran backward (a validation pass left in .train(), a dropped
             # output): the early bucket was (rightly) not sent, nothing is wrong with THIS step's gradients, but
@@ -152,4 +170,5 @@ class DataParallel:
         self._pending = None
         self._fwd_calls = 0
         self._bwd_calls = 0
+        self._trigger_events.clear()
         return 1.0 / self.world

@@ -128,10 +128,13 @@ class Deeplabv2(nn.Module):
                 gv.copy_(p.grad)
                 p.grad = gv
             p._uem_grad_view = (lambda vo=view_of, ga=garena: vo(ga))
+            p._uem_grad2_view = (lambda vo=view_of, me=self: vo(me._shadow_grad_arena()))
+            p.__dict__.pop("_uem_g2", None)
             p._uem_owner = self
             p._uem_off = off
             off += (n + 3) // 4 * 4
         self._arena, self._grad_arena, self._n_params = arena, garena, total
+        self._grad_arena2, self._g2_dirty, self._g2_hi, self._g2_task = None, False, total, None
         # one int64 arena for every BatchNorm's num_batches_tracked: a training forward bumps all of them with ONE
         # add instead of one tiny launch per layer (53 per forward on ResNet-50)
         bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
@@ -141,9 +144,106 @@ class Deeplabv2(nn.Module):
             bn._buffers["num_batches_tracked"] = nbt[i]
             bn._uem_nbt_arena = True
         self._nbt, self._bns = nbt, bns
+        # ... and one fp32 arena for every BatchNorm's running mean / variance, with a zeroed SHADOW of the same layout: while the
+        # step's second forward runs on its own stream (step.forward_pair) the modules' buffers point into the shadow, whose zeros
+        # turn the kernels' `(1 - m) * r + m * v` into the EMA contribution m * v; `apply_shadow_running_stats` then applies it to the
+        # real statistics behind the join, in the reference's order (source batch first) and to the last bit of the sequential form
+        tracked = [bn for bn in bns if bn.running_mean is not None and bn.running_var is not None]
+        sizes = [(bn.running_mean.numel() + 3) // 4 * 4 for bn in tracked]
+        rs = torch.zeros(max(2 * sum(sizes), 4), device=dev, dtype=torch.float32)
+        self._rs_views = []
+        off = 0
+        for bn, n_ in zip(tracked, sizes):
+            c = bn.running_mean.numel()
+            for name in ("running_mean", "running_var"):
+                view = rs[off:off + c]
+                view.copy_(bn._buffers[name])
+                bn._buffers[name] = view
+                self._rs_views.append((bn, name, off, c))
+                off += n_
+        self._rs, self._rs_shadow, self._rs_tracked = rs, torch.zeros_like(rs), tracked
+        self._nbt_skip = False
+
+    # ---- the step's second forward on its own stream (step.forward_pair) --------------------------------------------
+    def two_stream_ok(self):
+        """may the second train-mode forward of a step run beside the first?  Every BatchNorm in training mode, tracking its running
+        statistics with one common momentum; no checkpointed layer (its re-run inside backward would queue work on the second stream)"""
+        if self._arena is None or not self.training or not self._rs_tracked or len(self._rs_tracked) != len(self._bns):
+            return False
+        m0 = self._rs_tracked[0].momentum
+        if m0 is None or any((not bn.training) or bn.momentum != m0 for bn in self._bns):
+            return False
+        return not any(self.encoder.config.with_cp)
+
+    def shadow_running_stats(self):
+        """context manager: inside it every BatchNorm's running-statistics buffers are views of the zeroed shadow arena and the
+        num_batches_tracked bump is skipped (the caller bumps it on the main stream)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            for bn, name, off, c in self._rs_views:
+                bn._buffers[name] = self._rs_shadow[off:off + c]
+            self._nbt_skip = True
+            try:
+                yield
+            finally:
+                self._nbt_skip = False
+                for bn, name, off, c in self._rs_views:
+                    bn._buffers[name] = self._rs[off:off + c]
+        return cm()
+
+    def apply_shadow_running_stats(self):
+        """running = (1 - momentum) * running + shadow; shadow = 0 -- on the current stream, behind the join of the two forwards: what
+        the second forward would have done to the statistics the first one left, multiplication and addition rounded as in the
+        kernels' own update (bn_stats_finish)"""
+        m = float(self._rs_tracked[0].momentum)
+        ops.call("uem_scale", ops.ptr(self._rs), self._rs.numel(), 1.0 - m, ops.stream())
+        ops.add_(self._rs, self._rs_shadow)
+        self._rs_shadow.zero_()
+        self._nbt_step()
+
+    # ---- the second graph's backward on its own stream: the shadow gradient arena (ops: two streams) ------------------
+    def _shadow_grad_arena(self):
+        if self._grad_arena2 is None:
+            self._grad_arena2 = torch.zeros_like(self._grad_arena)
+        return self._grad_arena2
+
+    def shadow_grad(self, p):
+        """the slot of parameter `p` in the shadow gradient arena (same layout as p.grad), marked as holding gradients to fold"""
+        g = p.__dict__.get("_uem_g2")
+        if g is None:
+            g = p._uem_g2 = p._uem_grad2_view()
+        if not self._g2_dirty:
+            self._g2_dirty = True
+        ops.shadow_grads_touched(self)
+        return g
+
+    def fold_shadow_grads(self, lo=0, synced=False):
+        """gradient arena[lo:hi] += shadow[lo:hi]; shadow[lo:hi] = 0 on the current stream, once it has waited for the side stream and
+        the second stream (`synced`: the caller has ordered the current stream behind the writers of [lo:hi] itself); hi is the start
+        of what an earlier partial fold (the data-parallel early bucket) already covered.  Runs as the end-of-backward callback of a
+        pass that touched the shadow, and from ops.grad_join."""
+        if not self._g2_dirty or self._grad_arena2 is None:
+            return
+        hi = self._g2_hi
+        ops.side_join()
+        second = ops._FWD2.get(self._grad_arena.device.index)
+        cur = torch.cuda.current_stream()
+        if second is not None and cur != second and not synced:
+            cur.wait_stream(second)
+        if hi > lo:
+            a, b = self._grad_arena[lo:hi], self._grad_arena2[lo:hi]
+            ops.call("uem_add_clear", ops.ptr(a), ops.ptr(b), a.numel(), ops.stream())
+        if lo > 0:
+            self._g2_hi = lo                 # the rest is folded at the end of the pass
+        else:
+            self._g2_hi, self._g2_dirty, self._g2_task = self._n_params, False, None
 
     def _nbt_step(self):
         """BatchNorm2d.forward: `num_batches_tracked += 1` for every layer in training mode."""
+        if self._nbt_skip:
+            return
         if all(bn.training for bn in self._bns):
             self._nbt.add_(1)
         else:
@@ -166,7 +266,7 @@ class Deeplabv2(nn.Module):
         """Zero the flat gradient arena (one memset) and keep every .grad attached to it."""
         if self._grad_arena is None:
             return super().zero_grad(set_to_none)
-        ops.side_join()             # weight gradients a failed backward left on the side stream must not land after the memset
+        ops.grad_join()             # weight gradients a failed backward left on the side / second stream must not land after the memset
         self._grad_arena.zero_()
         for p in self.parameters():
             if p.grad is None and p.requires_grad:           # a frozen parameter keeps .grad = None, as under torch autograd

@@ -16,6 +16,8 @@ from torch.autograd import Function
 from .. import ops
 from ..ops import UemError
 
+_on_bwd = ops.on_backward_stream          # ops, "two streams for the step's two graphs"
+
 
 def grad_buffer(p):
     """The tensor wgrad kernels accumulate into: p.grad, (re)attached to the flat arena when None.  None for a frozen
@@ -23,6 +25,15 @@ def grad_buffer(p):
     skip its gradient and its .grad stays None, as under torch autograd."""
     if not p.requires_grad:
         return None
+    if ops._FWD2 and ops.on_second_stream():
+        # a backward node of the step's second graph, on the second stream: it accumulates into the owner's shadow gradient arena,
+        # folded into p.grad at the end of the pass (ops: two streams) -- never the same address as the first graph's node next door
+        owner = getattr(p, "_uem_owner", None)
+        if owner is None or not hasattr(p, "_uem_grad2_view"):
+            raise UemError("a backward node is running on the second stream for a parameter outside a flat gradient arena")
+        if p.grad is None:
+            p.grad = p._uem_grad_view()
+        return owner.shadow_grad(p)
     if p.grad is None:
         maker = getattr(p, "_uem_grad_view", None)
         g = maker() if maker is not None else torch.zeros_like(p)
@@ -88,6 +99,7 @@ class StemFn(Function):
         return y
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         x4, z, stbuf, idx = ctx.saved_tensors
         resnet = ctx.resnet
@@ -184,6 +196,7 @@ class BottleneckFn(Function):
         return y
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         blk = ctx.blk
         sv = ctx.saved_tensors
@@ -293,6 +306,7 @@ class InstNormFn(Function):
         return y
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         y, invstd = ctx.saved_tensors
         return ops.instnorm_bwd(y, dy.contiguous(), invstd), None
@@ -366,6 +380,7 @@ class ASPPHeadsFn(Function):
         return (x1, x2) if nh == 2 else x1
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, d1, d2=None):
         import ctypes
         feat, wall = ctx.saved_tensors

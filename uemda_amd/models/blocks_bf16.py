@@ -11,6 +11,8 @@ from torch.autograd import Function
 from .. import ops, ops_bf16 as ob
 from .blocks import _Link, _st_from, _st_tensor, grad_buffer, grad_ohwi
 
+_on_bwd = ops.on_backward_stream          # every backward of a step on ONE stream (ops: two forward streams)
+
 
 class CastFn(Function):
     """fp32 <-> bf16 at the two ends of the bf16 region (gradient cast back on the way down)."""
@@ -21,6 +23,7 @@ class CastFn(Function):
         return ob.to_bf16(x.contiguous()) if to_bf16 else ob.to_f32(x.contiguous())
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         dy = dy.contiguous()
         return (ob.to_f32(dy) if ctx.to_bf16 else ob.to_bf16(dy)), None
@@ -45,6 +48,7 @@ class StemBf16Fn(Function):
         return y
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         x4, z, stbuf, idx = ctx.saved_tensors
         resnet = ctx.resnet
@@ -65,6 +69,7 @@ class InstNormBf16Fn(Function):
         return y
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         y, invstd = ctx.saved_tensors
         return ob.instnorm_bwd(y, dy.contiguous(), invstd), None
@@ -104,6 +109,7 @@ class BottleneckBf16Fn(Function):
         return y
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dy):
         blk = ctx.blk
         sv = ctx.saved_tensors

@@ -11,6 +11,8 @@ from .. import ops
 from ..ops import UemError, call, ptr, stream
 from .blocks import _BN, _st_from, _st_tensor, grad_buffer, grad_ohwi
 
+_on_bwd = ops.on_backward_stream          # every backward of a step on ONE stream (ops: two forward streams)
+
 _drop_counter = itertools.count(1)
 
 
@@ -77,6 +79,7 @@ class PPMHeadFn(Function):
             return PPMHeadFn._forward(ctx, feat, head)
 
     @staticmethod
+    @_on_bwd
     def backward(ctx, dout):
         with ops.conv_precision(ctx.prec):
             return PPMHeadFn._backward(ctx, dout)

@@ -192,6 +192,7 @@ class _Side:
         self.dirty = False               # work was queued since the last join
         self.reads = []                  # (first byte, past-the-end byte, label) of what the queued launches read, since the last join
         self.held = []                   # the tensors those launches read, kept alive until the join (see on_side)
+        self.users = []                  # the streams that queued launches since the last join (two when the step's graphs run on two)
 
     @classmethod
     def get(cls):
@@ -205,9 +206,14 @@ class _Side:
         self.task = None
         self.reads.clear()
         if self.dirty:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.stream)
+            for s in self.users:         # every stream that handed tensors to the side stream waits: the held ones go back to ITS pool
+                if s != cur:
+                    s.wait_stream(self.stream)
             self.dirty = False
-        self.held.clear()                # freed in main-stream order BEHIND the wait: reusable at once, no cross-stream bookkeeping
+        self.users.clear()
+        self.held.clear()                # freed in their streams' order BEHIND the wait: reusable at once, no cross-stream bookkeeping
 
 
 def side_join():
@@ -269,6 +275,8 @@ def on_side(launch, tensors, label="weight gradient"):
             t.record_stream(st.stream)
         st.reads.append(_byte_range(t) + (f"{label} reading {tuple(t.shape)}", weakref.ref(t if t._base is None else t._base)))
     st.dirty = True
+    if main not in st.users:
+        st.users.append(main)
     # one join per backward pass, queued in THAT pass: the flag is the graph task's id, not a boolean -- a pass that raised after
     # queueing never ran its callbacks, and a boolean left True would keep every later pass from queueing its own
     tid = torch._C._current_graph_task_id()
@@ -281,6 +289,98 @@ def on_side(launch, tensors, label="weight gradient"):
         except RuntimeError:
             st.join()
 
+
+
+# ---- two streams for the step's two graphs (round 6) -------------------------------------------------------------------------------
+# The two train-mode forwards of a train_ssl_uem step (source batch, target batch) are independent until the mining reads both, and so
+# are their backward chains: the step runs the second forward on its own stream (step.forward_pair), and autograd then runs that
+# graph's backward nodes on the same stream, beside the first graph's.  Every launch of the bf16 path and most of the fp32 path leaves
+# part of the chip idle (latency- and L2-bound kernels, the ramp and tail of every launch), and two independent chains fill each
+# other's gaps (profiles/r06_l_two_streams.txt).  What the two graphs share is kept in order by construction:
+#   * BatchNorm running statistics: the second forward writes its EMA contribution into a shadow arena, applied behind the join in the
+#     reference's order -- bit for bit the sequential pair's statistics; num_batches_tracked is bumped on the main stream;
+#   * derived filter banks: all refreshed before the fork;
+#   * parameter gradients (read-modify-write accumulations: BatchNorm gamma / beta, the stem's and the Winograd folds, every
+#     dw += ...): a backward node running on the second stream accumulates into a SHADOW gradient arena (blocks.grad_buffer), which the
+#     end-of-backward callback adds to the real one on the caller's stream once that stream has waited for the second (and the side)
+#     stream -- no two streams ever update one address; weight gradients of both graphs still share the ONE side stream, in order;
+#   * the data-parallel early bucket: the last trigger waits for the other graph's trigger event and folds the shadow slice first.
+# UEM_TWO_STREAM_BWD=0 keeps the forwards on two streams and moves every backward node to the step's stream (`on_backward_stream`).
+TWO_STREAM_FWD = os.environ.get("UEM_TWO_STREAM_FWD", "1") != "0"
+TWO_STREAM_BWD = os.environ.get("UEM_TWO_STREAM_BWD", "1") != "0"
+_FWD2 = {}                 # device index -> the second stream
+_BWD_MAIN = {}             # device index -> the stream backward work is redirected to when TWO_STREAM_BWD is off
+_SHADOW_OWNERS = weakref.WeakSet()      # models whose shadow gradient arena holds unfolded gradients
+
+
+def second_stream():
+    dev = torch.cuda.current_device()
+    st = _FWD2.get(dev)
+    if st is None:
+        st = _FWD2[dev] = torch.cuda.Stream()
+    return st
+
+
+def on_second_stream():
+    """is the current stream this package's second stream (a backward node of the step's second graph is running)?"""
+    if not _FWD2:
+        return False
+    st = _FWD2.get(torch.cuda.current_device())
+    return st is not None and torch.cuda.current_stream() == st
+
+
+def set_backward_stream(stream_):
+    _BWD_MAIN[torch.cuda.current_device()] = stream_
+
+
+def on_backward_stream(fn):
+    """decorator of an autograd Function's backward.  A node whose forward ran on the second stream is handed that stream by the
+    engine; with TWO_STREAM_BWD (default) it stays there (gradients go to the shadow arena, see above); without, its work is moved
+    to the step's stream (ordered behind what the engine queued on the node's stream, and the node's stream behind it)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(ctx, *grads):
+        if TWO_STREAM_BWD or not _BWD_MAIN:
+            return fn(ctx, *grads)
+        main = _BWD_MAIN.get(torch.cuda.current_device())
+        if main is None:
+            return fn(ctx, *grads)
+        cur = torch.cuda.current_stream()
+        if cur == main:
+            return fn(ctx, *grads)
+        main.wait_stream(cur)
+        with torch.cuda.stream(main):
+            out = fn(ctx, *grads)
+        cur.wait_stream(main)
+        return out
+    return wrapper
+
+
+def shadow_grads_touched(owner):
+    """blocks.grad_buffer handed out a view of `owner`'s shadow gradient arena: fold it at the end of this backward pass (once per
+    pass; `grad_join` folds what a pass that raised left behind)"""
+    _SHADOW_OWNERS.add(owner)
+    tid = torch._C._current_graph_task_id()
+    if tid >= 0 and getattr(owner, "_g2_task", None) != tid:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(owner.fold_shadow_grads)
+            owner._g2_task = tid
+        except RuntimeError:
+            pass
+
+
+def grad_join():
+    """Whoever reads or clears the gradient arena next (FusedSGD.step, clip_grad_norm_, DataParallel.reduce_gradients, zero_grad, the
+    step after backward) calls this first: the current stream waits for the side stream's weight gradients and for the second
+    stream's backward chain, and shadow gradients not yet folded (a backward pass that raised never ran its callbacks) are folded."""
+    side_join()
+    for owner in list(_SHADOW_OWNERS):
+        owner.fold_shadow_grads()
+    if _FWD2:
+        st = _FWD2.get(torch.cuda.current_device())
+        if st is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_stream(st)
 
 
 SIDE_OFF = 0            # > 0: no side stream (GraphedStep raises it around its capture when UEM_GRAPH_SIDE=0)
@@ -608,6 +708,20 @@ class _WeightPrep:
             j["stamp"] = self._stamp(j["ref"]())
         return job["dst"]
 
+    def refresh_all(self):
+        """every live bank fresh NOW, on the current stream (step.forward_pair: before the second forward stream forks off, so that
+        neither forward finds a stale bank and refreshes it under the other's reads)"""
+        if not self.jobs:
+            return
+        self.settle()
+        if self.table is None:
+            return
+        if all(j["stamp"] == self._stamp(j["ref"]()) for j in self.live):
+            return
+        self._run(self.table)
+        for j in self.live:
+            j["stamp"] = self._stamp(j["ref"]())
+
     def settle(self):
         """(re)build the device job table if the set of live jobs changed since it was built: new banks, parameters that were freed or
         moved to another arena (their old address may be unmapped).  GraphedStep calls this before capturing, and keeps the table's
@@ -630,6 +744,11 @@ class _WeightPrep:
 class _WeightPrepPerDevice:
     def __init__(self):
         self.by_device = {}
+
+    def refresh_all(self):
+        prep = self.by_device.get(torch.cuda.current_device())
+        if prep is not None:
+            prep.refresh_all()
 
     def get(self, param, kind, shape, dtype=torch.float32):
         need_gpu(param)

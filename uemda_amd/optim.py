@@ -31,7 +31,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2):
         raise UemError("clip_grad_norm_: only the L2 norm is implemented")
     model = _arena_of(parameters)
     arena, garena, n = model.flat_parameters()
-    ops.side_join()                # weight gradients still on the side stream (a backward that raised never ran its join callback)
+    ops.grad_join()                # weight gradients still on the side / second stream (a backward that raised never ran its join callback)
     norm = grad_norm(model)
     coef = torch.clamp(float(max_norm) / (norm + 1e-6), max=1.0)      # one scalar
     call("uem_scale_by_scalar", ptr(garena), None, n, ptr(coef), stream())
@@ -77,7 +77,7 @@ class FusedSGD(torch.optim.Optimizer):
     def step(self, closure=None, max_norm=None, grad_prescale=1.0):
         g = self.param_groups[0]
         arena, garena, n = self.model.flat_parameters()
-        ops.side_join()            # no-op after a clean backward (its end-of-backward callback joined); the safety net after one that raised
+        ops.grad_join()            # no-op after a clean backward (its end-of-backward callback joined); the safety net after one that raised
         norm = None
         if max_norm is not None:
             norm = grad_norm(self.model)

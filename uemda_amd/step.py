@@ -11,6 +11,11 @@ HYPER = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4, max_norm=32.0, cutoff_top
              ignore_label=-1)
 
 
+def _ops():
+    from . import ops
+    return ops
+
+
 class StepState:
     """loss objects the reference builds once before its loop (train_ssl_uem.py:129-137)."""
 
@@ -21,6 +26,38 @@ class StepState:
                                   ignore_label=hp["ignore_label"])
 
 
+def forward_pair(model, images_a, images_b):
+    """The two train-mode forwards of a step, `model(images_a)` then `model(images_b)` (tools/train_ssl_uem.py:205-207), the second on
+    its own stream beside the first when nothing forbids it (ops.TWO_STREAM_FWD; Deeplabv2.two_stream_ok): the outputs, the BatchNorm
+    running statistics and num_batches_tracked are those of the sequential pair, bit for bit.  The second graph's backward nodes run
+    on the second stream too and accumulate into the model's shadow gradient arena, folded into .grad at the end of the backward
+    pass (ops, "two streams"; `ops.grad_join()` is what a caller who reads .grad right after backward may call).  Sequential while a hipGraph is being captured, under per-launch event timing, and
+    until the model has taken two training forwards (its derived filter banks exist from then on)."""
+    import torch
+    from . import ops
+    n_seen = getattr(model, "_uem_train_forwards", 0)
+    model._uem_train_forwards = n_seen + 2
+    two = (ops.TWO_STREAM_FWD and n_seen >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok() and torch.is_grad_enabled()
+           and not ops.PROF.enabled and not torch.cuda.is_current_stream_capturing())
+    if not two:
+        return model(images_a), model(images_b)
+    main = torch.cuda.current_stream()
+    second = ops.second_stream()
+    ops.PREP.refresh_all()                                  # every derived filter bank fresh before the fork ...
+    if getattr(model.encoder, "storage", "fp32") == "bf16":
+        from . import ops_bf16
+        ops_bf16.weight(next(p for p in model.encoder.parameters() if p.dim() == 4))    # ... and the bf16 copy of the weight arena
+    ops.set_backward_stream(main)
+    second.wait_stream(main)
+    out_a = model(images_a)
+    with model.shadow_running_stats():
+        with torch.cuda.stream(second):
+            out_b = model(images_b)
+    main.wait_stream(second)
+    model.apply_shadow_running_stats()
+    return out_a, out_b
+
+
 def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None, mark=None):
     """`mark(name)`, if given, is called at the phase boundaries (bench.py records a HIP event there)."""
     hp = state.hp
@@ -28,9 +65,8 @@ def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id
     model.train()
     optimizer.param_groups[0]["lr"] = lr
     mark("start")
-    pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # :205
+    (pred_s1, pred_s2, feat_s), (pred_t1, pred_t2, feat_t) = forward_pair(model, batch["images_s"], batch["images_t"])   # :205-207
     mark("forward_source")
-    pred_t1, pred_t2, feat_t = model(batch["images_t"])                         # :207
     mark("forward_target")
     soft, hard = aligner.refine_and_select(batch["label_t_sup"], feat_t, [pred_t1, pred_t2], batch["label_t_soft"],
                                            mode=hp["refine_mode"], temp=hp["refine_temp"], cutoff_top=hp["cutoff_top"],
@@ -44,6 +80,7 @@ def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id
     mark("losses_forward")
     optimizer.zero_grad()
     loss.backward()
+    _ops().grad_join()              # the step's stream behind the side stream and the second graph's stream (no-op when neither ran)
     mark("backward")
     prescale = dp.reduce_gradients() if dp is not None else 1.0
     mark("grad_allreduce_wait")
