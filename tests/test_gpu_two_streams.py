@@ -56,8 +56,8 @@ def test_forward_pair_on_two_streams_equals_the_sequential_pair(storage, monkeyp
     assert int(par[1]["encoder.resnet.bn1.num_batches_tracked"]) == 4
 
 
-@pytest.mark.parametrize("storage,use_ppm", [("fp32", False), ("bf16", False), ("fp32", True)])
-def test_ssl_steps_with_two_forward_streams_match_the_sequential_steps(storage, use_ppm, monkeypatch):
+@pytest.mark.parametrize("storage,use_ppm,pipelines", [("fp32", False, True), ("bf16", False, True), ("fp32", True, True), ("fp32", False, False)])
+def test_ssl_steps_with_two_forward_streams_match_the_sequential_steps(storage, use_ppm, pipelines, monkeypatch):
     """three train_ssl_uem steps (the second and third fork).  Step 2 -- same weights to the order of step 1's fp32 atomics (split-K
     weight gradients, BatchNorm partial sums) -- must agree with the sequential step to that order.  Step 3 has seen that noise through
     two clipped updates of a randomly initialised network (gradient norm ~550 against the clip's 32): two SEQUENTIAL runs differ there
@@ -71,6 +71,7 @@ def test_ssl_steps_with_two_forward_streams_match_the_sequential_steps(storage, 
     from uemda_amd.step import HYPER, StepState, ssl_step
     batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=9).items()}
     res = {}
+    monkeypatch.setattr(ops, "TWO_PIPELINES", pipelines)       # the target graph's mining and loss on its stream too / on the caller's
     for two in (False, True):
         monkeypatch.setattr(ops, "TWO_STREAM_FWD", two)
         model = _model(storage, use_ppm)

@@ -308,6 +308,10 @@ def on_side(launch, tensors, label="weight gradient"):
 # UEM_TWO_STREAM_BWD=0 keeps the forwards on two streams and moves every backward node to the step's stream (`on_backward_stream`).
 TWO_STREAM_FWD = os.environ.get("UEM_TWO_STREAM_FWD", "1") != "0"
 TWO_STREAM_BWD = os.environ.get("UEM_TWO_STREAM_BWD", "1") != "0"
+# step.ssl_step with the target graph's mining and loss on its stream too and two backward passes (the source pipeline never waits for the
+# target's): built, tested, measured SLOWER than the joined form on one box (profiles/r06_l_two_streams.txt: bf16 36.3 against 35.6 ms,
+# R101-1024 192.9 against 191.2, fp32 97.4 against 96.8) -- the two chains drift apart and stop sharing each layer's filter bank in L2.
+TWO_PIPELINES = os.environ.get("UEM_TWO_PIPELINES", "0") != "0"
 _FWD2 = {}                 # device index -> the second stream
 _BWD_MAIN = {}             # device index -> the stream backward work is redirected to when TWO_STREAM_BWD is off
 _SHADOW_OWNERS = weakref.WeakSet()      # models whose shadow gradient arena holds unfolded gradients

@@ -26,21 +26,32 @@ class StepState:
                                   ignore_label=hp["ignore_label"])
 
 
-def forward_pair(model, images_a, images_b):
+def _may_fork(model):
+    """may this step's second train-mode forward run on its own stream?  (the predicate of forward_pair, without side effects)"""
+    import torch
+    from . import ops
+    return (ops.TWO_STREAM_FWD and getattr(model, "_uem_train_forwards", 0) >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok()
+            and torch.is_grad_enabled() and not ops.PROF.enabled and not torch.cuda.is_current_stream_capturing())
+
+
+def forward_pair(model, images_a, images_b, join=True):
     """The two train-mode forwards of a step, `model(images_a)` then `model(images_b)` (tools/train_ssl_uem.py:205-207), the second on
     its own stream beside the first when nothing forbids it (ops.TWO_STREAM_FWD; Deeplabv2.two_stream_ok): the outputs, the BatchNorm
     running statistics and num_batches_tracked are those of the sequential pair, bit for bit.  The second graph's backward nodes run
     on the second stream too and accumulate into the model's shadow gradient arena, folded into .grad at the end of the backward
-    pass (ops, "two streams"; `ops.grad_join()` is what a caller who reads .grad right after backward may call).  Sequential while a hipGraph is being captured, under per-launch event timing, and
-    until the model has taken two training forwards (its derived filter banks exist from then on)."""
+    pass (ops, "two streams"; `ops.grad_join()` is what a caller who reads .grad right after backward may call).  Sequential while a
+    hipGraph is being captured, under per-launch event timing, and until the model has taken two training forwards (its derived
+    filter banks exist from then on).
+    join=False (ssl_step's two pipelines): returns (out_a, out_b, finish); out_b is then still in flight on `ops.second_stream()`, and
+    `finish()` -- current stream behind the second stream, the second forward's running statistics applied -- is the caller's to call
+    before anyone reads the statistics or touches out_b on another stream (finish is None when the pair ran sequentially)."""
     import torch
     from . import ops
-    n_seen = getattr(model, "_uem_train_forwards", 0)
-    model._uem_train_forwards = n_seen + 2
-    two = (ops.TWO_STREAM_FWD and n_seen >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok() and torch.is_grad_enabled()
-           and not ops.PROF.enabled and not torch.cuda.is_current_stream_capturing())
+    two = _may_fork(model)
+    model._uem_train_forwards = getattr(model, "_uem_train_forwards", 0) + 2
     if not two:
-        return model(images_a), model(images_b)
+        out = model(images_a), model(images_b)
+        return out if join else out + (None,)
     main = torch.cuda.current_stream()
     second = ops.second_stream()
     ops.PREP.refresh_all()                                  # every derived filter bank fresh before the fork ...
@@ -53,17 +64,65 @@ def forward_pair(model, images_a, images_b):
     with model.shadow_running_stats():
         with torch.cuda.stream(second):
             out_b = model(images_b)
-    main.wait_stream(second)
-    model.apply_shadow_running_stats()
-    return out_a, out_b
+
+    def finish():
+        torch.cuda.current_stream().wait_stream(second)
+        model.apply_shadow_running_stats()
+    if join:
+        finish()
+        return out_a, out_b
+    return out_a, out_b, finish
+
+
+def _ssl_step_two_pipelines(model, aligner, optimizer, state, batch, lr, dp, sup_ignore_id):
+    """ssl_step with the source graph's whole pipeline (forward, loss, backward) on the caller's stream and the target graph's
+    (forward, label refinement and selection, loss, backward) on the second stream (ops, "two streams").  Same kernels on the same
+    inputs as the sequential step; what the two pipelines share is ordered explicitly:
+      * the prototypes: refined against (second stream) BEFORE the source features update them (caller's stream) -- :209-216's order;
+      * gradients: the caller's arena / the shadow arena, folded when the second backward pass ends; zero_grad comes first (it joins);
+      * BatchNorm running statistics: the second forward's contribution is applied after the join, source batch first;
+      * data parallel: DataParallel's early bucket waits for both graphs' triggers (dp._on_trigger_backward)."""
+    import torch
+    from . import ops
+    hp = state.hp
+    optimizer.zero_grad()                                   # before the fork: it waits for every stream the last step used
+    main, second = torch.cuda.current_stream(), ops.second_stream()
+    (pred_s1, pred_s2, feat_s), (pred_t1, pred_t2, feat_t), finish = forward_pair(model, batch["images_s"], batch["images_t"], join=False)
+    if finish is None:
+        raise ops.UemError("ssl_step: the forward pair declined to fork after _may_fork said it would")
+    with torch.cuda.stream(second):
+        soft, hard = aligner.refine_and_select(batch["label_t_sup"], feat_t, [pred_t1, pred_t2], batch["label_t_soft"],
+                                               mode=hp["refine_mode"], temp=hp["refine_temp"], cutoff_top=hp["cutoff_top"],
+                                               cutoff_low=hp["cutoff_low"], sup_ignore_id=sup_ignore_id)   # :209-214
+        refined = torch.cuda.Event()
+        refined.record()
+        loss_target = loss_calc_uvem([pred_t1, pred_t2], hard, soft, loss_fn=state.loss_fn_t, multi=True)    # :221
+    main.wait_event(refined)                                # the prototypes were read: now they may move
+    label_ds = aligner.update_prototype(feat_s, batch["label_s"])               # :216
+    loss_source = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :219
+    # loss = loss_source + loss_target; loss.backward() (:222-227) as two passes over two disjoint graphs: the source pass is queued on
+    # the caller's stream without waiting for the target pipeline; the target pass ends with the join and the fold of its gradients
+    loss_source.backward()
+    loss_target.backward()
+    ops.grad_join()
+    finish()
+    prescale = dp.reduce_gradients() if dp is not None else 1.0
+    optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)             # :230-232 (clip 32 + SGD)
+    aligner.check_superpixel_ids(wait=False)
+    return dict(loss_source=loss_source.detach(), loss_target=loss_target.detach(), label_t_soft=soft,
+                label_t_hard=hard, label_s_ds=label_ds, pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
+                pred_t1=pred_t1.detach(), pred_t2=pred_t2.detach(), feat_s=feat_s.detach(), feat_t=feat_t.detach(),
+                grad_norm=optimizer.last_grad_norm)
 
 
 def ssl_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_id=None, mark=None):
     """`mark(name)`, if given, is called at the phase boundaries (bench.py records a HIP event there)."""
     hp = state.hp
-    mark = mark or (lambda name: None)
     model.train()
     optimizer.param_groups[0]["lr"] = lr
+    if mark is None and _ops().TWO_PIPELINES and _ops().TWO_STREAM_BWD and _may_fork(model):
+        return _ssl_step_two_pipelines(model, aligner, optimizer, state, batch, lr, dp, sup_ignore_id)
+    mark = mark or (lambda name: None)
     mark("start")
     (pred_s1, pred_s2, feat_s), (pred_t1, pred_t2, feat_t) = forward_pair(model, batch["images_s"], batch["images_t"])   # :205-207
     mark("forward_source")
