@@ -14,7 +14,8 @@ the matrix pipe EXECUTES (a Winograd conv issues 2.25x / 4x fewer than its algor
 figure beside it.  `roofline_hbm` prices the HBM-bound mining phase (label_refine + pseudo_selection).  `cpu_baseline` is the
 oracle (CPU restatement of the reference, `kind: "port"`) timed on the host cores at BASELINE config 1.
 `other_configs` (N = 1): the same step in the other configurations BASELINE.json names (bf16 storage, the PPM head,
-ResNet-101 on 1024x1024 tiles), 3 timed steps each AFTER the headline, each with its own roofline entry; they never touch `value`.
+ResNet-101 on 1024x1024 tiles; BASELINE config 2's source-only step), 6 timed steps each AFTER the headline plus one untimed step
+with per-launch events for its own roofline entry; they never touch `value`.
 """
 import argparse
 import gc
@@ -322,9 +323,10 @@ def replay_leg(s, workload, step0, tiles_per_step, nrep=5):
 
 
 def short_leg(cfg, steps=6, warmup=2):
-    """One of the `other_configs`: fresh model, `warmup` untimed + `steps` timed steps, per-launch events on the last one (that one step
-    runs its weight gradients serially -- ops.in_backward -- so that the family fractions mean something: six steps keep its share of
-    the average at a sixth)."""
+    """One of the `other_configs`: fresh model, `warmup` untimed + `steps` timed steps as shipped (weight gradients on the side stream,
+    the two graphs on two streams), then ONE more step, outside the timed region, with per-launch events for the family fractions
+    (that step runs one kernel at a time -- ops.in_backward, step.forward_pair -- so that the fractions mean something; until
+    round 6 it was the last of the timed steps and put a sixth of its serial time into ms_per_step)."""
     from uemda_amd import ops
     s = Setup(cfg, 0, 1, None)
     for i in range(warmup):
@@ -335,10 +337,12 @@ def short_leg(cfg, steps=6, warmup=2):
     torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for i in range(steps):
-        ops.PROF.enabled = i == steps - 1
         s.one_step(warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ops.PROF.enabled = True
+    s.one_step(warmup + steps)
+    torch.cuda.synchronize()
     ops.PROF.enabled = False
     bf16 = cfg.storage == "bf16"
     out = dict(value=round(s.tiles_per_step / dt, 2), unit=f"tiles({cfg.size}x{cfg.size})/s", ms_per_step=round(1e3 * dt, 2), steps=steps,
@@ -346,10 +350,11 @@ def short_leg(cfg, steps=6, warmup=2):
                workload=f"{cfg.model}-{cfg.head} {cfg.workload} step, {cfg.batch} source + {cfg.batch if cfg.workload == 'ssl' else 0} target {cfg.size}x{cfg.size} tiles",
                roofline=roofline_of(ops.PROF.summary(), BF16_MATRIX_PEAK_TFLOPS if bf16 else F32_MATRIX_PEAK_TFLOPS),
                peak_allocated_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1),
-               peak_reserved_GB=round(torch.cuda.max_memory_reserved() / 1e9, 1))
+               peak_reserved_GB=round(torch.cuda.max_memory_reserved() / 1e9, 1),
+               profiled_step="one extra step after the timed ones (per-launch events, one kernel at a time): not in ms_per_step")
     ops.PROF.records = []
     if cfg.storage == "bf16" and cfg.size <= 512 and not getattr(cfg, "no_hipgraph", False):
-        out["hipgraph"] = replay_leg(s, cfg.workload, warmup + steps, s.tiles_per_step)     # where the host's share was largest (16 of 45 ms)
+        out["hipgraph"] = replay_leg(s, cfg.workload, warmup + steps + 1, s.tiles_per_step)     # where the host's share was largest (16 of 45 ms)
     del s
     gc.collect()
     torch.cuda.empty_cache()

@@ -24,13 +24,15 @@ fi
 # Kernel trace with the weight gradients on the MAIN stream (UEM_SIDE_WGRAD=0 / UEM_BF16_SIDE_WGRAD=0): one kernel at a time, so the
 # per-kernel durations add up to the step and agree with the bench line's roofline (whose one profiled step is serial too).  A second
 # trace with the shipped default (weight gradients on a side stream) follows: its durations OVERLAP -- their sum exceeds the step.
-export UEM_SIDE_WGRAD=0 UEM_BF16_SIDE_WGRAD=0
+# (round 6: the step's two graphs run on two streams by default -- UEM_TWO_STREAM_FWD=0 keeps this trace and the counter passes serial)
+export UEM_SIDE_WGRAD=0 UEM_BF16_SIDE_WGRAD=0 UEM_TWO_STREAM_FWD=0
 echo "[measure] kernel trace (serial)"; timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o step -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err" || exit 1
 python3 scripts/kernel_stats.py "$(find "$OUT/trace" -name '*.db' | head -1)" > "$OUT/kernel_stats.csv"
 rm -rf "$OUT/trace"
-unset UEM_SIDE_WGRAD UEM_BF16_SIDE_WGRAD
-echo "[measure] kernel trace (side stream, overlapped)"; timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o step -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof_overlapped.json" 2> "$OUT/trace2.err" || exit 1
+unset UEM_SIDE_WGRAD UEM_BF16_SIDE_WGRAD UEM_TWO_STREAM_FWD
+echo "[measure] kernel trace (side stream + two graph streams, overlapped)"; timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o step -- python3 bench.py $ARGS > "$OUT/bench_under_rocprof_overlapped.json" 2> "$OUT/trace2.err" || exit 1
 python3 scripts/kernel_stats.py "$(find "$OUT/trace" -name '*.db' | head -1)" > "$OUT/kernel_stats_overlapped.csv"
+export UEM_TWO_STREAM_FWD=0
 echo "[measure] pmc FETCH_SIZE"; timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $ARGS --no-kernel-events > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || exit 1
 echo "[measure] pmc WRITE_SIZE"; timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $ARGS --no-kernel-events > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err" || exit 1
 if [ -z "$EXTRA" ]; then
