@@ -157,3 +157,47 @@ def test_gradients_of_a_forked_pair_equal_the_sequential_pair(storage, monkeypat
         for n, g in grads["seq"].items():
             d = float((grads[mode][n] - g).norm()) / max(float(g.norm()), 1e-20)
             assert d < (2e-2 if storage == "bf16" else 1e-4), (mode, n, d)
+
+
+@pytest.mark.parametrize("which", ["src_align_domain", "align"])
+def test_the_other_two_graph_steps_fork_and_match(which, monkeypatch):
+    """train_src.py --align-domain (source + target forward, CORAL between the features) and train_align_uem.py's step (source forward,
+    prototype update, target forward, PCL) take their two forwards through forward_pair too: two steps, the second forked, against the
+    sequential steps -- losses and weights to the order of step 1's fp32 atomics, BatchNorm counters equal"""
+    from oracle import synth
+    from uemda_amd.gast.alignment import Aligner
+    from uemda_amd.optim import FusedSGD
+    from uemda_amd.step import HYPER, StepState, align_step, src_step
+    batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=13).items()}
+    res = {}
+    for two in (False, True):
+        monkeypatch.setattr(ops, "TWO_STREAM_FWD", two)
+        model = _model("fp32")
+        with torch.no_grad():                     # confident heads, so that some on-the-fly pseudo labels survive (random heads: every
+            for head in (model.layer5, model.layer6):        # target label ignored, PCL = 0/0 = NaN, in the reference too)
+                for conv in head.conv2d_list:
+                    conv.bias[0] += 1.5
+        al = Aligner(None, 2048, C, -1, HYPER["proto_decay"])
+        al.prototypes = batch["prototypes"].clone()
+        opt, state = FusedSGD(model, lr=1e-2, momentum=0.9, weight_decay=5e-4), StepState(C)
+        outs = []
+        for _ in range(2):
+            if which == "align":
+                outs.append(align_step(model, al, opt, state, batch, 2e-3))
+            else:
+                outs.append(src_step(model, opt, state, batch, 2e-3, aligner=al, align_domain=True))
+        torch.cuda.synchronize()
+        assert (model._grad_arena2 is not None) == two
+        res[two] = (outs, model.flat_parameters()[0].clone(), _bn_state(model))
+    (o0, w0, b0), (o1, w1, b1) = res[False], res[True]
+    for k in o0[1]:
+        if k.startswith("loss"):
+            assert torch.isfinite(o0[1][k]).all(), k
+            assert abs(float(o0[1][k]) - float(o1[1][k])) <= 1e-4 * max(1.0, abs(float(o0[1][k]))), k
+    rel = float((w0 - w1).norm() / w0.norm())
+    assert rel < 5e-5, rel
+    for k in b0:
+        if "num_batches" in k:
+            assert torch.equal(b0[k], b1[k]), k
+        else:
+            torch.testing.assert_close(b0[k], b1[k], rtol=1e-3, atol=1e-4)

@@ -160,15 +160,19 @@ def src_step(model, optimizer, state, batch, lr, dp=None, aligner=None, align_do
     hp = state.hp
     model.train()
     optimizer.param_groups[0]["lr"] = lr
-    pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # train_src.py:116
+    if align_domain:
+        # :116 and :127 -- two train-mode forwards with nothing between them that the second one reads: the pair may fork (forward_pair)
+        (pred_s1, pred_s2, feat_s), (_p1, _p2, feat_t) = forward_pair(model, batch["images_s"], batch["images_t"])
+    else:
+        pred_s1, pred_s2, feat_s = model(batch["images_s"])                     # train_src.py:116
     loss_seg = loss_calc([pred_s1, pred_s2], batch["label_s"], loss_fn=state.loss_fn_s, multi=True)   # :132
     loss_domain = None
     if align_domain:
-        _p1, _p2, feat_t = model(batch["images_t"])                             # :127
         loss_domain = aligner.align_domain(feat_s, feat_t)                      # :134
     loss = loss_seg + loss_domain if align_domain else loss_seg
     optimizer.zero_grad()
     loss.backward()
+    _ops().grad_join()
     prescale = dp.reduce_gradients() if dp is not None else 1.0
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
     out = dict(loss_source=loss_seg.detach(), pred_s1=pred_s1.detach(), pred_s2=pred_s2.detach(),
@@ -189,9 +193,10 @@ def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_
         state.loss_fn_pcl = PrototypeContrastiveLoss(temperature=pcl_temp, ignore_label=hp["ignore_label"])
     model.train()
     optimizer.param_groups[0]["lr"] = lr
-    pred_s1, pred_s2, feat_s = model(batch["images_s"])                         # :147
+    # :147 and :156 as a pair that may fork (forward_pair): the prototype update between them (:150) reads the source features only and
+    # nothing of it enters the target forward
+    (pred_s1, pred_s2, feat_s), (pred_t1, pred_t2, feat_t) = forward_pair(model, batch["images_s"], batch["images_t"])
     label_s_down = aligner.update_prototype(feat_s, batch["label_s"])           # :150
-    pred_t1, pred_t2, feat_t = model(batch["images_t"])                         # :156
     # on-the-fly soft labels (:158-160): (softmax(up(x1)) + softmax(up(x2))) / 2, the eval-output kernel
     x1, x2 = ops.as_nhwc(pred_t1.detach()).contiguous(), ops.as_nhwc(pred_t2.detach()).contiguous()
     n, h, w, c = x1.shape
@@ -209,6 +214,7 @@ def align_step(model, aligner, optimizer, state, batch, lr, dp=None, sup_ignore_
     loss = loss_seg + loss_domain + loss_align
     optimizer.zero_grad()
     loss.backward()
+    ops.grad_join()
     prescale = dp.reduce_gradients() if dp is not None else 1.0
     optimizer.step(max_norm=hp["max_norm"], grad_prescale=prescale)
     aligner.check_superpixel_ids(wait=False)
