@@ -187,6 +187,11 @@ class Deeplabv2(nn.Module):
             self._nbt_skip = True
             try:
                 yield
+            except BaseException:
+                if self._rs_shadow.is_cuda:      # a forward that raised half way: its partial contribution must not reach the statistics
+                    torch.cuda.synchronize()     # (error path: simply let whatever stream it ran on finish first)
+                self._rs_shadow.zero_()
+                raise
             finally:
                 self._nbt_skip = False
                 for bn, name, off, c in self._rs_views:

@@ -351,8 +351,8 @@ def on_backward_stream(fn):
         if main is None:
             return fn(ctx, *grads)
         cur = torch.cuda.current_stream()
-        if cur == main:
-            return fn(ctx, *grads)
+        if cur == main or cur != _FWD2.get(torch.cuda.current_device()):
+            return fn(ctx, *grads)          # only a node the engine put on the SECOND stream moves (never e.g. a capturing stream)
         main.wait_stream(cur)
         with torch.cuda.stream(main):
             out = fn(ctx, *grads)
