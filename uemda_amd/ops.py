@@ -183,11 +183,20 @@ SIDE_WGRAD_F32 = os.environ.get("UEM_SIDE_WGRAD", "1") != "0"
 SIDE_HOLD = os.environ.get("UEM_SIDE_HOLD", "1") != "0"       # 0: record_stream instead of holding references until the join (rounds 5 / early 6)
 
 
+# Stream priorities (0 = default, -1 = high).  The second graph's stream runs at HIGH priority: its chain is queued behind the first
+# graph's by the host and trails it on the device, and whatever of it is left when the first chain has finished runs alone -- with
+# priority it catches up and the two chains end together (same-box A/B, profiles/r06_l_two_streams.txt: bf16 36.5-36.7 -> 35.7-35.8 ms,
+# fp32 98.7-99.9 -> 98.5-98.6).  A high-priority SIDE stream loses (fp32 100.0, bf16 36.8: weight gradients in front of the chain
+# that produces their inputs).
+SIDE_PRIORITY = int(os.environ.get("UEM_SIDE_PRIORITY", "0"))
+SECOND_PRIORITY = int(os.environ.get("UEM_SECOND_PRIORITY", "-1"))
+
+
 class _Side:
     by_device = {}
 
     def __init__(self):
-        self.stream = torch.cuda.Stream()
+        self.stream = torch.cuda.Stream(priority=SIDE_PRIORITY)
         self.task = None                 # id of the backward graph task whose end-of-backward callback will join (None: no join queued)
         self.dirty = False               # work was queued since the last join
         self.reads = []                  # (first byte, past-the-end byte, label) of what the queued launches read, since the last join
@@ -321,7 +330,7 @@ def second_stream():
     dev = torch.cuda.current_device()
     st = _FWD2.get(dev)
     if st is None:
-        st = _FWD2[dev] = torch.cuda.Stream()
+        st = _FWD2[dev] = torch.cuda.Stream(priority=SECOND_PRIORITY)
     return st
 
 
