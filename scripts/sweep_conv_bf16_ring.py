@@ -47,13 +47,14 @@ def main():
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     lib = _lib.load()
     what = os.environ.get("SWEEP", "split")                  # ring: the three-stage ring with the classic epilogue; split: + loader / storer waves
-    for f in ("uemdbg_conv_bf16_ring", "uemdbg_conv_bf16_pw", "uemdbg_conv_bf16_big"):
+    for f in ("uemdbg_conv_bf16_ring", "uemdbg_conv_bf16_pw", "uemdbg_conv_bf16_big", "uemdbg_conv_bf16_areg"):
         getattr(lib, f).argtypes = [ctypes.c_int]
         getattr(lib, f).restype = None
 
     def switch(on):
         lib.uemdbg_conv_bf16_ring({"ring": 1, "split": 2}.get(what, 0) if on else 0)
         lib.uemdbg_conv_bf16_pw(1 if (on and what == "pw") else 0)
+        lib.uemdbg_conv_bf16_areg((1 if on else 0) if what == "areg" else 0)      # the A-stationary pointwise block forced on / off
         if what == "big":                                    # 256-row two-stage tiles (256 x 256 where the columns allow) forced on / rule
             lib.uemdbg_conv_bf16_pw(0)
             lib.uemdbg_conv_bf16_big(1 if on else -1)
@@ -106,6 +107,7 @@ def main():
         lib.uemdbg_conv_bf16_ring(-1)
         lib.uemdbg_conv_bf16_pw(-1)
         lib.uemdbg_conv_bf16_big(-1)
+        lib.uemdbg_conv_bf16_areg(-1)
         mo = y.numel() // cout
         t256 = (mo // 256) * max(1, cout // 128) if mo % 256 == 0 else 0
         print(f"{name:22s} {M:8d} {t256:6d} | " + " | ".join(cells), flush=True)

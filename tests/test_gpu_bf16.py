@@ -824,3 +824,42 @@ def test_pointwise_stream_kernel_equals_the_dispatched_kernel(cin, cout, hw, sta
     else:
         assert torch.equal(out, ref)
     assert torch.equal(out_d, ref_d)
+
+
+@pytest.mark.parametrize("cin,cout,n,hw,stats", [(256, 1024, 8, 32, True), (128, 512, 8, 64, True), (64, 256, 2, 128, True), (256, 1024, 2, 32, False),
+                                                  (256, 64, 8, 32, True), (128, 1024, 10, 64, False)])
+def test_a_stationary_pointwise_kernel_equals_the_dispatched_kernel(cin, cout, n, hw, stats):
+    """Round 6, late: pw_bf16_areg_kernel (a block of eight waves owns 512 rows and all columns: A once into registers, B as whole 64-column
+    tiles through a double buffer, wave-private output staging).  Forced on wherever it is legal (K in 64 / 128 / 256, M a multiple of 512 --
+    the last two cases have several panels per block's stride or a narrow output), it must equal the dispatched kernel bit for bit (same
+    accumulation order over k), forward with and without the BatchNorm tile statistics and as the plain data gradient of the mirrored
+    shape; the statistics to their summation order."""
+    import ctypes
+    from uemda_amd import _lib, ops_bf16
+    lib = _lib.load()
+    lib.uemdbg_conv_bf16_areg.argtypes = [ctypes.c_int]
+    lib.uemdbg_conv_bf16_areg.restype = None
+    g = torch.Generator().manual_seed(cin + cout + n)
+    x = torch.randn(n, hw, hw, cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) * 0.05).cuda().bfloat16()
+    # the data gradient with the same reduction length: dy has `cin` channels, dx `cout`
+    w2 = (torch.randn(cin, 1, 1, cout, generator=g) * 0.05).cuda().bfloat16()
+    dy = torch.randn(n, hw, hw, cin, generator=g).cuda().bfloat16()
+    wt2 = w2.permute(3, 1, 2, 0).contiguous()
+    xs = (n, hw, hw, cout)
+    try:
+        lib.uemdbg_conv_bf16_areg(0)
+        ref = ops_bf16.conv2d(x, w, want_stats=stats)
+        ref_d = ops_bf16.conv2d_dgrad(dy, wt2, xs)
+        lib.uemdbg_conv_bf16_areg(1)
+        out = ops_bf16.conv2d(x, w, want_stats=stats)
+        out_d = ops_bf16.conv2d_dgrad(dy, wt2, xs)
+    finally:
+        lib.uemdbg_conv_bf16_areg(-1)
+    torch.cuda.synchronize()
+    if stats:
+        assert torch.equal(out[0], ref[0])
+        torch.testing.assert_close(out[1], ref[1], rtol=2e-5, atol=2e-3)
+    else:
+        assert torch.equal(out, ref)
+    assert torch.equal(out_d, ref_d)

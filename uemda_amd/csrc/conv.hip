@@ -2552,6 +2552,200 @@ static bool conv_bf16_pw_try(const ConvP& p, unsigned xb, unsigned wb, hipStream
     }
     return true;
 }
+// =========================================================================================================
+// A-STATIONARY pointwise bf16 block (round 6, late): pointwise layers with a SHORT reduction and MANY output columns -- conv3 of a
+// bottleneck forward (C -> 4C) and the plain data gradient of the same shape.  The six block structures above all fetch, per 256 x 128
+// output tile, a 256 x K slab of A and a 128 x K slab of B from L2: (A + B) bytes per flop is what bounds these layers (DESIGN 3.3,
+// round 6), and no pipeline inside the block changes it.  Here a block of eight waves owns 512 ROWS and ALL columns:
+//   * each wave loads its 64 x K rows of A ONCE, straight into registers in the MFMA operand layout (K = 256: 128 VGPRs), and keeps
+//     them for the N / 64 column tiles of the panel;
+//   * B travels as whole 64-column tiles (64 x K bf16 = 32 KB at K = 256), double-buffered, by LDS-DMA, every wave issuing its share
+//     and waiting for it by count (the stores of the previous tile are younger than the pieces it waits for); ONE barrier per tile;
+//   * a wave's 64 x 64 results go through a wave-private 8 KB staging area (no block barrier) and leave as 16-byte row segments;
+//   * BatchNorm tile statistics (sums of the rounded values per 128 rows): per-wave column sums, paired through a small scratch
+//     behind the next tile's barrier.
+// Operand bytes per 512 x N panel: 512 K (A) + N K (B) against 4 (N / 128) (256 K + 128 K) for the 256 x 128 tiles: 3-4x fewer.
+// Same accumulation order over k as conv_bf16_kernel: outputs bit-equal; the statistics' summation order differs (fp32, 1e-6).
+// =========================================================================================================
+template <int KC, bool STATS>
+__global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const int npanels) {
+    constexpr int QN = 64, NKS = KC / 32, B_ELEMS = QN * KC, NPW = (NKS * 4) / 8, NSTR = 8;
+    static_assert(NPW >= 1, "at least one DMA piece per wave and B tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const ob = lds16 + 2 * B_ELEMS;                                       // [8 waves][64][64] bf16
+    float* const sc = reinterpret_cast<float*>(ob + 8 * 4096);                            // [2][8 waves][2][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5, lrow = lane >> 2;
+    const int nt = p.N / QN;
+    const i32x4 rs_b = conv_rsrc(p.B, p.b_bytes);
+    unsigned short* const ow = ob + wave * 4096;
+    // ---- B tile `t` into stage `st`: this wave's NPW pieces (16 columns x 32 channels each)
+    auto issue_b = [&](int t, int st) {
+#pragma unroll
+        for (int u = 0; u < NPW; ++u) {
+            const int q = wave * NPW + u, ksl = q >> 2, c = (q & 3) * 16 + lrow;
+            const unsigned off = ((unsigned)(t * QN + c) * (unsigned)KC + (unsigned)(ksl * 32 + (((lane & 3) ^ ((c >> 2) & 3)) * 8))) * 2u;
+            uem_raw_buffer_load_lds(rs_b, (lds_u32p)(lds16 + st * B_ELEMS + ksl * 2048 + (q & 3) * 512), 16, (int)off, 0, 0, 0);
+        }
+    };
+    auto write_stats = [&](int buf, int m0, int n0) {                                      // 4 entries of 128 rows x 64 columns, by threads 0..255
+        if (tid < 256) {
+            const int e = tid >> 6, col = tid & 63;
+            // waves 2e and 2e + 1 hold the two 64-row halves of entry e: [wave][sum | sum of squares][64 columns]; hand-written reads (the
+            // compiler would put an LDS read behind every DMA piece and store in flight)
+            const unsigned l0 = (unsigned)(unsigned long long)(lds_u32p)(sc + ((buf * 8 + 2 * e) * 2) * 64 + col);
+            float a0, b0, a1, b1;
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1) : "v"(l0) : "memory");
+            const size_t tiles_m = (size_t)(p.M / 128);
+            p.tile_stats[((size_t)0 * p.N + n0 + col) * tiles_m + (size_t)(m0 / 128 + e)] = a0 + a1;
+            p.tile_stats[((size_t)1 * p.N + n0 + col) * tiles_m + (size_t)(m0 / 128 + e)] = b0 + b1;
+        }
+    };
+    int it = 0, pm0 = 0, pn0 = 0;
+    bool have_prev = false;
+    if (blockIdx.x < npanels) issue_b(0, 0);
+    for (int vi = blockIdx.x; vi < npanels; vi += gridDim.x) {
+        const int m0 = vi * 512, wr0 = m0 + wave * 64;
+        bf16x8 a[2][KC / 16];
+        bool a_loaded = false;
+        for (int t = 0; t < nt; ++t, ++it) {
+            const int st = it & 1;
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTR) : "memory");   // this tile's pieces are older than the last tile's stores
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (STATS) {
+                if (have_prev) write_stats((it - 1) & 1, pm0, pn0);
+            }
+            {                                                                             // the next tile of this block, if any, into the other stage
+                const bool more_t = t + 1 < nt;
+                if (more_t || vi + (int)gridDim.x < npanels) issue_b(more_t ? t + 1 : 0, st ^ 1);
+            }
+            if (!a_loaded) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ss = 0; ss < KC / 16; ++ss)
+                        a[i][ss] = *reinterpret_cast<const bf16x8*>(p.A + (size_t)(wr0 + i * 32 + fr) * p.lda + ss * 16 + fh * 8);
+                a_loaded = true;
+            }
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            const unsigned short* __restrict__ const Bs = lds16 + st * B_ELEMS;
+#pragma unroll
+            for (int ss = 0; ss < KC / 16; ++ss) {
+                bf16x8 b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = j * 32 + fr;
+                    b[j] = *reinterpret_cast<const bf16x8*>(&Bs[(ss >> 1) * 2048 + c * 32 + ((((ss & 1) * 2 + fh) ^ ((c >> 2) & 3)) * 8)]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][ss], b[j], acc[i][j], 0, 0, 0);
+            }
+            const int n0 = t * QN;
+            if constexpr (STATS) {
+                float* const sw = sc + ((st * 8 + wave) * 2) * 64;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { const float vr = bf2f(f2bf(acc[i][j][r])); s1 += vr; s2 = fmaf(vr, vr, s2); }
+                    s1 += __shfl_xor(s1, 32);
+                    s2 += __shfl_xor(s2, 32);
+                    if (fh == 0) { sw[j * 32 + fr] = s1; sw[64 + j * 32 + fr] = s2; }
+                }
+            }
+            // ---- the wave's 64 x 64 results: bf16 into its private staging area, back as 16-byte row segments, out
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ow[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 64 + j * 32 + fr] = f2bf(acc[i][j][r]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                f32x4v v[NSTR];
+#pragma unroll
+                for (int u = 0; u < NSTR; ++u) {
+                    const unsigned la = (unsigned)(unsigned long long)(lds_u32p)(ow + (u * 8 + (lane >> 3)) * 64 + (lane & 7) * 8);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(la));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NSTR; ++u)
+                    *reinterpret_cast<f32x4v*>(p.C + (size_t)(wr0 + u * 8 + (lane >> 3)) * p.ldc + n0 + (lane & 7) * 8) = v[u];
+            }
+            pm0 = m0; pn0 = n0; have_prev = true;
+        }
+    }
+    if constexpr (STATS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (have_prev) write_stats((it - 1) & 1, pm0, pn0);
+    }
+}
+// -1 = rule, 0 = never, 1 = wherever legal
+static int g_bf16_areg = -1;
+extern "C" void uemdbg_conv_bf16_areg(int v) { g_bf16_areg = v; }
+template <int KC>
+static bool pw_areg_go(const PwP& q, int npanels, hipStream_t st) {
+    constexpr int LDS = 2 * 64 * KC * 2 + 8 * 4096 * 2 + 2 * 8 * 2 * 64 * 4;
+    const int grid = npanels > 256 ? 256 : npanels;
+    if (q.tile_stats != nullptr) {
+        auto k = pw_bf16_areg_kernel<KC, true>;
+        if (!uem_allow_lds((const void*)k, LDS)) return false;
+        k<<<grid, 512, LDS, st>>>(q, npanels);
+    } else {
+        auto k = pw_bf16_areg_kernel<KC, false>;
+        if (!uem_allow_lds((const void*)k, LDS)) return false;
+        k<<<grid, 512, LDS, st>>>(q, npanels);
+    }
+    return true;
+}
+template <int MODE>
+static bool conv_bf16_areg_try(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
+    static const int env = getenv("UEM_CONV_BF16_AREG") ? atoi(getenv("UEM_CONV_BF16_AREG")) : -1;
+    const int set = g_bf16_areg >= 0 ? g_bf16_areg : env;
+    const bool pointwise = p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
+    if (set == 0 || !pointwise || p.M % 512 != 0 || p.Cout % 64 != 0 || p.accumulate) return false;
+    if (p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
+    if (MODE == 1 && (p.acc_src || p.tile_bnbwd)) return false;
+    if (p.x_ld % 8 != 0 || p.y_ld % 8 != 0 || (((uintptr_t)p.x | (uintptr_t)p.y) & 15) != 0) return false;
+    if ((double)p.M * p.y_ld * 2.0 >= 4294967280.0 * 4.0) return false;
+    const int npanels = p.M / 512;
+    // Rule (scripts/sweep_conv_bf16_ring.py SWEEP=areg, profiles/r06_m_conv_bf16_areg_sweep_*.txt; forced on = wherever legal): a reduction
+    // of 128 or 256 channels, at least twice as many output columns, and a panel for every CU.  There it is 10-30 % faster than the tiled
+    // kernels (256 -> 1024 on 1024 x 1024 tiles: 0.144 -> 0.101 ms; 128 -> 512: -10 % / -27 % at 1024 / 512; plain data gradients of those
+    // shapes -12 ... -34 %).  It loses with 64 channels (+24 %: the A registers buy nothing, the 64-column tiles cost), with no more
+    // columns than channels (256 -> 64 / 128: +27 %) and with fewer panels than CUs (256 -> 1024 at 512 x 512: 64 panels, +140 %).
+    if (set != 1 && !(set < 0 && npanels >= 256 && p.Cout >= 2 * p.Cin && p.Cin >= 128)) return false;
+    PwP q;
+    q.A = reinterpret_cast<const unsigned short*>(p.x); q.B = reinterpret_cast<const unsigned short*>(p.w);
+    q.C = reinterpret_cast<unsigned short*>(p.y); q.tile_stats = MODE == 0 ? p.tile_stats : nullptr;
+    q.M = p.M; q.N = p.Cout; q.K = p.Cin; q.lda = p.x_ld; q.ldc = p.y_ld; q.a_bytes = xb; q.b_bytes = wb;
+    switch (p.Cin) {
+        case 64: return pw_areg_go<64>(q, npanels, st);
+        case 128: return pw_areg_go<128>(q, npanels, st);
+        default: return pw_areg_go<256>(q, npanels, st);
+    }
+}
 // Ring of three operand stages on persistent 256-row blocks (conv_bf16_kernel<..., NST = 3>): full dense tiles, forward (plain / with the
 // BatchNorm tile statistics) and data gradient (plain / residual tail / BatchNorm-backward partial sums).  -1 = rule, 0 = never,
 // 1 = wherever legal (tests, sweeps).
@@ -2719,6 +2913,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
         p.x_ld = s->x_ld; p.y_ld = s->y_ld; p.M = s->N * s->Ho * s->Wo;
         const double xb = (double)p.N * p.H * p.W * p.x_ld * 2.0, wb = (double)p.Cout * p.KH * p.KW * p.Cin * 2.0;
         if (xb >= 4294967280.0 || wb >= 4294967280.0) return uem_fail(UEM_ERR_UNSUPPORTED, "conv2d_bf16: tensor beyond 32-bit buffer offsets");
+        if (conv_bf16_areg_try<0>(p, (unsigned)xb, (unsigned)wb, st)) return uem_check_launch("conv2d_bf16 (A-stationary pointwise)");
         if (conv_bf16_pw_try<0>(p, (unsigned)xb, (unsigned)wb, st)) return uem_check_launch("conv2d_bf16 (pointwise stream)");
         const int ring = conv_bf16_ring_bn<0>(p);
         const int big = ring ? 0 : conv_bf16_big_bn<0>(p);
@@ -2763,6 +2958,7 @@ static int conv2d_bf16_impl(const uint16_t* x, const uint16_t* w, uint16_t* y, c
             static const int wt_env = getenv("UEM_BF16_WIDE_TAIL") ? atoi(getenv("UEM_BF16_WIDE_TAIL")) : 0;
             const bool wide_tail = wt_env != 0 && (p.accumulate != 0 || p.tile_bnbwd != nullptr) && 2 * p.ntaps * p.Cin <= p.Cout &&
                                    (wt_env != 2 || p.Cin <= 256);
+            if (!wide_tail && conv_bf16_areg_try<1>(p, (unsigned)xb, (unsigned)wb, st)) continue;
             if (!wide_tail && conv_bf16_pw_try<1>(p, (unsigned)xb, (unsigned)wb, st)) continue;
             const int ring = wide_tail ? 0 : conv_bf16_ring_bn<1>(p);
             const int big = (wide_tail || ring) ? 0 : conv_bf16_big_bn<1>(p);
