@@ -21,7 +21,7 @@ CASES = [
 ]
 
 
-@pytest.fixture(params=["rule", "persistent", "big", "big-persistent"])
+@pytest.fixture(params=["rule", "persistent", "big", "big-persistent", "areg"])
 def persist(request):
     """the conv kernel's persistent-block form by its dispatch rule (>= 1024 full tiles), and forced onto every full-tile launch;
     "big": the 256-row tiles (eight waves, round 5) forced onto every launch whose row count is a multiple of 256 -- by rule only
@@ -30,9 +30,14 @@ def persist(request):
     lib = _lib.load()
     lib.uemdbg_conv_bf16_persist(1 if request.param.endswith("persistent") else -1)
     lib.uemdbg_conv_bf16_big(1 if request.param.startswith("big") else -1)
+    import ctypes
+    lib.uemdbg_conv_bf16_areg.argtypes = [ctypes.c_int]
+    lib.uemdbg_conv_bf16_areg.restype = None
+    lib.uemdbg_conv_bf16_areg(1 if request.param == "areg" else -1)      # "areg": the A-stationary pointwise block wherever it is legal
     yield request.param
     lib.uemdbg_conv_bf16_persist(-1)
     lib.uemdbg_conv_bf16_big(-1)
+    lib.uemdbg_conv_bf16_areg(-1)
 
 
 def _bf(t):
@@ -126,6 +131,10 @@ TAIL_CASES = [
     (4, 8, 8, 512, 128, 1, 1, "accumulate", "bits"),   # after a stride-1 downsample's data gradient
     (1, 16, 24, 64, 64, 3, 1, "none", "z"),            # 64-wide column tiles
     (8, 64, 64, 256, 64, 1, 1, "bits", "bits"),        # layer1's residual tail at 1024 tiles: persistent blocks by rule
+    (2, 16, 16, 512, 128, 1, 1, "bits", "bits"),       # layer2's / layer3's tails: 128 / 256 reduction channels (the A-stationary block's
+    (4, 16, 16, 1024, 256, 1, 1, "bits", "bits"),      # tail forms when it is forced on: one panel, two panels)
+    (2, 16, 16, 512, 128, 1, 1, "bits", "none"),
+    (2, 16, 16, 1024, 256, 1, 1, "none", "bits"),
 ]
 
 

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void conv_fwd_kernel(const 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned int* lds_u32p;
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 extern "C" __device__ void uem_raw_buffer_load_lds(i32x4 rsrc, lds_u32p lds, int size, int voffset, int soffset, int offset,
                                                    int aux) __asm("llvm.amdgcn.raw.buffer.load.lds");
 #define CONV_OOB 0xFFFFFFF0u
@@ -2326,9 +2327,11 @@ static void conv_bf16_launch(const ConvP& p, unsigned xb, unsigned wb, hipStream
 // =========================================================================================================
 struct PwP {
     const unsigned short* A; const unsigned short* B; unsigned short* C;
-    float* tile_stats;                    // [2][N][M / 128] or null
+    float* tile_stats;                    // [2][N][M / 128] or null (forward: BatchNorm statistics; tail: the BatchNorm-backward partial sums)
     int M, N, K, lda, ldc;
     unsigned a_bytes, b_bytes;
+    // fused data-gradient tail (pw_bf16_areg_kernel<..., TAIL>): the tensor accumulated into + its gate bits, the BatchNorm input + its mask bits
+    const unsigned short* acc; const unsigned* acc_bits; const unsigned short* bn_z; const float* bn_vec; const unsigned* bn_bits;
 };
 template <bool STATS>
 __global__ __launch_bounds__(512, 1) void pw_bf16_stream_kernel(const PwP p, const int ntiles) {
@@ -2567,20 +2570,43 @@ static bool conv_bf16_pw_try(const ConvP& p, unsigned xb, unsigned wb, hipStream
 // Operand bytes per 512 x N panel: 512 K (A) + N K (B) against 4 (N / 128) (256 K + 128 K) for the 256 x 128 tiles: 3-4x fewer.
 // Same accumulation order over k as conv_bf16_kernel: outputs bit-equal; the statistics' summation order differs (fp32, 1e-6).
 // =========================================================================================================
-template <int KC, bool STATS>
-__global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const int npanels) {
+// TAIL (the fused data gradient of conv1 taken backwards: K = C, N = 4C): 0 none; bit 0: dx += gate(acc) -- the identity gradient through the
+// packed ReLU mask (or the tensor itself where no mask is given); bit 1: the BatchNorm-backward partial sums of the layer dx feeds, over the
+// ROUNDED dx, its mask from packed bits.  The wave's results are then staged in fp32, 32 rows at a time, and every 16-byte row segment is
+// combined with the 16-byte segments of acc / z it needs -- each pass's loads issued one pass ahead of its arithmetic and stores, so that no
+// wait for a load ever implies a wait for a store.  dx is bit-equal to conv_bf16_kernel's, the partial sums equal to their summation order.
+template <int KC, bool STATS, int TAIL = 0>
+__global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const int npanels, const int ngroups) {
     constexpr int QN = 64, NKS = KC / 32, B_ELEMS = QN * KC, NPW = (NKS * 4) / 8, NSTR = 8;
+    constexpr bool T_ACC = (TAIL & 1) != 0, T_BN = (TAIL & 2) != 0, SUMS = STATS || T_BN;
+    constexpr int SLD = 68;                                                               // floats per staged row (tail)
     static_assert(NPW >= 1, "at least one DMA piece per wave and B tile");
+    static_assert(!(STATS && TAIL), "forward statistics or a data-gradient tail");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* const lds16 = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* const ob = lds16 + 2 * B_ELEMS;                                       // [8 waves][64][64] bf16
-    float* const sc = reinterpret_cast<float*>(ob + 8 * 4096);                            // [2][8 waves][2][64]
+    unsigned short* const ob = lds16 + 2 * B_ELEMS;                                       // [8 waves][64][64] bf16 | tail: [8 waves][32][SLD] fp32
+    float* const sc = reinterpret_cast<float*>(ob + (TAIL ? 8 * 32 * SLD * 2 : 8 * 4096)); // [2][8 waves][2][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5, lrow = lane >> 2;
     const int nt = p.N / QN;
     const i32x4 rs_b = conv_rsrc(p.B, p.b_bytes);
     unsigned short* const ow = ob + wave * 4096;
+    // tail: buffer resources of the epilogue's streams, and the table [2][N] of the BatchNorm's mean / inverse deviation in LDS
+    float* const vt = sc + 2 * 8 * 2 * 64;
+    const bool has_ab = T_ACC && p.acc_bits != nullptr;
+    __amdgpu_buffer_rsrc_t rs_acc, rs_ab, rs_z, rs_zb, rs_c;
+    if constexpr (TAIL != 0) {
+        const unsigned cbytes = (unsigned)(((size_t)p.M - 1) * p.ldc * 2 + (size_t)p.N * 2), zbytes = (unsigned)((size_t)p.M * p.N * 2), bbytes = (unsigned)((size_t)p.M * p.N / 8);
+        rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, cbytes, 0x00020000);
+        rs_acc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(T_ACC ? p.acc : p.C), 0, cbytes, 0x00020000);
+        rs_ab = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(has_ab ? p.acc_bits : reinterpret_cast<const unsigned*>(p.C)), 0, has_ab ? bbytes : 0u, 0x00020000);
+        rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(T_BN ? p.bn_z : p.C), 0, T_BN ? zbytes : 0u, 0x00020000);
+        rs_zb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(T_BN ? p.bn_bits : reinterpret_cast<const unsigned*>(p.C)), 0, T_BN ? bbytes : 0u, 0x00020000);
+        if constexpr (T_BN) {
+            for (int i = tid; i < 2 * p.N; i += 512) vt[i] = p.bn_vec[2 * p.N + i];        // rows 2 (mean) and 3 (inverse deviation) of bn_vec [4][N]
+        }
+    }
     // ---- B tile `t` into stage `st`: this wave's NPW pieces (16 columns x 32 channels each)
     auto issue_b = [&](int t, int st) {
 #pragma unroll
@@ -2604,25 +2630,29 @@ __global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const
             p.tile_stats[((size_t)1 * p.N + n0 + col) * tiles_m + (size_t)(m0 / 128 + e)] = b0 + b1;
         }
     };
+    // Work items: (row panel, column group).  With fewer panels than CUs the N / 64 column tiles of a panel are shared out over `ngroups`
+    // blocks (each loads the panel's A rows itself: A traffic x ngroups, still one pass over B per block); ngroups = 1 otherwise.
+    const int nitems = npanels * ngroups, ntg = nt / ngroups;
     int it = 0, pm0 = 0, pn0 = 0;
     bool have_prev = false;
-    if (blockIdx.x < npanels) issue_b(0, 0);
-    for (int vi = blockIdx.x; vi < npanels; vi += gridDim.x) {
-        const int m0 = vi * 512, wr0 = m0 + wave * 64;
+    if ((int)blockIdx.x < nitems) issue_b(((int)blockIdx.x % ngroups) * ntg, 0);
+    for (int vi = blockIdx.x; vi < nitems; vi += gridDim.x) {
+        const int m0 = (vi / ngroups) * 512, wr0 = m0 + wave * 64, t_lo = (vi % ngroups) * ntg, t_hi = t_lo + ntg;
         bf16x8 a[2][KC / 16];
         bool a_loaded = false;
-        for (int t = 0; t < nt; ++t, ++it) {
+        for (int t = t_lo; t < t_hi; ++t, ++it) {
             const int st = it & 1;
             if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTR) : "memory");   // this tile's pieces are older than the last tile's stores
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if constexpr (STATS) {
+            if constexpr (SUMS) {
                 if (have_prev) write_stats((it - 1) & 1, pm0, pn0);
             }
             {                                                                             // the next tile of this block, if any, into the other stage
-                const bool more_t = t + 1 < nt;
-                if (more_t || vi + (int)gridDim.x < npanels) issue_b(more_t ? t + 1 : 0, st ^ 1);
+                const bool more_t = t + 1 < t_hi;
+                const int vn = vi + (int)gridDim.x;
+                if (more_t || vn < nitems) issue_b(more_t ? t + 1 : (vn % ngroups) * ntg, st ^ 1);
             }
             if (!a_loaded) {
 #pragma unroll
@@ -2668,6 +2698,108 @@ __global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const
                     if (fh == 0) { sw[j * 32 + fr] = s1; sw[64 + j * 32 + fr] = s2; }
                 }
             }
+            if constexpr (TAIL != 0) {
+                // per lane: a 16-byte segment (8 columns c8..c8+7) of row prow of each 8-row pass; everything else about an address is
+                // uniform and travels as the buffer instructions' scalar offset
+                float* const sg = reinterpret_cast<float*>(ob) + wave * (32 * SLD);
+                const int prow = lane >> 3, c8 = (lane & 7) * 8;
+                const unsigned v_row = ((unsigned)prow * (unsigned)p.ldc + (unsigned)c8) * 2u;                 // acc / dx
+                const unsigned v_z = ((unsigned)prow * (unsigned)p.N + (unsigned)c8) * 2u;                     // bn_z (dense rows)
+                const unsigned v_bit = (((unsigned)prow * (unsigned)p.N) >> 5) * 4u + (unsigned)(c8 >> 5) * 4u; // the 32-bit word of the lane's 8 bits
+                const unsigned bshift = (unsigned)(c8 & 31);
+                float pb[8], pg[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = pg[e] = 0.f;
+                u32x4v eo[2], ez[2];
+                unsigned eaw[2], ebw[2];
+                auto fetch = [&](const int k) {                                            // pass k = (half k >> 2, rows (k & 3) * 8 + prow of it)
+                    const unsigned mrow = (unsigned)(wr0 + (k >> 2) * 32 + (k & 3) * 8);   // uniform
+                    if constexpr (T_ACC) {
+                        eo[k & 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, v_row, (mrow * (unsigned)p.ldc + (unsigned)n0) * 2u, 0);
+                        eaw[k & 1] = has_ab ? __builtin_amdgcn_raw_buffer_load_b32(rs_ab, v_bit, ((mrow * (unsigned)p.N + (unsigned)n0) >> 5) * 4u, 0) : 0xffffffffu;
+                    }
+                    if constexpr (T_BN) {
+                        ez[k & 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, v_z, (mrow * (unsigned)p.N + (unsigned)n0) * 2u, 0);
+                        ebw[k & 1] = __builtin_amdgcn_raw_buffer_load_b32(rs_zb, v_bit, ((mrow * (unsigned)p.N + (unsigned)n0) >> 5) * 4u, 0);
+                    }
+                };
+                fetch(0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((k & 3) == 0) {                                                    // the half's 32 rows into the staging area
+                        const int i = k >> 2;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the previous half's reads are done
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sg[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + fr] = acc[i][j][r];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (k + 1 < 8) fetch(k + 1);
+                    const int row = (k & 3) * 8 + prow;
+                    const unsigned mrow = (unsigned)(wr0 + (k >> 2) * 32 + (k & 3) * 8);
+                    f32x4v lo, hi;
+                    {
+                        const unsigned la = (unsigned)(unsigned long long)(lds_u32p)(sg + row * SLD + c8);
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(la) : "memory");
+                    }
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                    if constexpr (T_ACC) {
+                        const unsigned abyte = (eaw[k & 1] >> bshift) & 0xffu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned w = eo[k & 1][e];
+                            const float flo = __uint_as_float(w << 16), fhi = __uint_as_float(w & 0xffff0000u);
+                            v[2 * e] += ((abyte >> (2 * e)) & 1u) ? flo : 0.f;
+                            v[2 * e + 1] += ((abyte >> (2 * e + 1)) & 1u) ? fhi : 0.f;
+                        }
+                    }
+                    u32x4v pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned l16 = f2bf(v[2 * e]), h16 = f2bf(v[2 * e + 1]);
+                        pk[e] = l16 | (h16 << 16);
+                        v[2 * e] = bf2f((unsigned short)l16); v[2 * e + 1] = bf2f((unsigned short)h16);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_c, v_row, (mrow * (unsigned)p.ldc + (unsigned)n0) * 2u, 0);
+                    if constexpr (T_BN) {
+                        const unsigned bbyte = (ebw[k & 1] >> bshift) & 0xffu;
+                        // the lane's columns' mean / inverse deviation from the table every block loaded at its start
+                        f32x4v mu0, mu1, is0, is1;
+                        {
+                            const unsigned lm = (unsigned)(unsigned long long)(lds_u32p)(vt + n0 + c8);
+                            const unsigned li = (unsigned)(unsigned long long)(lds_u32p)(vt + p.N + n0 + c8);
+                            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(mu0), "=&v"(mu1), "=&v"(is0), "=&v"(is1) : "v"(lm), "v"(li) : "memory");
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned w = ez[k & 1][e >> 1];
+                            const float z = (e & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+                            const float mu = e < 4 ? mu0[e] : mu1[e - 4], is = e < 4 ? is0[e] : is1[e - 4];
+                            const float dp = ((bbyte >> e) & 1u) ? v[e] : 0.f;
+                            pb[e] += dp;
+                            pg[e] = fmaf(dp, (z - mu) * is, pg[e]);
+                        }
+                    }
+                }
+                if constexpr (T_BN) {                                                      // the eight row-lanes of a column group -> the wave's 64-row sums
+                    float* const sw = sc + ((st * 8 + wave) * 2) * 64;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float a = pb[e], b = pg[e];
+                        a += __shfl_xor(a, 8);  b += __shfl_xor(b, 8);
+                        a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                        if (prow == 0) { sw[c8 + e] = a; sw[64 + c8 + e] = b; }
+                    }
+                }
+                pm0 = m0; pn0 = n0; have_prev = true;
+                continue;
+            }
             // ---- the wave's 64 x 64 results: bf16 into its private staging area, back as 16-byte row segments, out
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -2694,7 +2826,7 @@ __global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const
             pm0 = m0; pn0 = n0; have_prev = true;
         }
     }
-    if constexpr (STATS) {
+    if constexpr (SUMS) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -2704,31 +2836,55 @@ __global__ __launch_bounds__(512, 1) void pw_bf16_areg_kernel(const PwP p, const
 // -1 = rule, 0 = never, 1 = wherever legal
 static int g_bf16_areg = -1;
 extern "C" void uemdbg_conv_bf16_areg(int v) { g_bf16_areg = v; }
-template <int KC>
-static bool pw_areg_go(const PwP& q, int npanels, hipStream_t st) {
-    constexpr int LDS = 2 * 64 * KC * 2 + 8 * 4096 * 2 + 2 * 8 * 2 * 64 * 4;
-    const int grid = npanels > 256 ? 256 : npanels;
-    if (q.tile_stats != nullptr) {
-        auto k = pw_bf16_areg_kernel<KC, true>;
-        if (!uem_allow_lds((const void*)k, LDS)) return false;
-        k<<<grid, 512, LDS, st>>>(q, npanels);
-    } else {
-        auto k = pw_bf16_areg_kernel<KC, false>;
-        if (!uem_allow_lds((const void*)k, LDS)) return false;
-        k<<<grid, 512, LDS, st>>>(q, npanels);
-    }
+template <int KC, bool STATS, int TAIL>
+static bool pw_areg_launch(const PwP& q, int npanels, int ngroups, hipStream_t st) {
+    const int LDS = 2 * 64 * KC * 2 + (TAIL ? 8 * 32 * 68 * 4 : 8 * 4096 * 2) + 2 * 8 * 2 * 64 * 4 + ((TAIL & 2) ? 2 * q.N * 4 : 0);
+    if (LDS > 160 * 1024) return false;
+    const int grid = npanels * ngroups > 256 ? 256 : npanels * ngroups;
+    auto k = pw_bf16_areg_kernel<KC, STATS, TAIL>;
+    if (!uem_allow_lds((const void*)k, LDS)) return false;
+    k<<<grid, 512, LDS, st>>>(q, npanels, ngroups);
     return true;
+}
+template <int KC>
+static bool pw_areg_go(const PwP& q, int npanels, int ngroups, int tail, hipStream_t st) {
+    switch (tail) {
+        case 1: return pw_areg_launch<KC, false, 1>(q, npanels, ngroups, st);
+        case 2: return pw_areg_launch<KC, false, 2>(q, npanels, ngroups, st);
+        case 3: return pw_areg_launch<KC, false, 3>(q, npanels, ngroups, st);
+        default: break;
+    }
+    return q.tile_stats != nullptr ? pw_areg_launch<KC, true, 0>(q, npanels, ngroups, st) : pw_areg_launch<KC, false, 0>(q, npanels, ngroups, st);
 }
 template <int MODE>
 static bool conv_bf16_areg_try(const ConvP& p, unsigned xb, unsigned wb, hipStream_t st) {
     static const int env = getenv("UEM_CONV_BF16_AREG") ? atoi(getenv("UEM_CONV_BF16_AREG")) : -1;
+    static const int env_tail = getenv("UEM_CONV_BF16_AREG_TAIL") ? atoi(getenv("UEM_CONV_BF16_AREG_TAIL")) : -1;
     const int set = g_bf16_areg >= 0 ? g_bf16_areg : env;
     const bool pointwise = p.KH * p.KW == 1 && p.pad == 0 && ((MODE == 1) ? (p.sub == 1 && p.stride == 1) : p.stride == 1);
-    if (set == 0 || !pointwise || p.M % 512 != 0 || p.Cout % 64 != 0 || p.accumulate) return false;
+    if (set == 0 || !pointwise || p.M % 512 != 0 || p.Cout % 64 != 0) return false;
     if (p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
-    if (MODE == 1 && (p.acc_src || p.tile_bnbwd)) return false;
     if (p.x_ld % 8 != 0 || p.y_ld % 8 != 0 || (((uintptr_t)p.x | (uintptr_t)p.y) & 15) != 0) return false;
-    if ((double)p.M * p.y_ld * 2.0 >= 4294967280.0 * 4.0) return false;
+    // the fused data-gradient tail: the identity gradient (through packed gate bits, or the tensor itself) and / or the BatchNorm-backward
+    // partial sums with the mask from packed bits; everything else those epilogues can do stays with conv_bf16_kernel
+    int tail = 0;
+    if (MODE == 1) {
+        if (p.accumulate) tail |= 1;
+        if (p.tile_bnbwd != nullptr) {
+            if (p.bn_bits == nullptr || p.bn_z == nullptr || p.bn_vec == nullptr || p.y_ld != p.Cout) return false;
+            tail |= 2;
+        }
+        if (p.acc_bits != nullptr && p.y_ld != p.Cout) return false;
+        // The tail forms are built, tested (tests/test_gpu_bf16.py, fixture "areg": fp64 references) and MEASURED SLOWER than
+        // conv_bf16_kernel's epilogue on every shape (profiles/r06_m_*: +20 ... +64 %): a tail is bound by its three 4C-wide streams, and a
+        // wave fetching one 8-row pass ahead keeps ~20 KB per CU in flight where the tiled kernel's block fetches a 64-row chunk ahead;
+        // at 256 reduction channels the A registers (128) + accumulators (64) + the epilogue's state no longer fit 256 VGPRs (the
+        // compiler moves 108 A registers to scratch and re-reads them per tile).  Never by rule: forced on only (set == 1).
+        if (tail != 0 && (set != 1 || env_tail == 0)) return false;
+        if (tail != 0 && (double)p.M * p.y_ld * 2.0 >= 4294967280.0) return false;           // the tail's streams use 32-bit buffer offsets
+    } else if (p.accumulate) {
+        return false;
+    }
     const int npanels = p.M / 512;
     // Rule (scripts/sweep_conv_bf16_ring.py SWEEP=areg, profiles/r06_m_conv_bf16_areg_sweep_*.txt; forced on = wherever legal): a reduction
     // of 128 or 256 channels, at least twice as many output columns, and a panel for every CU.  There it is 10-30 % faster than the tiled
@@ -2736,14 +2892,24 @@ static bool conv_bf16_areg_try(const ConvP& p, unsigned xb, unsigned wb, hipStre
     // shapes -12 ... -34 %).  It loses with 64 channels (+24 %: the A registers buy nothing, the 64-column tiles cost), with no more
     // columns than channels (256 -> 64 / 128: +27 %) and with fewer panels than CUs (256 -> 1024 at 512 x 512: 64 panels, +140 %).
     if (set != 1 && !(set < 0 && npanels >= 256 && p.Cout >= 2 * p.Cin && p.Cin >= 128)) return false;
+    // Fewer panels than CUs (forced on only): the panel's column tiles shared out over 2 / 4 / 8 blocks while each keeps at least four
+    // tiles.  Measured: 256 -> 1024 at 512 x 512 (64 panels x 4 groups of 4 tiles) 0.032 -> 0.036 ms instead of 0.072 without the
+    // groups -- a block that lives for four tiles spends as long loading its A rows and waiting for its first B tile: not by rule.
+    int ngroups = 1;
+    const int ntiles_n = p.Cout / 64;
+    while (npanels * ngroups < 256 && ngroups < 8 && ntiles_n % (2 * ngroups) == 0 && ntiles_n / (2 * ngroups) >= 4) ngroups *= 2;
     PwP q;
     q.A = reinterpret_cast<const unsigned short*>(p.x); q.B = reinterpret_cast<const unsigned short*>(p.w);
-    q.C = reinterpret_cast<unsigned short*>(p.y); q.tile_stats = MODE == 0 ? p.tile_stats : nullptr;
+    q.C = reinterpret_cast<unsigned short*>(p.y);
+    q.tile_stats = MODE == 0 ? p.tile_stats : ((tail & 2) ? p.tile_bnbwd : nullptr);
     q.M = p.M; q.N = p.Cout; q.K = p.Cin; q.lda = p.x_ld; q.ldc = p.y_ld; q.a_bytes = xb; q.b_bytes = wb;
+    q.acc = (tail & 1) ? (p.acc_src != nullptr ? reinterpret_cast<const unsigned short*>(p.acc_src) : q.C) : nullptr;
+    q.acc_bits = (tail & 1) ? p.acc_bits : nullptr;
+    q.bn_z = reinterpret_cast<const unsigned short*>(p.bn_z); q.bn_vec = p.bn_vec; q.bn_bits = p.bn_bits;
     switch (p.Cin) {
-        case 64: return pw_areg_go<64>(q, npanels, st);
-        case 128: return pw_areg_go<128>(q, npanels, st);
-        default: return pw_areg_go<256>(q, npanels, st);
+        case 64: return pw_areg_go<64>(q, npanels, ngroups, tail, st);
+        case 128: return pw_areg_go<128>(q, npanels, ngroups, tail, st);
+        default: return pw_areg_go<256>(q, npanels, ngroups, tail, st);
     }
 }
 // Ring of three operand stages on persistent 256-row blocks (conv_bf16_kernel<..., NST = 3>): full dense tiles, forward (plain / with the
