@@ -128,7 +128,7 @@ class DataParallel:
             raise ops.UemError(f"DataParallel: {self._bwd_calls} backward passes through the model since the last "
                                f"reduce_gradients() but only {self._fwd_calls} train-mode forwards were counted")
         last = self._bwd_calls == self._fwd_calls
-        two = bool(ops._FWD2) and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing()   # a captured step is sequential
+        two = bool(ops._FWD2) and torch.cuda.is_available()      # (also while capturing: events between capturing streams are graph edges)
         if two and not last:
             # the step's graphs may run their backward chains on two streams (ops, "two streams"): remember where this one stood
             ev = torch.cuda.Event()

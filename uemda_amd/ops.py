@@ -383,6 +383,20 @@ def shadow_grads_touched(owner):
             pass
 
 
+# The two-stream form inside a captured hipGraph (step.GraphedStep): the fork and the joins become graph edges -- two long branches, a
+# handful of cross edges (unlike the ~70 forks of a captured side stream, GRAPH_SIDE).  Built, tested (the replay equals the eager
+# step, tests/test_gpu_model.py) and measured (profiles/r06_n_hipgraph_two_streams.txt): the two-branch graph replays SLOWER than the
+# captured sequential step -- fp32 101.8 against 99.8 ms (eager 97.2-97.7), bf16 40.4 against 38.6 (eager 35.6-35.7), 2.1-2.5 ms of
+# host time per replay against 0.29: the runtime's launch of a graph with parallel branches costs more than the branches return.
+# Default off; UEM_GRAPH_TWO_STREAM=1 captures the fork.
+GRAPH_TWO_STREAM = os.environ.get("UEM_GRAPH_TWO_STREAM", "0") != "0"
+
+
+def stream_capturing(st):
+    with torch.cuda.stream(st):
+        return torch.cuda.is_current_stream_capturing()
+
+
 def grad_join():
     """Whoever reads or clears the gradient arena next (FusedSGD.step, clip_grad_norm_, DataParallel.reduce_gradients, zero_grad, the
     step after backward) calls this first: the current stream waits for the side stream's weight gradients and for the second
@@ -392,7 +406,9 @@ def grad_join():
         owner.fold_shadow_grads()
     if _FWD2:
         st = _FWD2.get(torch.cuda.current_device())
-        if st is not None and not torch.cuda.is_current_stream_capturing():
+        # while capturing: only a second stream that is part of the capture may (and must) be joined -- a dependency on a stream
+        # outside the capture would invalidate it
+        if st is not None and (not torch.cuda.is_current_stream_capturing() or stream_capturing(st)):
             torch.cuda.current_stream().wait_stream(st)
 
 

@@ -30,8 +30,17 @@ def _may_fork(model):
     """may this step's second train-mode forward run on its own stream?  (the predicate of forward_pair, without side effects)"""
     import torch
     from . import ops
-    return (ops.TWO_STREAM_FWD and getattr(model, "_uem_train_forwards", 0) >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok()
-            and torch.is_grad_enabled() and not ops.PROF.enabled and not torch.cuda.is_current_stream_capturing())
+    if not (ops.TWO_STREAM_FWD and getattr(model, "_uem_train_forwards", 0) >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok()
+            and torch.is_grad_enabled() and not ops.PROF.enabled):
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the fork becomes graph edges (ops.GRAPH_TWO_STREAM); the second stream, the shadow gradient arena
+        # and the full two-stream backward must exist from an eager forked step (nothing may be allocated for them while capturing)
+        # (not together with a captured side stream, ops.GRAPH_SIDE: ending such a capture -- side-stream forks off two branches --
+        # crashed inside the HIP runtime; each form alone captures and replays)
+        return bool(ops.GRAPH_TWO_STREAM and not ops.GRAPH_SIDE and ops.TWO_STREAM_BWD and ops._FWD2.get(torch.cuda.current_device()) is not None
+                    and getattr(model, "_grad_arena2", None) is not None)
+    return True
 
 
 def forward_pair(model, images_a, images_b, join=True):
@@ -39,8 +48,8 @@ def forward_pair(model, images_a, images_b, join=True):
     its own stream beside the first when nothing forbids it (ops.TWO_STREAM_FWD; Deeplabv2.two_stream_ok): the outputs, the BatchNorm
     running statistics and num_batches_tracked are those of the sequential pair, bit for bit.  The second graph's backward nodes run
     on the second stream too and accumulate into the model's shadow gradient arena, folded into .grad at the end of the backward
-    pass (ops, "two streams"; `ops.grad_join()` is what a caller who reads .grad right after backward may call).  Sequential while a
-    hipGraph is being captured, under per-launch event timing, and until the model has taken two training forwards (its derived
+    pass (ops, "two streams"; `ops.grad_join()` is what a caller who reads .grad right after backward may call).  Sequential under per-launch
+    event timing, while a hipGraph is being captured unless an eager forked step came before (ops.GRAPH_TWO_STREAM), and until the model has taken two training forwards (its derived
     filter banks exist from then on).
     join=False (ssl_step's two pipelines): returns (out_a, out_b, finish); out_b is then still in flight on `ops.second_stream()`, and
     `finish()` -- current stream behind the second stream, the second forward's running statistics applied -- is the caller's to call
