@@ -14,8 +14,8 @@ storage = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 use_ppm = len(sys.argv) > 2 and sys.argv[2] == "ppm"
 batch = {k: v.cuda() for k, v in synth.make_batch(B=2, H=256, W=256, C=C, k=2048, seed=9).items()}
 res = []
-for name, fwd, bwd in (("seq", 0, 0), ("seq2", 0, 0), ("seq3", 0, 0), ("two", 1, 1), ("two2", 1, 1), ("two3", 1, 1), ("fwdonly", 1, 0)):
-    ops.TWO_STREAM_FWD, ops.TWO_STREAM_BWD = bool(fwd), bool(bwd)
+for name, fwd, bwd in (("seq", 0, 0), ("seq2", 0, 0), ("seq3", 0, 0), ("two", 1, 1), ("two2", 1, 1), ("two3", 1, 1), ("fwdonly", 1, 0), ("pipe", 1, 2), ("pipe2", 1, 2), ("pipe3", 1, 2), ("pipe4", 1, 2)):
+    ops.TWO_STREAM_FWD, ops.TWO_STREAM_BWD, ops.TWO_PIPELINES = bool(fwd), bool(bwd), bwd == 2      # pipe*: the two-pipeline form of ssl_step
     model = _model(storage, use_ppm)
     if use_ppm:
         pass

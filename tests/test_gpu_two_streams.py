@@ -95,9 +95,11 @@ def test_ssl_steps_with_two_forward_streams_match_the_sequential_steps(storage, 
     # step 1 is sequential in both runs; the forward of step 2 sees weights that differ by atomics' order only
     assert torch.equal(o0[0]["pred_t1"], o1[0]["pred_t1"])
     for i in (1, 2):
-        # step 2, fp32: two sequential runs differ by up to 8e-6 (ASPP heads) / 1.1e-4 (PPM heads, gradient norm ~5000) of the loss
-        tol = (5e-3 if storage == "bf16" else 5e-4 if use_ppm else 5e-5) if i == 1 else 1e-1
+        # step 2, fp32: two sequential runs differ by up to 8e-6 (ASPP heads) / 1.1e-4 (PPM heads, gradient norm ~5000) of the loss; the
+        # target loss also moves in quanta -- one marginal pseudo label selected or not: 2.4e-4 on this batch, seen in forked and in
+        # sequential runs alike (profiles/r06_l_two_streams.txt)
         for k in ("loss_source", "loss_target"):
+            tol = (5e-3 if storage == "bf16" else 5e-4 if (use_ppm or k == "loss_target") else 5e-5) if i == 1 else 1e-1
             assert abs(float(o0[i][k]) - float(o1[i][k])) <= tol * max(1.0, abs(float(o0[i][k]))), (i, k)
         agree = (o0[i]["label_t_hard"] == o1[i]["label_t_hard"]).float().mean().item()
         assert agree >= ((0.99 if storage == "bf16" else 0.999) if i == 1 else 0.9), (i, agree)
