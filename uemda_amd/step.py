@@ -26,12 +26,23 @@ class StepState:
                                   ignore_label=hp["ignore_label"])
 
 
+def _fork_wanted(model):
+    """the host-side half of _may_fork: the switch, two training forwards behind the model (its derived filter banks exist), a model
+    whose BatchNorm layers allow it (Deeplabv2.two_stream_ok), a graph being recorded, no per-launch event timing"""
+    import torch
+    from . import ops
+    return bool(ops.TWO_STREAM_FWD and getattr(model, "_uem_train_forwards", 0) >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok()
+                and torch.is_grad_enabled() and not ops.PROF.enabled)
+
+
 def _may_fork(model):
     """may this step's second train-mode forward run on its own stream?  (the predicate of forward_pair, without side effects)"""
     import torch
     from . import ops
-    if not (ops.TWO_STREAM_FWD and getattr(model, "_uem_train_forwards", 0) >= 2 and hasattr(model, "two_stream_ok") and model.two_stream_ok()
-            and torch.is_grad_enabled() and not ops.PROF.enabled):
+    if not _fork_wanted(model):
+        return False
+    arena = getattr(model, "_arena", None)
+    if arena is None or not arena.is_cuda:
         return False
     if torch.cuda.is_current_stream_capturing():
         # inside a hipGraph capture the fork becomes graph edges (ops.GRAPH_TWO_STREAM); the second stream, the shadow gradient arena
