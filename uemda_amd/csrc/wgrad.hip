@@ -649,7 +649,11 @@ extern "C" int uem_conv2d_wgrad_bf16(const uint16_t* x, const uint16_t* dy, floa
     // 128 x 128 tiles on the largest pointwise filter banks (Cin * Cout >= 2^20: layer4's 2048 <-> 512 and its 1024 -> 2048 downsample,
     // -4 ... -15 % in the step; the smaller banks lose 15-30 % on them: fewer tiles, longer split-K slices).  UEM_WGRAD_BF16_TN128 = 0
     // off, 1 every pointwise layer, else the threshold on Cin * Cout.
-    static const int tn128 = getenv("UEM_WGRAD_BF16_TN128") ? atoi(getenv("UEM_WGRAD_BF16_TN128")) : (1 << 20);
+    // Round 6: with 131072 pixels and more per bank (the 1024 x 1024 configuration's layer3) the split-K slices are long enough for the
+    // mid-sized banks too (Cin * Cout >= 2^18: 1024 <-> 256): R101-1024^2 step 193.0 -> 190.5 ms, A-B-A on one box; 2^16 / 2^14 add
+    // nothing measurable (190.6 / 191.1 against 191.1-191.3).  At 512 x 512 those banks see 32768 pixels and keep 128 x 64.
+    static const int tn128_env = getenv("UEM_WGRAD_BF16_TN128") ? atoi(getenv("UEM_WGRAD_BF16_TN128")) : -1;
+    const int tn128 = tn128_env >= 0 ? tn128_env : (p.M >= 131072 ? (1 << 18) : (1 << 20));
     const bool pw = s->KH == 1 && s->KW == 1 && s->pad == 0 && s->stride == 1;
     if (tn128 && pw && s->Cout % 128 == 0 && s->Cin % 128 == 0 && (tn128 == 1 || s->Cin * s->Cout >= tn128)) {
         wgb_go<128, 128, 1, 1, 0, true, 64>(p, (hipStream_t)stream);     // the only 128 x 128 instantiation: linear 1x1, 64-pixel steps
