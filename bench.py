@@ -608,7 +608,8 @@ def main():
                                    f"{B if args.workload == 'ssl' else 0} target {S}x{S} tiles, {prec_text if args.storage == 'fp32' else 'bf16 storage in the encoder (bf16 MFMA, fp32 accumulate)'}, "
                                    f"random init; tiles counted = source + target; every tile of a batch is its own seeded tile, "
                                    f"{len(s.batches)} distinct batches alternate step by step; the last timed step also records "
-                                   f"per-launch HIP events (about 1 ms of command-processor bubbles)",
+                                   f"per-launch HIP events and therefore runs one kernel at a time (no side stream, no second graph stream: "
+                                   f"about 4 ms longer than the others)",
                        "global_batch": tiles_per_step, "tile": S, "parallelism": f"dp{world}",
                        "collective": None if wrapper is None else f"torch.distributed {args.backend}",
                        "collective_bytes_per_step": None if wrapper is None else arena_bytes + 4 * (6 * 2048 + 6),
